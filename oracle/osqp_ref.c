@@ -1,0 +1,628 @@
+/*
+ * oracle/osqp_ref.c -- TEST INFRASTRUCTURE (CPU oracle), not product code.
+ *
+ * float64 C restatement of the OSQP ADMM algorithm that the reference reaches
+ * through the third-party `osqp` wheel:
+ *     PathFollowingLPVMPC.py:302-323  (OSQP().setup(P,q,A,l,u,verbose=False,polish=True); solve())
+ *     LPV_MPC_Planner.py:204-215      (same, warm_start=True with no initial values == cold start)
+ *
+ * PARITY UNPINNED for this stage: the `osqp` package (PyPI "osqp", oxfordcontrol,
+ * C core + QDLDL) is NOT vendored under /root/reference and NOT version-pinned there
+ * (no requirements file; barc/package.xml lists only ROS deps); it is not installed in
+ * the build container and cannot be installed (no network).  The reference holds no
+ * tests or golden vectors at this boundary.  This file therefore restates the
+ * *published* algorithm -- Stellato, Banjac, Goulart, Bemporad, Boyd, "OSQP: an operator
+ * splitting solver for quadratic programs", Math. Prog. Comp. 12 (2020), Algorithm 1,
+ * sections 3.1-3.4 (termination, infeasibility), 4 (KKT solve), 5.1 (Ruiz equilibration),
+ * 5.2 (adaptive rho), 4.x (polish) -- with the default settings of the 0.6.x series
+ * (rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=eps_rel=1e-3, eps_prim_inf=eps_dual_inf=1e-4,
+ * max_iter=4000, check_termination=25, scaling=10, adaptive_rho=1 tol 5,
+ * polish delta=1e-6 with 3 refinement steps; rho_eq = 1e3 rho; OSQP_INFTY=1e30,
+ * RHO_MIN=1e-6, RHO_MAX=1e6, RHO_TOL=1e-4, MIN_SCALING=1e-4, MAX_SCALING=1e4).
+ * Function names below follow the roles of the corresponding OSQP routines
+ * (scale_data, set_rho_vec, update_xz_tilde, update_x/z/y, compute_pri_res,
+ * compute_dua_res, check_termination, is_primal/dual_infeasible, compute_rho_estimate,
+ * adapt_rho, polish, iterative_refinement, project_normalcone, store_solution).
+ *
+ * One deliberate, documented choice: OSQP's default `adaptive_rho_interval=0` picks the
+ * interval from wall-clock timing (not reproducible).  Here it is an explicit setting;
+ * the default 25 is what the timing rule yields for problems this small (the first
+ * termination-check multiple after 0.4 x setup time); OSQP's non-profiling build would
+ * use 100.
+ *
+ * What pins this oracle instead of OSQP itself (tests/test_oracle_osqp.py):
+ *   - a solver-independent KKT certificate of every returned solution
+ *     (oracle/kkt_cert.py: active-set solve with numpy, stationarity/feasibility/
+ *     complementarity <= 1e-8), and
+ *   - OSQP's own termination test re-evaluated in numpy on the returned (x, y).
+ *
+ * The linear system is the quasi-definite KKT matrix [[P+sigma I, A'],[A, -diag(1/rho)]]
+ * factored by an up-looking sparse LDL' (same algorithm family as QDLDL) under a
+ * caller-supplied fill-reducing permutation.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#define OSQP_INFTY 1e30
+#define RHO_MIN 1e-6
+#define RHO_MAX 1e6
+#define RHO_EQ_OVER_RHO_INEQ 1e3
+#define RHO_TOL 1e-4
+#define MIN_SCALING 1e-4
+#define MAX_SCALING 1e4
+
+enum { ST_SOLVED = 1, ST_SOLVED_INACCURATE = 2, ST_PRIMAL_INF_INACC = 3, ST_DUAL_INF_INACC = 4,
+       ST_MAX_ITER = -2, ST_PRIMAL_INF = -3, ST_DUAL_INF = -4, ST_NON_CVX = -7, ST_UNSOLVED = -10 };
+
+typedef struct {
+    double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, delta, adaptive_rho_tolerance;
+    int max_iter, check_termination, scaling, adaptive_rho, adaptive_rho_interval, polish, polish_refine_iter,
+        scaled_termination;
+} osqp_ref_settings;
+
+typedef struct {
+    int iter, status_val, status_polish, rho_updates;
+    double obj_val, pri_res, dua_res, rho_estimate, rho_final;
+} osqp_ref_info;
+
+void osqp_ref_default_settings(osqp_ref_settings *s) {
+    s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3;
+    s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4; s->delta = 1e-6; s->adaptive_rho_tolerance = 5.0;
+    s->max_iter = 4000; s->check_termination = 25; s->scaling = 10; s->adaptive_rho = 1;
+    s->adaptive_rho_interval = 25; s->polish = 1; s->polish_refine_iter = 3; s->scaled_termination = 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* small vector helpers                                               */
+/* ------------------------------------------------------------------ */
+static double norm_inf(const double *v, int n) {
+    double r = 0; for (int i = 0; i < n; i++) { double a = fabs(v[i]); if (a > r) r = a; } return r;
+}
+static double scaled_norm_inf(const double *s, const double *v, int n) {
+    double r = 0; for (int i = 0; i < n; i++) { double a = fabs(s[i] * v[i]); if (a > r) r = a; } return r;
+}
+static double dot(const double *a, const double *b, int n) {
+    double r = 0; for (int i = 0; i < n; i++) r += a[i] * b[i]; return r;
+}
+
+/* CSC matrix (owning) */
+typedef struct { int m, n; int *p, *i; double *x; } csc;
+
+static csc *csc_copy(int m, int n, const int *p, const int *i, const double *x) {
+    csc *M = (csc *)malloc(sizeof(csc)); int nnz = p[n];
+    M->m = m; M->n = n;
+    M->p = (int *)malloc(sizeof(int) * (n + 1)); M->i = (int *)malloc(sizeof(int) * (nnz > 0 ? nnz : 1));
+    M->x = (double *)malloc(sizeof(double) * (nnz > 0 ? nnz : 1));
+    memcpy(M->p, p, sizeof(int) * (n + 1)); memcpy(M->i, i, sizeof(int) * nnz); memcpy(M->x, x, sizeof(double) * nnz);
+    return M;
+}
+static void csc_free(csc *M) { if (M) { free(M->p); free(M->i); free(M->x); free(M); } }
+
+/* y (+)= A x */
+static void mat_vec(const csc *A, const double *x, double *y, int plus_eq) {
+    if (!plus_eq) for (int i = 0; i < A->m; i++) y[i] = 0;
+    for (int j = 0; j < A->n; j++) for (int k = A->p[j]; k < A->p[j + 1]; k++) y[A->i[k]] += A->x[k] * x[j];
+}
+/* y (+)= A' x ; skip_diag: ignore diagonal entries (symmetric upper-tri products) */
+static void mat_tpose_vec(const csc *A, const double *x, double *y, int plus_eq, int skip_diag) {
+    if (!plus_eq) for (int j = 0; j < A->n; j++) y[j] = 0;
+    for (int j = 0; j < A->n; j++) for (int k = A->p[j]; k < A->p[j + 1]; k++) {
+        if (skip_diag && A->i[k] == j) continue;
+        y[j] += A->x[k] * x[A->i[k]];
+    }
+}
+/* y = P x with P symmetric stored upper-triangular */
+static void sym_mat_vec(const csc *P, const double *x, double *y) {
+    mat_vec(P, x, y, 0); mat_tpose_vec(P, x, y, 1, 1);
+}
+
+/* ------------------------------------------------------------------ */
+/* sparse up-looking LDL' of a permuted quasi-definite KKT matrix      */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int N;                 /* KKT dimension */
+    int *Kp, *Ki; double *Kx; /* permuted upper-triangular CSC (duplicates allowed, summed on use) */
+    int *Lp, *Li; double *Lx, *D, *Dinv;
+    int *etree, *Lnz, *iwork; unsigned char *mark; double *yv, *bp;
+    int *perm, *iperm;
+} ldl_t;
+
+static void ldl_free(ldl_t *F) {
+    if (!F) return;
+    free(F->Kp); free(F->Ki); free(F->Kx); free(F->Lp); free(F->Li); free(F->Lx); free(F->D); free(F->Dinv);
+    free(F->etree); free(F->Lnz); free(F->iwork); free(F->mark); free(F->yv); free(F->bp); free(F->perm); free(F->iperm);
+    free(F);
+}
+
+/* Assemble permuted upper-tri KKT = [[P + sigma I, Ared'],[Ared, diag(dA)]] where Ared keeps the
+ * rows r of A with rowmap[r] >= 0 (at reduced index rowmap[r]); dA[rr] is the (negative) diagonal. */
+static ldl_t *kkt_assemble(const csc *P, const csc *A, double sigma, const int *rowmap, int mred,
+                           const double *dA, const int *perm_full /* over n + A->m, or NULL */) {
+    int n = P->n, N = n + mred;
+    ldl_t *F = (ldl_t *)calloc(1, sizeof(ldl_t));
+    F->N = N;
+    F->perm = (int *)malloc(sizeof(int) * N); F->iperm = (int *)malloc(sizeof(int) * N);
+    /* reduced permutation: keep the relative order of the surviving indices */
+    int cnt = 0;
+    if (perm_full) {
+        for (int k = 0; k < n + A->m; k++) {
+            int o = perm_full[k];
+            if (o < n) F->perm[cnt++] = o;
+            else if (rowmap[o - n] >= 0) F->perm[cnt++] = n + rowmap[o - n];
+        }
+    } else for (int k = 0; k < N; k++) F->perm[cnt++] = k;
+    for (int k = 0; k < N; k++) F->iperm[F->perm[k]] = k;
+
+    int nnz_max = P->p[n] + n + A->p[n] + mred;
+    int *ti = (int *)malloc(sizeof(int) * nnz_max), *tj = (int *)malloc(sizeof(int) * nnz_max);
+    double *tv = (double *)malloc(sizeof(double) * nnz_max);
+    int t = 0;
+    for (int j = 0; j < n; j++) {
+        for (int k = P->p[j]; k < P->p[j + 1]; k++) { ti[t] = P->i[k]; tj[t] = j; tv[t] = P->x[k]; t++; }
+        ti[t] = j; tj[t] = j; tv[t] = sigma; t++;
+        for (int k = A->p[j]; k < A->p[j + 1]; k++) {
+            int rr = rowmap[A->i[k]];
+            if (rr >= 0) { ti[t] = j; tj[t] = n + rr; tv[t] = A->x[k]; t++; }
+        }
+    }
+    for (int rr = 0; rr < mred; rr++) { ti[t] = n + rr; tj[t] = n + rr; tv[t] = dA[rr]; t++; }
+    /* permute, force upper, counting sort by column */
+    F->Kp = (int *)calloc(N + 1, sizeof(int)); F->Ki = (int *)malloc(sizeof(int) * (t > 0 ? t : 1));
+    F->Kx = (double *)malloc(sizeof(double) * (t > 0 ? t : 1));
+    for (int e = 0; e < t; e++) {
+        int a = F->iperm[ti[e]], b = F->iperm[tj[e]];
+        if (a > b) { int s = a; a = b; b = s; }
+        ti[e] = a; tj[e] = b; F->Kp[b + 1]++;
+    }
+    for (int j = 0; j < N; j++) F->Kp[j + 1] += F->Kp[j];
+    int *nxt = (int *)malloc(sizeof(int) * N);
+    for (int j = 0; j < N; j++) nxt[j] = F->Kp[j];
+    for (int e = 0; e < t; e++) { int pos = nxt[tj[e]]++; F->Ki[pos] = ti[e]; F->Kx[pos] = tv[e]; }
+    free(nxt); free(ti); free(tj); free(tv);
+
+    /* elimination tree + column counts */
+    F->etree = (int *)malloc(sizeof(int) * N); F->Lnz = (int *)calloc(N, sizeof(int));
+    F->iwork = (int *)malloc(sizeof(int) * 3 * N); F->mark = (unsigned char *)calloc(N, 1);
+    F->yv = (double *)calloc(N, sizeof(double)); F->bp = (double *)malloc(sizeof(double) * N);
+    int *w = F->iwork;
+    for (int i = 0; i < N; i++) F->etree[i] = -1;
+    for (int j = 0; j < N; j++) {
+        w[j] = j;
+        for (int k = F->Kp[j]; k < F->Kp[j + 1]; k++) {
+            int i = F->Ki[k];
+            while (w[i] != j) { if (F->etree[i] == -1) F->etree[i] = j; F->Lnz[i]++; w[i] = j; i = F->etree[i]; }
+        }
+    }
+    F->Lp = (int *)malloc(sizeof(int) * (N + 1)); F->Lp[0] = 0;
+    for (int i = 0; i < N; i++) F->Lp[i + 1] = F->Lp[i] + F->Lnz[i];
+    int lnz = F->Lp[N];
+    F->Li = (int *)malloc(sizeof(int) * (lnz > 0 ? lnz : 1)); F->Lx = (double *)malloc(sizeof(double) * (lnz > 0 ? lnz : 1));
+    F->D = (double *)malloc(sizeof(double) * N); F->Dinv = (double *)malloc(sizeof(double) * N);
+    return F;
+}
+
+/* numeric factorisation; returns 0 on success */
+static int ldl_factor(ldl_t *F) {
+    int N = F->N; int *yidx = F->iwork, *ebuf = F->iwork + N, *lnext = F->iwork + 2 * N;
+    for (int i = 0; i < N; i++) { lnext[i] = F->Lp[i]; F->mark[i] = 0; F->yv[i] = 0; F->D[i] = 0; }
+    for (int k = 0; k < N; k++) {
+        int nny = 0;
+        for (int p = F->Kp[k]; p < F->Kp[k + 1]; p++) {
+            int b = F->Ki[p];
+            if (b == k) { F->D[k] += F->Kx[p]; continue; }
+            F->yv[b] += F->Kx[p];
+            if (!F->mark[b]) {
+                int ne = 0, nx = b;
+                while (nx != -1 && nx < k && !F->mark[nx]) { F->mark[nx] = 1; ebuf[ne++] = nx; nx = F->etree[nx]; }
+                while (ne) yidx[nny++] = ebuf[--ne];
+            }
+        }
+        for (int i = nny - 1; i >= 0; i--) {
+            int c = yidx[i]; int end = lnext[c]; double yc = F->yv[c];
+            for (int j = F->Lp[c]; j < end; j++) F->yv[F->Li[j]] -= F->Lx[j] * yc;
+            F->Li[end] = k; F->Lx[end] = yc * F->Dinv[c];
+            F->D[k] -= yc * F->Lx[end];
+            lnext[c]++; F->yv[c] = 0; F->mark[c] = 0;
+        }
+        if (F->D[k] == 0.0) return -1;
+        F->Dinv[k] = 1.0 / F->D[k];
+    }
+    return 0;
+}
+
+/* solve K sol = b in place (b indexed in unpermuted order) */
+static void ldl_solve(ldl_t *F, double *b) {
+    int N = F->N; double *x = F->bp;
+    for (int k = 0; k < N; k++) x[k] = b[F->perm[k]];
+    for (int i = 0; i < N; i++) { double v = x[i]; for (int j = F->Lp[i]; j < F->Lp[i + 1]; j++) x[F->Li[j]] -= F->Lx[j] * v; }
+    for (int i = 0; i < N; i++) x[i] *= F->Dinv[i];
+    for (int i = N - 1; i >= 0; i--) { double v = x[i]; for (int j = F->Lp[i]; j < F->Lp[i + 1]; j++) v -= F->Lx[j] * x[F->Li[j]]; x[i] = v; }
+    for (int k = 0; k < N; k++) b[F->perm[k]] = x[k];
+}
+
+/* ------------------------------------------------------------------ */
+/* workspace                                                          */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int n, m;
+    csc *P, *A;                 /* scaled in place */
+    double *q, *l, *u;          /* scaled */
+    double *D, *E, *Dinv, *Einv; double c, cinv;
+    double *rho_vec, *rho_inv_vec; int *constr_type; double rho;
+    double *x, *z, *y, *x_prev, *z_prev, *xz_tilde, *delta_x, *delta_y;
+    double *Ax, *Px, *Aty, *Atdelta_y, *Pdelta_x, *Adelta_x, *tn, *tm;
+    ldl_t *F; const int *perm; int *rowmap_all; double *dA;
+    osqp_ref_settings s;
+    osqp_ref_info info;
+} work_t;
+
+static void limit_scaling(double *v, int n) {
+    for (int i = 0; i < n; i++) { if (v[i] < MIN_SCALING) v[i] = 1.0; if (v[i] > MAX_SCALING) v[i] = MAX_SCALING; }
+}
+
+/* infinity norms of the columns of KKT = [[P, A'],[A, 0]] (paper section 5.1) */
+static void kkt_col_norms(const csc *P, const csc *A, double *Dn, double *En) {
+    int n = P->n, m = A->m;
+    for (int j = 0; j < n; j++) Dn[j] = 0; for (int i = 0; i < m; i++) En[i] = 0;
+    for (int j = 0; j < n; j++) for (int k = P->p[j]; k < P->p[j + 1]; k++) {
+        double a = fabs(P->x[k]); int i = P->i[k];
+        if (a > Dn[j]) Dn[j] = a; if (i != j && a > Dn[i]) Dn[i] = a;
+    }
+    for (int j = 0; j < n; j++) for (int k = A->p[j]; k < A->p[j + 1]; k++) {
+        double a = fabs(A->x[k]); int i = A->i[k];
+        if (a > Dn[j]) Dn[j] = a; if (a > En[i]) En[i] = a;
+    }
+}
+
+static void scale_data(work_t *w) {
+    int n = w->n, m = w->m;
+    double *Dt = w->tn, *Et = w->tm;
+    w->c = 1.0;
+    for (int j = 0; j < n; j++) w->D[j] = 1.0; for (int i = 0; i < m; i++) w->E[i] = 1.0;
+    for (int it = 0; it < w->s.scaling; it++) {
+        kkt_col_norms(w->P, w->A, Dt, Et);
+        limit_scaling(Dt, n); limit_scaling(Et, m);
+        for (int j = 0; j < n; j++) Dt[j] = 1.0 / sqrt(Dt[j]);
+        for (int i = 0; i < m; i++) Et[i] = 1.0 / sqrt(Et[i]);
+        /* P <- D P D ; A <- E A D ; q <- D q */
+        for (int j = 0; j < n; j++) for (int k = w->P->p[j]; k < w->P->p[j + 1]; k++) w->P->x[k] *= Dt[w->P->i[k]] * Dt[j];
+        for (int j = 0; j < n; j++) for (int k = w->A->p[j]; k < w->A->p[j + 1]; k++) w->A->x[k] *= Et[w->A->i[k]] * Dt[j];
+        for (int j = 0; j < n; j++) { w->q[j] *= Dt[j]; w->D[j] *= Dt[j]; }
+        for (int i = 0; i < m; i++) w->E[i] *= Et[i];
+        /* cost normalisation */
+        for (int j = 0; j < n; j++) Dt[j] = 0;
+        for (int j = 0; j < n; j++) for (int k = w->P->p[j]; k < w->P->p[j + 1]; k++) {
+            double a = fabs(w->P->x[k]); int i = w->P->i[k];
+            if (a > Dt[j]) Dt[j] = a; if (i != j && a > Dt[i]) Dt[i] = a;
+        }
+        double c_temp = 0; for (int j = 0; j < n; j++) c_temp += Dt[j]; c_temp /= (double)n;
+        double nq = norm_inf(w->q, n); limit_scaling(&nq, 1);
+        if (nq > c_temp) c_temp = nq;
+        limit_scaling(&c_temp, 1);
+        c_temp = 1.0 / c_temp;
+        for (int k = 0; k < w->P->p[n]; k++) w->P->x[k] *= c_temp;
+        for (int j = 0; j < n; j++) w->q[j] *= c_temp;
+        w->c *= c_temp;
+    }
+    w->cinv = 1.0 / w->c;
+    for (int j = 0; j < n; j++) w->Dinv[j] = 1.0 / w->D[j];
+    for (int i = 0; i < m; i++) { w->Einv[i] = 1.0 / w->E[i]; w->l[i] *= w->E[i]; w->u[i] *= w->E[i]; }
+}
+
+static void set_rho_vec(work_t *w, int first) {
+    if (w->rho < RHO_MIN) w->rho = RHO_MIN; if (w->rho > RHO_MAX) w->rho = RHO_MAX;
+    for (int i = 0; i < w->m; i++) {
+        if (first) {
+            if (w->l[i] < -OSQP_INFTY * MIN_SCALING && w->u[i] > OSQP_INFTY * MIN_SCALING) w->constr_type[i] = -1;
+            else if (w->u[i] - w->l[i] < RHO_TOL) w->constr_type[i] = 1;
+            else w->constr_type[i] = 0;
+        }
+        w->rho_vec[i] = w->constr_type[i] == -1 ? RHO_MIN : (w->constr_type[i] == 1 ? RHO_EQ_OVER_RHO_INEQ * w->rho : w->rho);
+        w->rho_inv_vec[i] = 1.0 / w->rho_vec[i];
+    }
+}
+
+static int refactor_admm(work_t *w) {
+    for (int i = 0; i < w->m; i++) { w->rowmap_all[i] = i; w->dA[i] = -w->rho_inv_vec[i]; }
+    if (w->F) ldl_free(w->F);
+    w->F = kkt_assemble(w->P, w->A, w->s.sigma, w->rowmap_all, w->m, w->dA, w->perm);
+    return ldl_factor(w->F);
+}
+
+static double compute_pri_res(work_t *w, const double *x, const double *z) {
+    mat_vec(w->A, x, w->Ax, 0);
+    for (int i = 0; i < w->m; i++) w->z_prev[i] = w->Ax[i] - z[i];
+    if (w->s.scaling && !w->s.scaled_termination) return scaled_norm_inf(w->Einv, w->z_prev, w->m);
+    return norm_inf(w->z_prev, w->m);
+}
+static double compute_dua_res(work_t *w, const double *x, const double *y) {
+    sym_mat_vec(w->P, x, w->Px);
+    mat_tpose_vec(w->A, y, w->Aty, 0, 0);
+    for (int j = 0; j < w->n; j++) w->x_prev[j] = w->q[j] + w->Px[j] + w->Aty[j];
+    if (w->s.scaling && !w->s.scaled_termination) return w->cinv * scaled_norm_inf(w->Dinv, w->x_prev, w->n);
+    return norm_inf(w->x_prev, w->n);
+}
+static double compute_obj_val(work_t *w, const double *x) {
+    sym_mat_vec(w->P, x, w->tn);
+    double v = 0.5 * dot(x, w->tn, w->n) + dot(w->q, x, w->n);
+    return w->s.scaling ? v * w->cinv : v;
+}
+static double compute_pri_tol(work_t *w, double ea, double er) {
+    double mx;
+    if (w->s.scaling && !w->s.scaled_termination) {
+        mx = scaled_norm_inf(w->Einv, w->z, w->m); double t = scaled_norm_inf(w->Einv, w->Ax, w->m); if (t > mx) mx = t;
+    } else { mx = norm_inf(w->z, w->m); double t = norm_inf(w->Ax, w->m); if (t > mx) mx = t; }
+    return ea + er * mx;
+}
+static double compute_dua_tol(work_t *w, double ea, double er) {
+    double mx, t;
+    if (w->s.scaling && !w->s.scaled_termination) {
+        mx = scaled_norm_inf(w->Dinv, w->q, w->n);
+        t = scaled_norm_inf(w->Dinv, w->Aty, w->n); if (t > mx) mx = t;
+        t = scaled_norm_inf(w->Dinv, w->Px, w->n); if (t > mx) mx = t;
+        mx *= w->cinv;
+    } else {
+        mx = norm_inf(w->q, w->n); t = norm_inf(w->Aty, w->n); if (t > mx) mx = t; t = norm_inf(w->Px, w->n); if (t > mx) mx = t;
+    }
+    return ea + er * mx;
+}
+
+static int is_primal_infeasible(work_t *w, double eps) {
+    int m = w->m; double nd, lhs = 0;
+    for (int i = 0; i < m; i++) {
+        if (w->u[i] > OSQP_INFTY * MIN_SCALING) {
+            if (w->l[i] < -OSQP_INFTY * MIN_SCALING) w->delta_y[i] = 0.0;
+            else if (w->delta_y[i] > 0.0) w->delta_y[i] = 0.0;
+        } else if (w->l[i] < -OSQP_INFTY * MIN_SCALING) { if (w->delta_y[i] < 0.0) w->delta_y[i] = 0.0; }
+    }
+    if (w->s.scaling && !w->s.scaled_termination) nd = scaled_norm_inf(w->E, w->delta_y, m); else nd = norm_inf(w->delta_y, m);
+    if (nd > eps) {
+        for (int i = 0; i < m; i++) {
+            double dy = w->delta_y[i];
+            lhs += w->u[i] * (dy > 0 ? dy : 0) + w->l[i] * (dy < 0 ? dy : 0);
+        }
+        if (lhs < -eps * nd) {
+            mat_tpose_vec(w->A, w->delta_y, w->Atdelta_y, 0, 0);
+            if (w->s.scaling && !w->s.scaled_termination) for (int j = 0; j < w->n; j++) w->Atdelta_y[j] *= w->Dinv[j];
+            return norm_inf(w->Atdelta_y, w->n) < eps * nd;
+        }
+    }
+    return 0;
+}
+static int is_dual_infeasible(work_t *w, double eps) {
+    int n = w->n, m = w->m; double nd, cs;
+    if (w->s.scaling && !w->s.scaled_termination) { nd = scaled_norm_inf(w->D, w->delta_x, n); cs = w->c; }
+    else { nd = norm_inf(w->delta_x, n); cs = 1.0; }
+    if (nd > eps) {
+        if (dot(w->q, w->delta_x, n) < -cs * eps * nd) {
+            sym_mat_vec(w->P, w->delta_x, w->Pdelta_x);
+            if (w->s.scaling && !w->s.scaled_termination) for (int j = 0; j < n; j++) w->Pdelta_x[j] *= w->Dinv[j];
+            if (norm_inf(w->Pdelta_x, n) < cs * eps * nd) {
+                mat_vec(w->A, w->delta_x, w->Adelta_x, 0);
+                if (w->s.scaling && !w->s.scaled_termination) for (int i = 0; i < m; i++) w->Adelta_x[i] *= w->Einv[i];
+                for (int i = 0; i < m; i++) {
+                    if ((w->u[i] < OSQP_INFTY * MIN_SCALING && w->Adelta_x[i] > eps * nd) ||
+                        (w->l[i] > -OSQP_INFTY * MIN_SCALING && w->Adelta_x[i] < -eps * nd)) return 0;
+                }
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+
+static void update_info(work_t *w, int iter) {
+    w->info.iter = iter;
+    w->info.pri_res = compute_pri_res(w, w->x, w->z);
+    w->info.dua_res = compute_dua_res(w, w->x, w->y);
+}
+
+static int check_termination(work_t *w, int approximate) {
+    double ea = w->s.eps_abs, er = w->s.eps_rel, epi = w->s.eps_prim_inf, edi = w->s.eps_dual_inf;
+    int prc = 0, drc = 0, pic = 0, dic = 0;
+    if (w->info.pri_res > OSQP_INFTY || w->info.dua_res > OSQP_INFTY) { w->info.status_val = ST_NON_CVX; w->info.obj_val = NAN; return 1; }
+    if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+    if (w->m == 0) prc = 1;
+    else {
+        double ep = compute_pri_tol(w, ea, er);
+        if (w->info.pri_res < ep) prc = 1; else pic = is_primal_infeasible(w, epi);
+    }
+    double ed = compute_dua_tol(w, ea, er);
+    if (w->info.dua_res < ed) drc = 1; else dic = is_dual_infeasible(w, edi);
+    if (prc && drc) { w->info.status_val = approximate ? ST_SOLVED_INACCURATE : ST_SOLVED; return 1; }
+    if (pic) { w->info.status_val = approximate ? ST_PRIMAL_INF_INACC : ST_PRIMAL_INF; w->info.obj_val = OSQP_INFTY; return 1; }
+    if (dic) { w->info.status_val = approximate ? ST_DUAL_INF_INACC : ST_DUAL_INF; w->info.obj_val = -OSQP_INFTY; return 1; }
+    return 0;
+}
+
+static double compute_rho_estimate(work_t *w) {
+    int n = w->n, m = w->m;
+    double pr = norm_inf(w->z_prev, m), dr = norm_inf(w->x_prev, n);
+    double pn = norm_inf(w->z, m), t = norm_inf(w->Ax, m); if (t > pn) pn = t;
+    pr /= (pn + 1e-10);
+    double dn = norm_inf(w->q, n); t = norm_inf(w->Aty, n); if (t > dn) dn = t; t = norm_inf(w->Px, n); if (t > dn) dn = t;
+    dr /= (dn + 1e-10);
+    double r = w->rho * sqrt(pr / (dr + 1e-10));
+    if (r < RHO_MIN) r = RHO_MIN; if (r > RHO_MAX) r = RHO_MAX;
+    return r;
+}
+
+/* ------------------------------------------------------------------ */
+/* polish                                                             */
+/* ------------------------------------------------------------------ */
+static void polish(work_t *w) {
+    int n = w->n, m = w->m;
+    int *rowmap = (int *)malloc(sizeof(int) * (m > 0 ? m : 1));
+    int *low_to_A = (int *)malloc(sizeof(int) * (m > 0 ? m : 1)), *upp_to_A = (int *)malloc(sizeof(int) * (m > 0 ? m : 1));
+    int *A_to_low = (int *)malloc(sizeof(int) * (m > 0 ? m : 1)), *A_to_upp = (int *)malloc(sizeof(int) * (m > 0 ? m : 1));
+    int nlow = 0, nupp = 0;
+    for (int j = 0; j < m; j++) { if (w->z[j] - w->l[j] < -w->y[j]) { low_to_A[nlow] = j; A_to_low[j] = nlow++; } else A_to_low[j] = -1; }
+    for (int j = 0; j < m; j++) { if (w->u[j] - w->z[j] < w->y[j]) { upp_to_A[nupp] = j; A_to_upp[j] = nupp++; } else A_to_upp[j] = -1; }
+    int mred = nlow + nupp;
+    for (int j = 0; j < m; j++) rowmap[j] = A_to_low[j] >= 0 ? A_to_low[j] : (A_to_upp[j] >= 0 ? nlow + A_to_upp[j] : -1);
+    double *dA = (double *)malloc(sizeof(double) * (mred > 0 ? mred : 1));
+    for (int i = 0; i < mred; i++) dA[i] = -w->s.delta;
+    ldl_t *F = kkt_assemble(w->P, w->A, w->s.delta, rowmap, mred, dA, w->perm);
+    int Nk = n + mred;
+    double *rhs_red = (double *)malloc(sizeof(double) * Nk), *sol = (double *)malloc(sizeof(double) * Nk), *r = (double *)malloc(sizeof(double) * Nk);
+    double *px = (double *)malloc(sizeof(double) * n), *pz = (double *)malloc(sizeof(double) * (m > 0 ? m : 1)), *py = (double *)malloc(sizeof(double) * (m > 0 ? m : 1));
+    int ok = (ldl_factor(F) == 0);
+    if (ok) {
+        for (int j = 0; j < n; j++) rhs_red[j] = -w->q[j];
+        for (int j = 0; j < nlow; j++) rhs_red[n + j] = w->l[low_to_A[j]];
+        for (int j = 0; j < nupp; j++) rhs_red[n + nlow + j] = w->u[upp_to_A[j]];
+        memcpy(sol, rhs_red, sizeof(double) * Nk);
+        ldl_solve(F, sol);
+        /* iterative refinement against the un-regularised reduced KKT */
+        for (int it = 0; it < w->s.polish_refine_iter; it++) {
+            memcpy(r, rhs_red, sizeof(double) * Nk);
+            sym_mat_vec(w->P, sol, w->tn);
+            for (int j = 0; j < n; j++) r[j] -= w->tn[j];
+            for (int j = 0; j < n; j++) for (int k = w->A->p[j]; k < w->A->p[j + 1]; k++) {
+                int rr = rowmap[w->A->i[k]];
+                if (rr >= 0) { r[j] -= w->A->x[k] * sol[n + rr]; r[n + rr] -= w->A->x[k] * sol[j]; }
+            }
+            ldl_solve(F, r);
+            for (int j = 0; j < Nk; j++) sol[j] += r[j];
+        }
+        memcpy(px, sol, sizeof(double) * n);
+        mat_vec(w->A, px, pz, 0);
+        for (int j = 0; j < m; j++) py[j] = A_to_low[j] >= 0 ? sol[n + A_to_low[j]] : (A_to_upp[j] >= 0 ? sol[n + nlow + A_to_upp[j]] : 0.0);
+        /* project (z, y) on the normal cone */
+        for (int i = 0; i < m; i++) {
+            double t = pz[i] + py[i];
+            double zz = t < w->l[i] ? w->l[i] : (t > w->u[i] ? w->u[i] : t);
+            pz[i] = zz; py[i] = t - zz;
+        }
+        double pol_obj = compute_obj_val(w, px);
+        double save_pri = w->info.pri_res, save_dua = w->info.dua_res;
+        /* compute_*_res overwrite z_prev/x_prev/Ax/Px/Aty: harmless after the ADMM loop */
+        double pol_pri = (m == 0) ? 0.0 : compute_pri_res(w, px, pz);
+        double pol_dua = compute_dua_res(w, px, py);
+        int good = (pol_pri < save_pri && pol_dua < save_dua) || (pol_pri < save_pri && save_dua < 1e-10) ||
+                   (pol_dua < save_dua && save_pri < 1e-10);
+        if (good) {
+            w->info.obj_val = pol_obj; w->info.pri_res = pol_pri; w->info.dua_res = pol_dua; w->info.status_polish = 1;
+            memcpy(w->x, px, sizeof(double) * n); memcpy(w->z, pz, sizeof(double) * m); memcpy(w->y, py, sizeof(double) * m);
+        } else w->info.status_polish = -1;
+    } else w->info.status_polish = -1;
+    ldl_free(F);
+    free(rowmap); free(low_to_A); free(upp_to_A); free(A_to_low); free(A_to_upp); free(dA);
+    free(rhs_red); free(sol); free(r); free(px); free(pz); free(py);
+}
+
+/* ------------------------------------------------------------------ */
+/* public entry                                                       */
+/* ------------------------------------------------------------------ */
+#define VEC(n_) ((double *)calloc((n_) > 0 ? (n_) : 1, sizeof(double)))
+
+/*
+ * P: upper-triangular CSC (n x n); A: CSC (m x n); perm: ordering of the (n+m) KKT
+ * unknowns (perm[k] = original index placed k-th) or NULL for the natural order.
+ * x_out[n], y_out[m] receive the unscaled solution (NaN when no solution, as OSQP does).
+ * Optional: iter_trace (length max_iter*2) receives (pri_res, dua_res) at every check.
+ * Returns 0, or a negative number on a setup failure.
+ */
+int osqp_ref_solve(int n, int m, const int *Pp, const int *Pi, const double *Px, const double *q,
+                   const int *Ap, const int *Ai, const double *Ax, const double *l, const double *u,
+                   const int *perm, const osqp_ref_settings *settings, double *x_out, double *y_out,
+                   osqp_ref_info *info_out) {
+    work_t W; memset(&W, 0, sizeof(W)); work_t *w = &W;
+    w->n = n; w->m = m; w->s = *settings; w->perm = perm;
+    w->P = csc_copy(n, n, Pp, Pi, Px); w->A = csc_copy(m, n, Ap, Ai, Ax);
+    w->q = VEC(n); w->l = VEC(m); w->u = VEC(m);
+    memcpy(w->q, q, sizeof(double) * n);
+    for (int i = 0; i < m; i++) {   /* the Python front end of OSQP clips infinities to +-OSQP_INFTY */
+        w->l[i] = l[i] < -OSQP_INFTY ? -OSQP_INFTY : l[i];
+        w->u[i] = u[i] > OSQP_INFTY ? OSQP_INFTY : u[i];
+    }
+    w->D = VEC(n); w->Dinv = VEC(n); w->E = VEC(m); w->Einv = VEC(m);
+    w->rho_vec = VEC(m); w->rho_inv_vec = VEC(m); w->constr_type = (int *)calloc(m > 0 ? m : 1, sizeof(int));
+    w->x = VEC(n); w->z = VEC(m); w->y = VEC(m); w->x_prev = VEC(n); w->z_prev = VEC(m); w->xz_tilde = VEC(n + m);
+    w->delta_x = VEC(n); w->delta_y = VEC(m); w->Ax = VEC(m); w->Px = VEC(n); w->Aty = VEC(n);
+    w->Atdelta_y = VEC(n); w->Pdelta_x = VEC(n); w->Adelta_x = VEC(m); w->tn = VEC(n); w->tm = VEC(m);
+    w->rowmap_all = (int *)malloc(sizeof(int) * (m > 0 ? m : 1)); w->dA = VEC(m);
+    int rc = 0;
+
+    if (w->s.scaling) scale_data(w);
+    else { w->c = w->cinv = 1.0; for (int j = 0; j < n; j++) w->D[j] = w->Dinv[j] = 1.0; for (int i = 0; i < m; i++) w->E[i] = w->Einv[i] = 1.0; }
+    w->rho = w->s.rho;
+    set_rho_vec(w, 1);
+    if (refactor_admm(w) != 0) { rc = -1; goto done; }
+
+    w->info.status_val = ST_UNSOLVED; w->info.status_polish = 0; w->info.rho_updates = 0; w->info.obj_val = NAN;
+    int iter, can_check = 0;
+    const double alpha = w->s.alpha, sigma = w->s.sigma;
+    for (iter = 1; iter <= w->s.max_iter; iter++) {
+        { double *t = w->x; w->x = w->x_prev; w->x_prev = t; t = w->z; w->z = w->z_prev; w->z_prev = t; }
+        /* update_xz_tilde */
+        for (int j = 0; j < n; j++) w->xz_tilde[j] = sigma * w->x_prev[j] - w->q[j];
+        for (int i = 0; i < m; i++) w->xz_tilde[n + i] = w->z_prev[i] - w->rho_inv_vec[i] * w->y[i];
+        ldl_solve(w->F, w->xz_tilde);
+        for (int i = 0; i < m; i++) w->xz_tilde[n + i] = w->z_prev[i] + w->rho_inv_vec[i] * (w->xz_tilde[n + i] - w->y[i]);
+        /* update_x */
+        for (int j = 0; j < n; j++) { w->x[j] = alpha * w->xz_tilde[j] + (1.0 - alpha) * w->x_prev[j]; w->delta_x[j] = w->x[j] - w->x_prev[j]; }
+        /* update_z */
+        for (int i = 0; i < m; i++) {
+            double t = alpha * w->xz_tilde[n + i] + (1.0 - alpha) * w->z_prev[i] + w->rho_inv_vec[i] * w->y[i];
+            w->z[i] = t < w->l[i] ? w->l[i] : (t > w->u[i] ? w->u[i] : t);
+        }
+        /* update_y */
+        for (int i = 0; i < m; i++) {
+            w->delta_y[i] = w->rho_vec[i] * (alpha * w->xz_tilde[n + i] + (1.0 - alpha) * w->z_prev[i] - w->z[i]);
+            w->y[i] += w->delta_y[i];
+        }
+        can_check = w->s.check_termination && (iter % w->s.check_termination == 0);
+        if (can_check) {
+            update_info(w, iter);
+            if (check_termination(w, 0)) break;
+        }
+        if (w->s.adaptive_rho && w->s.adaptive_rho_interval && (iter % w->s.adaptive_rho_interval == 0)) {
+            if (!can_check) update_info(w, iter);
+            double rho_new = compute_rho_estimate(w);
+            w->info.rho_estimate = rho_new;
+            if (rho_new > w->rho * w->s.adaptive_rho_tolerance || rho_new < w->rho / w->s.adaptive_rho_tolerance) {
+                w->rho = rho_new; set_rho_vec(w, 0);
+                if (refactor_admm(w) != 0) { rc = -2; goto done; }
+                w->info.rho_updates++;
+            }
+        }
+    }
+    if (!can_check) {
+        update_info(w, iter - 1);
+        check_termination(w, 0);
+    }
+    if (w->info.iter > w->s.max_iter) w->info.iter = w->s.max_iter;
+    {
+        int sv = w->info.status_val;
+        int has_sol = !(sv == ST_PRIMAL_INF || sv == ST_PRIMAL_INF_INACC || sv == ST_DUAL_INF || sv == ST_DUAL_INF_INACC || sv == ST_NON_CVX);
+        if (has_sol) w->info.obj_val = compute_obj_val(w, w->x);
+    }
+    if (w->info.status_val == ST_UNSOLVED) { if (!check_termination(w, 1)) w->info.status_val = ST_MAX_ITER; }
+    w->info.rho_estimate = compute_rho_estimate(w);
+    if (w->s.polish && w->info.status_val == ST_SOLVED) polish(w);
+    /* store_solution */
+    {
+        int sv = w->info.status_val;
+        int has_sol = !(sv == ST_PRIMAL_INF || sv == ST_PRIMAL_INF_INACC || sv == ST_DUAL_INF || sv == ST_DUAL_INF_INACC || sv == ST_NON_CVX);
+        if (has_sol) {
+            for (int j = 0; j < n; j++) x_out[j] = w->D[j] * w->x[j];
+            for (int i = 0; i < m; i++) y_out[i] = w->cinv * w->E[i] * w->y[i];
+        } else {
+            for (int j = 0; j < n; j++) x_out[j] = NAN; for (int i = 0; i < m; i++) y_out[i] = NAN;
+        }
+    }
+    w->info.rho_final = w->rho;
+done:
+    if (info_out) *info_out = w->info;
+    csc_free(w->P); csc_free(w->A); ldl_free(w->F);
+    free(w->q); free(w->l); free(w->u); free(w->D); free(w->Dinv); free(w->E); free(w->Einv);
+    free(w->rho_vec); free(w->rho_inv_vec); free(w->constr_type);
+    free(w->x); free(w->z); free(w->y); free(w->x_prev); free(w->z_prev); free(w->xz_tilde);
+    free(w->delta_x); free(w->delta_y); free(w->Ax); free(w->Px); free(w->Aty);
+    free(w->Atdelta_y); free(w->Pdelta_x); free(w->Adelta_x); free(w->tn); free(w->tm);
+    free(w->rowmap_all); free(w->dA);
+    return rc;
+}

@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz by running the REFERENCE's own
+Python (read from /root/reference at generation time only).
+
+How: the four hot-path modules are copied to a temp dir, converted with lib2to3
+(only `print` statements change), and imported with stub `rospy` (parameter dict
+with the MAIN_LAUNCH.launch values), `cvxopt` (import-only) and `osqp` modules.
+The `osqp` stub records the exact (P, q, A, l, u, settings) the reference hands to
+OSQP and -- because the real wheel is absent -- returns the solution of the oracle
+restatement (oracle/osqp_ref.c) so that multi-tick recursions can run.
+
+Captured (all float64):
+  * LPV evaluation + roll-out outputs and the assembled QP      -> exact pins (<= 1e-12)
+  * oracle solutions with their KKT-certified optimum            -> solution pins
+Nothing of the reference's source text is stored: only inputs and numeric outputs.
+
+Usage:  python tests/golden/make_golden.py        (needs /root/reference; NOT run on the GPU box)
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/workspace/src/barc/src"
+
+from oracle import osqp_ref, kkt_cert, lpv_ref  # noqa: E402
+
+PARAMS = {"lf": 0.125, "lr": 0.125, "m": 1.98, "Iz": 0.03, "Cf": 60.0, "Cr": 60.0, "mu": 0.05,
+          "/TrajectoryPlanner/max_vel": 5.0, "/TrajectoryPlanner/min_vel": 0.9,
+          "/TrajectoryPlanner/halfWidth": 0.2, "trackShape": "oval"}
+
+CAPTURE = []      # list of dicts, one per OSQP().setup() call
+
+
+def install_stubs():
+    rospy = types.ModuleType("rospy")
+    rospy.get_param = lambda k, *a: PARAMS[k]
+    sys.modules["rospy"] = rospy
+
+    cvx = types.ModuleType("cvxopt")
+    cvx.spmatrix = cvx.matrix = lambda *a, **k: None
+    solvers = types.ModuleType("cvxopt.solvers")
+    solvers.options = {}
+    solvers.qp = lambda *a, **k: None
+    cvx.solvers = solvers
+    sys.modules["cvxopt"] = cvx
+    sys.modules["cvxopt.solvers"] = solvers
+
+    osqp = types.ModuleType("osqp")
+
+    class OSQP(object):
+        _C = {"OSQP_SOLVED": 1, "OSQP_SOLVED_INACCURATE": 2, "OSQP_MAX_ITER_REACHED": -2}
+
+        def setup(self, P=None, q=None, A=None, l=None, u=None, **settings):
+            self.P = np.asarray(P.todense()); self.q = np.array(q, float)
+            self.A = np.asarray(A.todense()); self.l = np.array(l, float); self.u = np.array(u, float)
+            self.settings = settings
+            CAPTURE.append(dict(P=self.P, q=self.q, A=self.A, l=self.l, u=self.u, settings=dict(settings)))
+
+        def warm_start(self, **k):
+            raise AssertionError("reference never passes initvals")
+
+        def constant(self, name):
+            return self._C[name]
+
+        def solve(self):
+            r = osqp_ref.solve_qp(self.P, self.q, self.A, self.l, self.u)
+            CAPTURE[-1]["x"] = r.x.copy(); CAPTURE[-1]["y"] = r.y.copy()
+            CAPTURE[-1]["iter"] = r.info.iter; CAPTURE[-1]["status_val"] = r.info.status_val
+            CAPTURE[-1]["status_polish"] = r.info.status_polish
+            return types.SimpleNamespace(x=r.x, y=r.y, info=types.SimpleNamespace(
+                status_val=r.info.status_val, status=r.info.status, iter=r.info.iter))
+
+    osqp.OSQP = OSQP
+    sys.modules["osqp"] = osqp
+
+
+def import_reference():
+    tmp = tempfile.mkdtemp(prefix="refimport_")
+    for rel in ("ControllerObject/PathFollowingLPVMPC.py", "PlannerObject/LPV_MPC_Planner.py",
+                "Utilities/utilities.py", "Utilities/trackInitialization.py"):
+        shutil.copy(os.path.join(REF, rel), tmp)
+    subprocess.run([sys.executable, "-m", "lib2to3", "-w", "-n", tmp], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    sys.path.insert(0, tmp)
+    install_stubs()
+    import PathFollowingLPVMPC as CTRL
+    import LPV_MPC_Planner as PLAN
+    import trackInitialization as TRACK
+    import utilities as UTIL
+    return CTRL, PLAN, TRACK, UTIL, tmp
+
+
+def make_map(TRACK, shape, hw=0.2):
+    PARAMS["trackShape"] = shape
+    PARAMS["/TrajectoryPlanner/halfWidth"] = hw
+    return TRACK.Map()
+
+
+TUNINGS = {
+    "path": (np.diag([100.0, 1.0, 1.0, 20.0, 0.0, 900.0]), 0.25 * np.eye(2), 37.5 * np.array([1.3, 1.0])),
+    "race": (np.diag([400.0, 1.0, 1.0, 20.0, 0.0, 1100.0]), 0.0 * np.eye(2), np.array([100.0, 45.0])),
+}
+PLAN_Q = -np.diag([-0.000000000000088, -9.703658572659423, -0.5, 0.000000000213635, -0.153591566469547])
+PLAN_L = -np.array([1.00702414775175, 0.187661946033823, -0.0, 0.0, -0.0329493219494661])
+PLAN_R = np.diag([0.8, 0.0])
+PLAN_dR = np.array([6.0, 6.0])
+
+
+def stackL(lst):
+    return np.stack([np.asarray(a, float) for a in lst])
+
+
+def certified_optimum(c):
+    l = np.where(c["l"] < -1e29, -np.inf, c["l"]); u = np.where(c["u"] > 1e29, np.inf, c["u"])
+    if not np.all(np.isfinite(c["x"])):
+        return np.full_like(c["x"], np.nan), np.full_like(c["y"], np.nan), np.array([np.nan] * 3)
+    try:
+        xs, ys, _ = kkt_cert.active_set_optimum(c["P"], c["q"], c["A"], l, u, c["x"], c["y"])
+    except RuntimeError:
+        return np.full_like(c["x"], np.nan), np.full_like(c["y"], np.nan), np.array([np.nan] * 3)
+    return xs, ys, np.array(kkt_cert.kkt_residuals(c["P"], c["q"], c["A"], l, u, xs, ys))
+
+
+def ctrl_case(CTRL, mp, tuning, N, dt, x0, u_prev, vel_ref, curv_ref, lap, old_u, cf_new=60.0):
+    Q, R, dR = TUNINGS[tuning]
+    c = CTRL.PathFollowingLPV_MPC(Q, R, dR, N, 1, dt, mp, "OSQP", 0, 0)
+    c.OldSteering = [float(old_u[0])]; c.OldAccelera = [float(old_u[1])]
+    S, A_L, B_L, C_L = c.LPVPrediction(x0, u_prev, vel_ref, curv_ref, cf_new, lap)
+    CAPTURE.clear()
+    c.solve(x0, 0.0, u_prev, False, vel_ref, A_L, B_L, C_L, 10)
+    cap = CAPTURE[-1]
+    xs, ys, cert = certified_optimum(cap)
+    return dict(x0=x0, u_prev=u_prev, vel_ref=np.asarray(vel_ref, float), curv_ref=np.asarray(curv_ref, float),
+                lap=lap, old_u=np.asarray(old_u, float), cf_new=cf_new, Q=Q, R=R, dR=dR, N=N, dt=dt,
+                states=S, A=stackL(A_L), B=stackL(B_L), P=cap["P"], q=cap["q"], Aqp=cap["A"], l=cap["l"], u=cap["u"],
+                x_orc=cap["x"], y_orc=cap["y"], iter_orc=cap["iter"], status_orc=cap["status_val"],
+                polish_orc=cap["status_polish"], x_star=xs, y_star=ys, cert=cert,
+                xPred=np.array(c.xPred), uPred=np.array(c.uPred), LinPoints=np.array(c.LinPoints))
+
+
+def plan_case(PLAN, mp, N, dt, x0, SS, u_prev, max_ey):
+    p = PLAN.LPV_MPC_Planner(PLAN_Q, PLAN_R, PLAN_dR, PLAN_L, N, dt, mp, "OSQP")
+    S, A_L, B_L, C_L = p.LPVPrediction(x0, SS, u_prev)
+    CAPTURE.clear()
+    p.solve(x0, 0, 0, A_L, B_L, C_L, 2, max_ey)
+    cap = CAPTURE[-1]
+    xs, ys, cert = certified_optimum(cap)
+    return dict(x0=x0, SS=np.asarray(SS, float), u_prev=u_prev, max_ey=max_ey, N=N, dt=dt,
+                Q=PLAN_Q, R=PLAN_R, dR=PLAN_dR, L_cf=PLAN_L,
+                states=S, A=stackL(A_L), B=stackL(B_L), P=cap["P"], q=cap["q"], Aqp=cap["A"], l=cap["l"], u=cap["u"],
+                x_orc=cap["x"], y_orc=cap["y"], iter_orc=cap["iter"], status_orc=cap["status_val"],
+                polish_orc=cap["status_polish"], x_star=xs, y_star=ys, cert=cert,
+                xPred=np.array(p.xPred), uPred=np.array(p.uPred), LinPoints=np.array(p.LinPoints))
+
+
+def save_cases(name, cases):
+    flat = {}
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            flat["c%02d_%s" % (i, k)] = np.asarray(v)
+    flat["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **flat)
+    print("wrote %s.npz (%d cases)" % (name, len(cases)))
+
+
+def main():
+    warnings.simplefilter("ignore")
+    CTRL, PLAN, TRACK, UTIL, tmp = import_reference()
+    try:
+        # ---------------- track tables + curvature samples ----------------
+        tracks = {}
+        for shape in ("oval", "L_shape", "3110", "Euge_Track"):
+            mp = make_map(TRACK, shape)
+            tab = np.array(mp.PointAndTangent)
+            ss = np.linspace(0.0, 2.2 * mp.TrackLength, 97)[:-1] + 1e-3
+            tracks[shape + "_table"] = tab
+            tracks[shape + "_length"] = np.array(mp.TrackLength)
+            tracks[shape + "_halfWidth"] = np.array(mp.halfWidth)
+            tracks[shape + "_s"] = ss
+            tracks[shape + "_curv"] = np.array([UTIL.Curvature(s, mp.PointAndTangent) for s in ss])
+        np.savez_compressed(os.path.join(HERE, "tracks.npz"), **tracks)
+        print("wrote tracks.npz")
+
+        oval = make_map(TRACK, "oval")
+        # ---------------- cfg 1: single controller solve, N=10, oval, fixed x0 ----------------
+        N = 10; dt = 1.0 / 30.0
+        x0 = np.array([1.0, 0.0, 0.0, 0.0, 0.5, 0.0])
+        _, uu = lpv_ref.ctrl_seed_vectors(x0)
+        cases = [ctrl_case(CTRL, oval, "path", N, dt, x0, uu[:N].copy(), np.ones(N + 1), np.zeros(N), 0, [0.0, 0.0])]
+        save_cases("ctrl_n10_cfg1", cases)
+
+        # ---------------- 16x controller N=20 oval, random x0, both tunings ----------------
+        rng = np.random.default_rng(0)
+        N = 20
+        cases = []
+        for i in range(16):
+            tuning = "race" if i % 2 == 0 else "path"
+            s = rng.uniform(0, 13); vx = rng.uniform(0.8, 3.0)
+            scale = 1.0 if i < 10 else 3.0           # later cases push steering / accel bounds
+            x0 = np.array([vx, rng.normal(0, 0.05) * scale, rng.normal(0, 0.3) * scale,
+                           rng.normal(0, 0.1) * scale, s, rng.normal(0, 0.1) * scale])
+            u_prev = np.tile([rng.normal(0, 0.05), rng.normal(0.2, 0.3)], (N, 1))
+            lap = 0 if i % 4 == 3 else 1
+            vref = np.full(N + 1, vx if i < 12 else vx + 1.5)
+            curv = np.full(N, UTIL.Curvature(s, oval.PointAndTangent))
+            cases.append(ctrl_case(CTRL, oval, tuning, N, dt, x0, u_prev, vref, curv, lap, u_prev[0]))
+        save_cases("ctrl_n20_oval", cases)
+
+        # ---------------- 16x planner N=30 L_shape ----------------
+        lsh = make_map(TRACK, "L_shape")
+        rng = np.random.default_rng(1)
+        N = 30; dtp = 0.05
+        cases = []
+        for i in range(16):
+            vx = rng.uniform(1, 4)
+            x0 = np.array([vx, np.clip(rng.normal(0, 0.03), -0.9, 0.9), np.clip(rng.normal(0, 0.2), -1.9, 1.9),
+                           np.clip(rng.normal(0, 0.05), -0.19, 0.19), np.clip(rng.normal(0, 0.05), -0.79, 0.79)])
+            s0 = rng.uniform(0, 19.2)
+            SS = s0 + np.arange(N + 1) * vx * dtp
+            u_prev = np.tile([rng.normal(0, 0.03), rng.normal(0.2, 0.2)], (N, 1))
+            cases.append(plan_case(PLAN, lsh, N, dtp, x0, SS, u_prev, 0.2))
+        save_cases("plan_n30_lshape", cases)
+
+        # ---------------- 4x planner N=40 (launch default) ----------------
+        N = 40
+        cases = []
+        for i in range(4):
+            vx = rng.uniform(1, 3)
+            x0 = np.array([vx, 0.0, 0.0, rng.normal(0, 0.03), rng.normal(0, 0.03)])
+            SS = rng.uniform(0, 10) + np.arange(N + 1) * vx * dtp
+            u_prev = np.tile([0.0, 0.2], (N, 1))
+            cases.append(plan_case(PLAN, lsh, N, dtp, x0, SS, u_prev, 0.2))
+        save_cases("plan_n40_lshape", cases)
+
+        # ---------------- seed-mode linearisations (a3 / a11) ----------------
+        N = 20
+        ls = np.array([1.2, 0.01, 0.05, 0.02, 3.0, -0.03])
+        xx, uu = lpv_ref.ctrl_seed_vectors(ls)
+        Q, R, dR = TUNINGS["path"]
+        c = CTRL.PathFollowingLPV_MPC(Q, R, dR, N, 1, dt, oval, "OSQP", 0, 0)
+        CAPTURE.clear()
+        c.solve(ls, xx, uu, False, np.ones(N), 0, 0, 0, 1)
+        cap = CAPTURE[-1]
+        seed = dict(ctrl_ls=ls, ctrl_xx=xx, ctrl_uu=uu, ctrl_A=stackL(c.A), ctrl_B=stackL(c.B),
+                    ctrl_P=cap["P"], ctrl_q=cap["q"], ctrl_Aqp=cap["A"], ctrl_l=cap["l"], ctrl_u=cap["u"],
+                    ctrl_xPred=np.array(c.xPred), ctrl_uPred=np.array(c.uPred))
+        Np = 30
+        px0 = np.array([1.0, 0.0, 0.0, 0.0, 0.0])
+        pxx, puu = lpv_ref.plan_seed_vectors(Np, px0, 0.2, dtp)
+        p = PLAN.LPV_MPC_Planner(PLAN_Q, PLAN_R, PLAN_dR, PLAN_L, Np, dtp, lsh, "OSQP")
+        CAPTURE.clear()
+        p.solve(px0, pxx, puu, 0, 0, 0, 1, 0.2)
+        cap = CAPTURE[-1]
+        seed.update(plan_x0=px0, plan_xx=pxx, plan_uu=puu, plan_A=stackL(p.A), plan_B=stackL(p.B),
+                    plan_P=cap["P"], plan_q=cap["q"], plan_Aqp=cap["A"], plan_l=cap["l"], plan_u=cap["u"],
+                    plan_xPred=np.array(p.xPred), plan_uPred=np.array(p.uPred))
+        np.savez_compressed(os.path.join(HERE, "seed_mode.npz"), **seed)
+        print("wrote seed_mode.npz")
+
+        # ---------------- closed-loop recursions (20 ticks) ----------------
+        # controller, lap-0 call pattern of controllerMain.py:310-331 (plant = the LPV prediction itself)
+        N = 20
+        Q, R, dR = TUNINGS["path"]
+        c = CTRL.PathFollowingLPV_MPC(Q, R, dR, N, 1, dt, oval, "OSQP", 0, 0)
+        st = np.array([1.0, 0.0, 0.0, 0.0, 0.3, 0.0])
+        trace_x, trace_u, trace_x0 = [], [], []
+        first_it = 1
+        cmd = np.zeros(2)
+        for tick in range(20):
+            c.OldSteering.append(float(cmd[0])); c.OldAccelera.append(float(cmd[1]))
+            c.OldSteering.pop(0); c.OldAccelera.pop(0)
+            trace_x0.append(st.copy())
+            if first_it < 10:
+                xx, uu = lpv_ref.ctrl_seed_vectors(st)
+                c.solve(st, xx, uu, False, np.ones(N), 0, 0, 0, first_it)
+                first_it += 1
+            else:
+                S, A_L, B_L, C_L = c.LPVPrediction(st, c.uPred, np.ones(N + 1), np.zeros(N), 60.0, 0)
+                c.solve(S[0, :], S, c.uPred, False, np.ones(N + 1), A_L, B_L, C_L, first_it)
+            cmd = np.array(c.uPred[0, :])
+            trace_x.append(np.array(c.xPred)); trace_u.append(np.array(c.uPred))
+            st = np.array(c.xPred[1, :])          # ideal plant: next state = predicted
+        cl = dict(ctrl_x0=np.array(trace_x0), ctrl_xPred=np.array(trace_x), ctrl_uPred=np.array(trace_u))
+        # planner, open-loop test mode of plannerMain.py:152-176 (s integration PMAIN:201-216)
+        Np = 30
+        p = PLAN.LPV_MPC_Planner(PLAN_Q, PLAN_R, PLAN_dR, PLAN_L, Np, dtp, lsh, "OSQP")
+        px0 = np.array([1.0, 0.0, 0.0, 0.0, 0.0])
+        SS = np.zeros(Np + 1)
+        first = 1
+        tx, tu, tss = [], [], []
+        for tick in range(20):
+            if first == 1:
+                pxx, puu = lpv_ref.plan_seed_vectors(Np, px0, 0.2, dtp)
+                p.solve(px0, pxx, puu, 0, 0, 0, first, 0.2)
+                first += 1
+            else:
+                S, A_L, B_L, C_L = p.LPVPrediction(p.xPred[1, :], SS, p.uPred)
+                p.solve(p.xPred[1, :], 0, 0, A_L, B_L, C_L, first, 0.2)
+            p.OldSteering.append(p.uPred[0, 0]); p.OldAccelera.append(p.uPred[0, 1])
+            for j in range(Np):
+                cv = UTIL.Curvature(SS[j], lsh.PointAndTangent)
+                SS[j + 1] = SS[j] + ((p.xPred[j, 0] * np.cos(p.xPred[j, 4]) - p.xPred[j, 1] * np.sin(p.xPred[j, 4]))
+                                     / (1 - p.xPred[j, 3] * cv)) * dtp
+            SS[0] = SS[1]
+            tx.append(np.array(p.xPred)); tu.append(np.array(p.uPred)); tss.append(SS.copy())
+        cl.update(plan_xPred=np.array(tx), plan_uPred=np.array(tu), plan_SS=np.array(tss))
+        np.savez_compressed(os.path.join(HERE, "closed_loop.npz"), **cl)
+        print("wrote closed_loop.npz")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
