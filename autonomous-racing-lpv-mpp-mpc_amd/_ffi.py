@@ -1,0 +1,124 @@
+"""ctypes binding of liblpvmpc.so (C ABI in include/lpvmpc.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at load time, and if no
+HIP device is usable ``lpvmpc_create`` fails with LPVMPC_E_NODEVICE which surfaces as ``LpvMpcError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblpvmpc.so")
+
+KIND_CONTROLLER, KIND_PLANNER = 0, 1
+MAX_TRACK_ROWS, MAX_N = 16, 64
+E_ARG, E_NODEVICE, E_HIP, E_NOMEM = -1, -2, -3, -4
+
+STATUS_TEXT = {1: "solved", 2: "solved inaccurate", 3: "primal infeasible inaccurate",
+               4: "dual infeasible inaccurate", -2: "maximum iterations reached",
+               -3: "primal infeasible", -4: "dual infeasible", -7: "problem non convex", -10: "unsolved"}
+
+_d, _i = C.c_double, C.c_int32
+
+
+class Config(C.Structure):
+    """Mirror of ``struct lpvmpc_config`` (include/lpvmpc.h) -- keep field order identical."""
+    _fields_ = [
+        ("kind", _i), ("N", _i), ("device", _i), ("reserved0", _i),
+        ("dt", _d),
+        ("lf", _d), ("lr", _d), ("m", _d), ("Iz", _d), ("Cf", _d), ("Cr", _d), ("mu", _d),
+        ("max_vel", _d), ("min_vel", _d),
+        ("Q", _d * 36), ("R", _d * 4), ("dR", _d * 2), ("L_cf", _d * 6),
+        ("ctrl_vx_min", _d), ("ctrl_delta_max", _d), ("ctrl_a_max", _d), ("ctrl_a_min_abs", _d),
+        ("plan_xmin", _d * 5), ("plan_xmax", _d * 5), ("plan_umin", _d * 2), ("plan_umax", _d * 2),
+        ("rho", _d), ("sigma", _d), ("alpha", _d), ("eps_abs", _d), ("eps_rel", _d),
+        ("eps_prim_inf", _d), ("eps_dual_inf", _d), ("polish_delta", _d), ("adaptive_rho_tolerance", _d),
+        ("max_iter", _i), ("check_termination", _i), ("scaling", _i), ("adaptive_rho", _i),
+        ("adaptive_rho_interval", _i), ("polish", _i), ("polish_refine_iter", _i), ("reserved1", _i),
+        ("track_rows", _i), ("reserved2", _i),
+        ("track", _d * (MAX_TRACK_ROWS * 6)),
+    ]
+
+
+SETTING_FIELDS = ("rho", "sigma", "alpha", "eps_abs", "eps_rel", "eps_prim_inf", "eps_dual_inf", "polish_delta",
+                  "adaptive_rho_tolerance", "max_iter", "check_termination", "scaling", "adaptive_rho",
+                  "adaptive_rho_interval", "polish", "polish_refine_iter",
+                  "ctrl_vx_min", "ctrl_delta_max", "ctrl_a_max", "ctrl_a_min_abs")
+
+
+class LpvMpcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lpvmpc error %d: %s" % (code, msg))
+        self.code = code
+
+
+EXPORTS = ("lpvmpc_version", "lpvmpc_default_config", "lpvmpc_create", "lpvmpc_destroy", "lpvmpc_last_error",
+           "lpvmpc_reserve", "lpvmpc_lpv_batch", "lpvmpc_estimate_abc_batch", "lpvmpc_solve_batch_AB",
+           "lpvmpc_solve_batch", "lpvmpc_solve_batch_dev", "lpvmpc_last_kernel_ms", "lpvmpc_set_timing")
+
+_lib = None
+
+
+def load():
+    """Load liblpvmpc.so.  If torch is (or will be) used in this process import it FIRST: the library
+    then binds to the HIP runtime torch already loaded (same SONAME) and device pointers are shared."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found -- build it with `python __graft_entry__.py` (or `make -C %s`); "
+                          "there is no CPU fallback" % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL if "torch" in sys.modules else C.RTLD_LOCAL)
+    P = C.POINTER
+    vp = C.c_void_p
+    lib.lpvmpc_version.restype = C.c_int
+    lib.lpvmpc_default_config.argtypes = [_i, P(Config)]
+    lib.lpvmpc_default_config.restype = None
+    lib.lpvmpc_create.argtypes = [P(Config)]
+    lib.lpvmpc_create.restype = vp
+    lib.lpvmpc_destroy.argtypes = [vp]
+    lib.lpvmpc_destroy.restype = None
+    lib.lpvmpc_last_error.argtypes = [vp]
+    lib.lpvmpc_last_error.restype = C.c_char_p
+    lib.lpvmpc_reserve.argtypes = [vp, _i]
+    lib.lpvmpc_lpv_batch.argtypes = [vp, _i, vp, vp, vp, vp, _d, _i, vp, vp, vp]
+    lib.lpvmpc_estimate_abc_batch.argtypes = [vp, _i, vp, vp, vp, vp]
+    lib.lpvmpc_solve_batch_AB.argtypes = [vp, _i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.lpvmpc_solve_batch.argtypes = [vp, _i, vp, vp, vp, vp, vp, vp, _d, _i, vp, vp, vp, vp, vp, vp]
+    lib.lpvmpc_solve_batch_dev.argtypes = [vp, _i, vp, vp, vp, vp, vp, vp, _d, _i, vp, vp, vp, vp, vp, vp, vp]
+    lib.lpvmpc_last_kernel_ms.argtypes = [vp]
+    lib.lpvmpc_last_kernel_ms.restype = _d
+    lib.lpvmpc_set_timing.argtypes = [vp, _i]
+    for name in ("lpvmpc_reserve", "lpvmpc_lpv_batch", "lpvmpc_estimate_abc_batch", "lpvmpc_solve_batch_AB",
+                 "lpvmpc_solve_batch", "lpvmpc_solve_batch_dev", "lpvmpc_set_timing"):
+        getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def default_config(kind):
+    cfg = Config()
+    load().lpvmpc_default_config(kind, C.byref(cfg))
+    return cfg
+
+
+def f64(a, shape=None, name="array"):
+    """Contiguous float64 copy/view with an optional exact shape check."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
+    return a
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def check(handle, rc):
+    if rc != 0:
+        msg = load().lpvmpc_last_error(handle)
+        raise LpvMpcError(rc, msg.decode() if msg else "?")

@@ -1,0 +1,710 @@
+// admm_solve.hip -- batched horizon-QP build + OSQP-style ADMM solve, one wavefront per MPC instance.
+//
+// Replaces, per instance, the reference chain
+//   _buildMatEqConst (CTRL:477-529 / PLAN:434-486), _buildMatCost (CTRL:382-473 / PLAN:145-169),
+//   _buildMatIneqConst (CTRL:329-378 / PLAN:173-181) and the OSQP setup()+solve() call
+//   (CTRL:273-325 / PLAN:200-215; algorithm = OSQP 0.6.x defaults, see oracle/osqp_ref.c header).
+//
+// Design (CDNA4): the whole solve of one instance -- Ruiz equilibration, KKT factorisation, every ADMM
+// iteration, adaptive-rho refactorisations, termination / infeasibility tests and the polish step --
+// runs inside ONE 64-lane wavefront with all state resident in LDS, so HBM sees only the LPV blocks
+// going in and the trajectory coming out.  The QP is never materialised as sparse matrices: the
+// decision vector is kept stage-interleaved, w_k = (x_k, u_k), which makes
+//     K = P + sigma I + A' diag(rho) A
+// block tridiagonal with 8x8 blocks.  K is factored as a block L D L' with explicit inverses of the
+// pivots (S_k^-1) so that a solve is 3 tile mat-vecs per stage.  Tile element [i][j] lives in lane
+// 8*i+j; reductions across i or j are wave shuffles.
+//
+// LDS layout per instance (doubles): three tile arrays [NS][72] (S^-1, L, scaled [A|B]) and 21 vectors
+// [NS][8] (NS = N+1), all padded to 8 per stage so that index = 8*stage + component.
+#include "lpvmpc_device.hpp"
+
+namespace lpvmpc {
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
+}
+// all-reduce over the column index j (lane bits 0..2) / the row index i (lane bits 3..5) of a tile
+__device__ inline double red_j(double v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    return v;
+}
+__device__ inline double red_i(double v) {
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ inline double limit_scaling(double v) {
+    v = v < kMinScaling ? 1.0 : v;
+    return v > kMaxScaling ? kMaxScaling : v;
+}
+__device__ inline double clipd(double t, double lo, double hi) { return t < lo ? lo : (t > hi ? hi : t); }
+
+template <int NX>
+struct Solver {
+    static constexpr int NB = NX + 2;
+    static constexpr bool kCtrl = (NX == 6);
+
+    const DevCfg &cfg;
+    const int N, NS, lane, ti, tj;
+    // tiles
+    double *tS, *tL, *tA;
+    // variable-space vectors
+    double *X, *Qv, *D, *XT, *DX, *VT, *AT;
+    // dynamics rows / box rows
+    double *Zd, *Yd, *Ed, *ZTd, *Wd, *DYd;
+    double *Zb, *Yb, *Eb, *ZTb, *Wb, *DYb, *Lo, *Hi;
+    double *beq;   // [8] scaled x0 (bounds of the stage-0 dynamics rows)
+    double c, cinv;
+
+    __device__ Solver(const DevCfg &cf, double *smem)
+        : cfg(cf), N(cf.N), NS(cf.N + 1), lane(threadIdx.x), ti(threadIdx.x >> 3), tj(threadIdx.x & 7) {
+        double *p = smem;
+        tS = p; p += NS * kTS; tL = p; p += NS * kTS; tA = p; p += NS * kTS;
+        const int V = NS * 8;
+        X = p; p += V; Qv = p; p += V; D = p; p += V; XT = p; p += V; DX = p; p += V; VT = p; p += V; AT = p; p += V;
+        Zd = p; p += V; Yd = p; p += V; Ed = p; p += V; ZTd = p; p += V; Wd = p; p += V; DYd = p; p += V;
+        Zb = p; p += V; Yb = p; p += V; Eb = p; p += V; ZTb = p; p += V; Wb = p; p += V; DYb = p; p += V;
+        Lo = p; p += V; Hi = p; p += V;
+        beq = p; p += 8;
+        c = 1.0; cinv = 1.0;
+    }
+    static __host__ __device__ size_t lds_doubles(int N) { return (size_t)(N + 1) * (3 * kTS + 21 * 8) + 8; }
+
+    // ---- problem structure ---------------------------------------------------------------------
+    __device__ int nvar(int k) const { return k < N ? NB : NX; }
+    __device__ int nbox(int k) const { return kCtrl ? (k < N ? 6 : 0) : (k < N ? 7 : 5); }
+    __device__ static int box_var(int r) { return kCtrl ? (r < 2 ? 0 : (r < 4 ? 6 : 7)) : r; }
+    __device__ static double box_sign(int r) { return kCtrl ? ((r == 0 || r == 3 || r == 5) ? -1.0 : 1.0) : 1.0; }
+    __device__ static void rows_on(int a, int &first, int &cnt) {
+        if (kCtrl) { first = (a == 0) ? 0 : (a == 6 ? 2 : 4); cnt = (a == 0 || a == 6 || a == 7) ? 2 : 0; }
+        else { first = a; cnt = 1; }
+    }
+    // unscaled Hessian entry inside stage block k (P = 2*M0, CTRL:398-432,464 / PLAN:145-169)
+    __device__ double Pc(int k, int a, int b) const {
+        if (a < NX && b < NX) return 2.0 * cfg.Q[a * NX + b];
+        if (a >= NX && b >= NX && a < NB && b < NB && k < N) {
+            double v = 2.0 * cfg.R[(a - NX) * 2 + (b - NX)];
+            if (a == b) v += 2.0 * ((k < N - 1) ? 2.0 : 1.0) * cfg.dR[a - NX];
+            return v;
+        }
+        return 0.0;
+    }
+    // OSQP constraint classes on scaled bounds (set_rho_vec)
+    __device__ static double rho_of(double lo, double hi, double rho) {
+        if (lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling) return kRhoMin;
+        if (hi - lo < kRhoTol) return kRhoEqOverIneq * rho;
+        return rho;
+    }
+    __device__ void sync() const { __syncthreads(); }
+
+    // ---- operators on the scaled problem ---------------------------------------------------------
+    // (dstD, dstB) = A * src
+    __device__ void A_mul(const double *src, double *dstD, double *dstB) const {
+        for (int e = lane; e < NS * 8; e += 64) {
+            const int k = e >> 3, r = e & 7;
+            double v = 0.0;
+            if (r < NX) {
+                v = Ed[e] * D[e] * src[e];
+                if (k >= 1) {
+                    const double *row = tA + (k - 1) * kTS + r * 8;
+                    const double *s = src + (k - 1) * 8;
+#pragma unroll
+                    for (int a = 0; a < NB; ++a) v -= row[a] * s[a];
+                }
+            }
+            dstD[e] = v;
+            double w = 0.0;
+            if (r < nbox(k)) { const int var = k * 8 + box_var(r); w = box_sign(r) * Eb[e] * D[var] * src[var]; }
+            dstB[e] = w;
+        }
+    }
+    // dst = A' * (srcD, srcB)
+    __device__ void At_mul(const double *srcD, const double *srcB, double *dst) const {
+        for (int e = lane; e < NS * 8; e += 64) {
+            const int k = e >> 3, a = e & 7;
+            double v = 0.0;
+            if (a < nvar(k)) {
+                int first, cnt; rows_on(a, first, cnt);
+                for (int t = 0; t < cnt; ++t) {
+                    const int r = first + t;
+                    if (r < nbox(k)) v += box_sign(r) * Eb[k * 8 + r] * D[e] * srcB[k * 8 + r];
+                }
+                if (a < NX) v += Ed[e] * D[e] * srcD[e];
+                if (k < N) {
+                    const double *col = tA + k * kTS + a;
+                    const double *s = srcD + (k + 1) * 8;
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) v -= col[r * 8] * s[r];
+                }
+            }
+            dst[e] = v;
+        }
+    }
+    // dst = P * src   (P = c D P0 D)
+    __device__ void P_mul(const double *src, double *dst) const {
+        for (int e = lane; e < NS * 8; e += 64) {
+            const int k = e >> 3, a = e & 7;
+            double v = 0.0;
+            const int nv = nvar(k);
+            if (a < nv) {
+                for (int b = 0; b < nv; ++b) v += Pc(k, a, b) * D[k * 8 + b] * src[k * 8 + b];
+                if (a >= NX) {
+                    const double cpl = -2.0 * cfg.dR[a - NX];
+                    if (k + 1 < N) v += cpl * D[e + 8] * src[e + 8];
+                    if (k >= 1) v += cpl * D[e - 8] * src[e - 8];
+                }
+                v *= c * D[e];
+            }
+            dst[e] = v;
+        }
+    }
+    // infinity norm of column (k,a) of the scaled Hessian
+    __device__ double P_colnorm(int k, int a) const {
+        const int nv = nvar(k);
+        if (a >= nv) return 0.0;
+        double cn = 0.0;
+        for (int b = 0; b < nv; ++b) cn = fmax(cn, fabs(Pc(k, a, b)) * D[k * 8 + b]);
+        if (a >= NX) {
+            const double cpl = 2.0 * fabs(cfg.dR[a - NX]);
+            if (k + 1 < N) cn = fmax(cn, cpl * D[(k + 1) * 8 + a]);
+            if (k >= 1) cn = fmax(cn, cpl * D[(k - 1) * 8 + a]);
+        }
+        return cn * c * D[k * 8 + a];
+    }
+
+    // ---- Ruiz equilibration (OSQP scale_data) ----------------------------------------------------
+    __device__ void scale_data() {
+        const int ntrue = NS * NX + N * 2;
+        for (int it = 0; it < cfg.scaling; ++it) {
+            // column norms of [P A'; A 0] -> XT (variables), ZTd / ZTb (rows)
+            for (int e = lane; e < NS * 8; e += 64) {
+                const int k = e >> 3, a = e & 7;
+                double dn = 0.0;
+                if (a < nvar(k)) {
+                    dn = P_colnorm(k, a);
+                    int first, cnt; rows_on(a, first, cnt);
+                    for (int t = 0; t < cnt; ++t) { const int r = first + t; if (r < nbox(k)) dn = fmax(dn, Eb[k * 8 + r] * D[e]); }
+                    if (a < NX) dn = fmax(dn, Ed[e] * D[e]);
+                    if (k < N) { const double *col = tA + k * kTS + a;
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) dn = fmax(dn, fabs(col[r * 8])); }
+                }
+                XT[e] = 1.0 / sqrt(limit_scaling(dn));
+                double en = 0.0;          // dynamics row (k, r=a)
+                if (a < NX) {
+                    en = Ed[e] * D[e];
+                    if (k >= 1) { const double *row = tA + (k - 1) * kTS + a * 8;
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) en = fmax(en, fabs(row[b])); }
+                }
+                ZTd[e] = 1.0 / sqrt(limit_scaling(en));
+                double bn = 0.0;          // box row (k, r=a)
+                if (a < nbox(k)) bn = Eb[e] * D[k * 8 + box_var(a)];
+                ZTb[e] = 1.0 / sqrt(limit_scaling(bn));
+            }
+            sync();
+            // A <- E A D on the stored [A|B] tiles
+            for (int k = 0; k < N; ++k) {
+                if (ti < NX && tj < NB) tA[k * kTS + lane] *= ZTd[(k + 1) * 8 + ti] * XT[k * 8 + tj];
+            }
+            sync();
+            for (int e = lane; e < NS * 8; e += 64) { D[e] *= XT[e]; Ed[e] *= ZTd[e]; Eb[e] *= ZTb[e]; }
+            sync();
+            // cost normalisation
+            double psum = 0.0, qmax = 0.0;
+            for (int e = lane; e < NS * 8; e += 64) {
+                const int k = e >> 3, a = e & 7;
+                psum += P_colnorm(k, a);
+                qmax = fmax(qmax, fabs(c * D[e] * Qv[e]));
+            }
+            psum = wave_sum(psum) / (double)ntrue;
+            qmax = limit_scaling(wave_max(qmax));
+            double ct = limit_scaling(fmax(psum, qmax));
+            c *= 1.0 / ct;
+            sync();
+        }
+        cinv = 1.0 / c;
+    }
+
+    // ---- block tridiagonal factorisation of K = P + sig I + A' diag(W) A --------------------------
+    __device__ void factor(double sig) {
+        double sinv_prev = 0.0;
+        for (int k = 0; k <= N; ++k) {
+            const int nv = nvar(k);
+            double kd;
+            if (ti < nv && tj < nv) {
+                kd = Pc(k, ti, tj) * c * D[k * 8 + ti] * D[k * 8 + tj];
+                if (ti == tj) {
+                    kd += sig;
+                    int first, cnt; rows_on(ti, first, cnt);
+                    for (int t = 0; t < cnt; ++t) { const int r = first + t;
+                        if (r < nbox(k)) { const double s = Eb[k * 8 + r] * D[k * 8 + ti]; kd += Wb[k * 8 + r] * s * s; } }
+                    if (ti < NX) { const double s = Ed[k * 8 + ti] * D[k * 8 + ti]; kd += Wd[k * 8 + ti] * s * s; }
+                }
+                if (k < N) {
+                    const double *ca = tA + k * kTS + ti, *cb = tA + k * kTS + tj;
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) kd += Wd[(k + 1) * 8 + r] * ca[r * 8] * cb[r * 8];
+                }
+            } else kd = (ti == tj) ? 1.0 : 0.0;
+            double s = kd, l = 0.0;
+            if (k >= 1) {
+                // off-diagonal block: rows = stage k, columns = stage k-1
+                double ko = 0.0;
+                if (tj < NB) {
+                    if (ti < NX) ko = -Wd[k * 8 + ti] * (Ed[k * 8 + ti] * D[k * 8 + ti]) * tA[(k - 1) * kTS + ti * 8 + tj];
+                    else if (ti == tj && ti < nv) ko = c * D[k * 8 + ti] * (-2.0 * cfg.dR[ti - NX]) * D[(k - 1) * 8 + ti];
+                }
+                // L = Koff * Sinv_prev ; S = Kd - L * Koff'
+#pragma unroll
+                for (int t = 0; t < 8; ++t) l += __shfl(ko, ti * 8 + t) * __shfl(sinv_prev, t * 8 + tj);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) s -= __shfl(l, ti * 8 + t) * __shfl(ko, tj * 8 + t);
+            }
+            tL[k * kTS + lane] = l;
+            // Gauss-Jordan inverse of the SPD pivot block
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const double p = __shfl(s, t * 9), rowt = __shfl(s, t * 8 + tj), colt = __shfl(s, ti * 8 + t);
+                const double pinv = 1.0 / p, rr = rowt * pinv;
+                if (ti == t) s = (tj == t) ? pinv : rr;
+                else s = (tj == t) ? -colt * pinv : s - colt * rr;
+            }
+            tS[k * kTS + lane] = s;
+            sinv_prev = s;
+        }
+        sync();
+    }
+
+    // ---- XT <- K^-1 XT ---------------------------------------------------------------------------
+    __device__ void kkt_solve() {
+        // forward: y_k = b_k - L_k y_{k-1}
+        double yj = XT[tj];
+        for (int k = 1; k <= N; ++k) {
+            const double t = red_j(tL[k * kTS + lane] * yj);
+            const double yi = XT[k * 8 + ti] - t;
+            yj = __shfl(yi, tj * 8);
+            if (tj == 0) XT[k * 8 + ti] = yi;
+        }
+        sync();
+        // v_k = Sinv_k y_k
+        for (int k = 0; k <= N; ++k) {
+            const double t = red_j(tS[k * kTS + lane] * XT[k * 8 + tj]);
+            if (tj == 0) VT[k * 8 + ti] = t;
+        }
+        sync();
+        // backward: x_k = v_k - L_{k+1}' x_{k+1}
+        double xi = VT[N * 8 + ti];
+        if (lane < 8) XT[N * 8 + lane] = VT[N * 8 + lane];
+        for (int k = N - 1; k >= 0; --k) {
+            const double t = red_i(tL[(k + 1) * kTS + lane] * xi);
+            const double xj = VT[k * 8 + tj] - t;
+            xi = __shfl(xj, ti);
+            if (ti == 0) XT[k * 8 + tj] = xj;
+        }
+        sync();
+    }
+
+    // ---- residuals (OSQP update_info) -----------------------------------------------------------
+    struct Res { double pri, dua, nAx, nz, nPx, nAty, nq, s_pri, s_dua, s_Ax, s_z, s_Px, s_Aty, s_q; };
+
+    // (xv, zd/zb, yd/yb) -> residual norms; leaves A x in ZT*, P x in VT, A'y in AT
+    __device__ Res residuals(const double *xv, const double *zd, const double *zb, const double *yd, const double *yb) {
+        A_mul(xv, ZTd, ZTb);
+        P_mul(xv, VT);
+        At_mul(yd, yb, AT);
+        sync();
+        Res r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int e = lane; e < NS * 8; e += 64) {
+            const double eid = 1.0 / Ed[e], eib = 1.0 / Eb[e], di = 1.0 / D[e];
+            const double rd = ZTd[e] - zd[e], rb = ZTb[e] - zb[e];
+            r.s_pri = fmax(r.s_pri, fmax(fabs(rd), fabs(rb)));
+            r.pri = fmax(r.pri, fmax(fabs(eid * rd), fabs(eib * rb)));
+            r.s_Ax = fmax(r.s_Ax, fmax(fabs(ZTd[e]), fabs(ZTb[e])));
+            r.nAx = fmax(r.nAx, fmax(fabs(eid * ZTd[e]), fabs(eib * ZTb[e])));
+            r.s_z = fmax(r.s_z, fmax(fabs(zd[e]), fabs(zb[e])));
+            r.nz = fmax(r.nz, fmax(fabs(eid * zd[e]), fabs(eib * zb[e])));
+            const double dr = Qv[e] + VT[e] + AT[e];
+            r.s_dua = fmax(r.s_dua, fabs(dr));       r.dua = fmax(r.dua, fabs(di * dr));
+            r.s_Px = fmax(r.s_Px, fabs(VT[e]));      r.nPx = fmax(r.nPx, fabs(di * VT[e]));
+            r.s_Aty = fmax(r.s_Aty, fabs(AT[e]));    r.nAty = fmax(r.nAty, fabs(di * AT[e]));
+            r.s_q = fmax(r.s_q, fabs(Qv[e]));        r.nq = fmax(r.nq, fabs(di * Qv[e]));
+        }
+        r.pri = wave_max(r.pri); r.dua = cinv * wave_max(r.dua);
+        r.nAx = wave_max(r.nAx); r.nz = wave_max(r.nz);
+        r.nPx = cinv * wave_max(r.nPx); r.nAty = cinv * wave_max(r.nAty); r.nq = cinv * wave_max(r.nq);
+        r.s_pri = wave_max(r.s_pri); r.s_dua = wave_max(r.s_dua); r.s_Ax = wave_max(r.s_Ax); r.s_z = wave_max(r.s_z);
+        r.s_Px = wave_max(r.s_Px); r.s_Aty = wave_max(r.s_Aty); r.s_q = wave_max(r.s_q);
+        sync();
+        return r;
+    }
+    __device__ double objective(const double *xv) {
+        P_mul(xv, VT);
+        sync();
+        double v = 0.0;
+        for (int e = lane; e < NS * 8; e += 64) v += xv[e] * (0.5 * VT[e] + Qv[e]);
+        v = wave_sum(v) * cinv;
+        sync();
+        return v;
+    }
+
+    // bounds of a dynamics row (equalities: l = u)
+    __device__ double dyn_bound(int e) const { return e < 8 ? beq[e] : 0.0; }
+
+    // ---- infeasibility certificates (OSQP is_primal_infeasible / is_dual_infeasible) ----------------
+    __device__ bool primal_infeasible(double eps) {
+        double nd = 0.0;
+        for (int e = lane; e < NS * 8; e += 64) {
+            // dynamics rows have finite bounds: no projection.  box rows: project on the polar recession cone
+            double dy = DYb[e];
+            const double lo = Lo[e], hi = Hi[e];
+            if (hi > kInfty * kMinScaling) { if (lo < -kInfty * kMinScaling) dy = 0.0; else dy = fmin(dy, 0.0); }
+            else if (lo < -kInfty * kMinScaling) dy = fmax(dy, 0.0);
+            DYb[e] = dy;
+            nd = fmax(nd, fmax(fabs(Ed[e] * DYd[e]), fabs(Eb[e] * dy)));
+        }
+        nd = wave_max(nd);
+        sync();
+        bool res = false;
+        if (nd > eps) {
+            double lhs = 0.0;
+            for (int e = lane; e < NS * 8; e += 64) {
+                const double b = dyn_bound(e), dyd = DYd[e], dyb = DYb[e];
+                lhs += b * fmax(dyd, 0.0) + b * fmin(dyd, 0.0);
+                lhs += Hi[e] * fmax(dyb, 0.0) + Lo[e] * fmin(dyb, 0.0);
+            }
+            lhs = wave_sum(lhs);
+            if (lhs < -eps * nd) {
+                At_mul(DYd, DYb, AT);
+                sync();
+                double na = 0.0;
+                for (int e = lane; e < NS * 8; e += 64) na = fmax(na, fabs(AT[e] / D[e]));
+                na = wave_max(na);
+                res = na < eps * nd;
+                sync();
+            }
+        }
+        return res;
+    }
+    __device__ bool dual_infeasible(double eps) {
+        double nd = 0.0, qdx = 0.0;
+        for (int e = lane; e < NS * 8; e += 64) { nd = fmax(nd, fabs(D[e] * DX[e])); qdx += Qv[e] * DX[e]; }
+        nd = wave_max(nd); qdx = wave_sum(qdx);
+        bool res = false;
+        if (nd > eps && qdx < -c * eps * nd) {
+            P_mul(DX, VT);
+            sync();
+            double np = 0.0;
+            for (int e = lane; e < NS * 8; e += 64) np = fmax(np, fabs(VT[e] / D[e]));
+            np = wave_max(np);
+            sync();
+            if (np < c * eps * nd) {
+                A_mul(DX, ZTd, ZTb);
+                sync();
+                double bad = 0.0;
+                for (int e = lane; e < NS * 8; e += 64) {
+                    const int k = e >> 3, r = e & 7;
+                    if (r < NX) { const double v = ZTd[e] / Ed[e]; if (v > eps * nd || v < -eps * nd) bad = 1.0; }
+                    if (r < nbox(k)) {
+                        const double v = ZTb[e] / Eb[e];
+                        if ((Hi[e] < kInfty * kMinScaling && v > eps * nd) || (Lo[e] > -kInfty * kMinScaling && v < -eps * nd)) bad = 1.0;
+                    }
+                }
+                res = wave_max(bad) == 0.0;
+                sync();
+            }
+        }
+        return res;
+    }
+
+    // set W (= rho_vec) from the constraint classes
+    __device__ void set_rho_vec(double rho) {
+        for (int e = lane; e < NS * 8; e += 64) {
+            Wd[e] = kRhoEqOverIneq * rho;              // dynamics rows: l == u
+            Wb[e] = rho_of(Lo[e], Hi[e], rho);
+        }
+        sync();
+    }
+
+    // ---- the whole solve --------------------------------------------------------------------------
+    __device__ void run(const SolveArgs &a, int inst) {
+        // ---------- load + build the unscaled problem ----------
+        for (int e = lane; e < NS * kTS; e += 64) { tA[e] = 0.0; }
+        for (int e = lane; e < NS * 8; e += 64) {
+            X[e] = 0; D[e] = 1.0; DX[e] = 0; Zd[e] = 0; Yd[e] = 0; Ed[e] = 1.0; DYd[e] = 0;
+            Zb[e] = 0; Yb[e] = 0; Eb[e] = 1.0; DYb[e] = 0; Lo[e] = 0; Hi[e] = 0; Qv[e] = 0;
+        }
+        sync();
+        {
+            const double *src = a.AB + (size_t)inst * N * NX * NB;
+            for (int e = lane; e < N * NX * NB; e += 64) {
+                const int k = e / (NX * NB), rem = e - k * (NX * NB), r = rem / NB, col = rem - r * NB;
+                tA[k * kTS + r * 8 + col] = src[e];
+            }
+        }
+        const double uo0 = a.u_old ? a.u_old[(size_t)inst * 2 + 0] : 0.0, uo1 = a.u_old ? a.u_old[(size_t)inst * 2 + 1] : 0.0;
+        const double mey = (!kCtrl && a.max_ey) ? a.max_ey[inst] : 0.0;
+        for (int e = lane; e < NS * 8; e += 64) {
+            const int k = e >> 3, r = e & 7;
+            // linear cost: controller q = -2 xtrack' M0 (CTRL:434-447); planner q = L_cf (PLAN:163)
+            double q = 0.0;
+            if (r < NX) {
+                if (kCtrl) q = -2.0 * cfg.Q[0 * NX + r] * a.vel_ref[(size_t)inst * (N + 1) + k];
+                else q = cfg.Lcf[r];
+            } else if (r < NB && k == 0) q = -2.0 * (r == NX ? uo0 : uo1) * cfg.dR[r - NX];   // CTRL:462 / PLAN:167
+            Qv[e] = q;
+            // box rows (CTRL:334-348 / PLAN:173-181); infinities clipped to +-1e30 like OSQP's front end
+            if (r < nbox(k)) {
+                double lo = cfg.box_lo[r], hi = cfg.box_hi[r];
+                if (!kCtrl && r == 3) { lo = -mey; hi = mey; }
+                Lo[e] = fmax(lo, -kInfty); Hi[e] = fmin(hi, kInfty);
+            }
+        }
+        if (lane < 8) beq[lane] = (lane < NX) ? a.x0[(size_t)inst * NX + lane] : 0.0;
+        sync();
+
+        // ---------- setup: scaling, rho, factorisation ----------
+        if (cfg.scaling > 0) scale_data();
+        for (int e = lane; e < NS * 8; e += 64) { Qv[e] *= c * D[e]; Lo[e] *= Eb[e]; Hi[e] *= Eb[e]; }
+        if (lane < 8) beq[lane] *= Ed[lane];
+        sync();
+        double rho = fmin(fmax(cfg.rho, kRhoMin), kRhoMax);
+        set_rho_vec(rho);
+        factor(cfg.sigma);
+
+        // ---------- ADMM ----------
+        const double alpha = cfg.alpha, sigma = cfg.sigma;
+        int status = LPVMPC_UNSOLVED_, iter = 0, rho_updates = 0, status_polish = 0;
+        double pri_res = 0, dua_res = 0, obj = __builtin_nan("");
+        Res R = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        bool checked = false;
+        for (iter = 1; iter <= cfg.max_iter; ++iter) {
+            // rhs = sigma x - q + A'(rho z - y)
+            for (int e = lane; e < NS * 8; e += 64) { ZTd[e] = Wd[e] * Zd[e] - Yd[e]; ZTb[e] = Wb[e] * Zb[e] - Yb[e]; }
+            sync();
+            At_mul(ZTd, ZTb, XT);
+            sync();
+            for (int e = lane; e < NS * 8; e += 64) XT[e] += sigma * X[e] - Qv[e];
+            sync();
+            kkt_solve();
+            A_mul(XT, ZTd, ZTb);           // z~ = A x~
+            sync();
+            for (int e = lane; e < NS * 8; e += 64) {
+                const double xn = alpha * XT[e] + (1.0 - alpha) * X[e];
+                DX[e] = xn - X[e]; X[e] = xn;
+                {   // dynamics rows
+                    const double w = Wd[e], winv = 1.0 / w, b = dyn_bound(e);
+                    const double zr = alpha * ZTd[e] + (1.0 - alpha) * Zd[e];
+                    const double zn = clipd(zr + winv * Yd[e], b, b);
+                    const double dy = w * (zr - zn);
+                    Yd[e] += dy; Zd[e] = zn; DYd[e] = dy;
+                }
+                {   // box rows
+                    const double w = Wb[e], winv = 1.0 / w;
+                    const double zr = alpha * ZTb[e] + (1.0 - alpha) * Zb[e];
+                    const double zn = clipd(zr + winv * Yb[e], Lo[e], Hi[e]);
+                    const double dy = w * (zr - zn);
+                    Yb[e] += dy; Zb[e] = zn; DYb[e] = dy;
+                }
+            }
+            sync();
+            checked = cfg.check_termination > 0 && (iter % cfg.check_termination == 0);
+            bool have_info = false;
+            if (checked) {
+                R = residuals(X, Zd, Zb, Yd, Yb); have_info = true;
+                pri_res = R.pri; dua_res = R.dua;
+                if (check_termination(R, false, status)) break;
+            }
+            if (cfg.adaptive_rho && cfg.adaptive_rho_interval > 0 && (iter % cfg.adaptive_rho_interval == 0)) {
+                if (!have_info) { R = residuals(X, Zd, Zb, Yd, Yb); pri_res = R.pri; dua_res = R.dua; }
+                const double rn = rho_estimate(R, rho);
+                if (rn > rho * cfg.rho_tol || rn < rho / cfg.rho_tol) {
+                    rho = rn; set_rho_vec(rho); factor(sigma); ++rho_updates;
+                }
+            }
+        }
+        if (iter > cfg.max_iter) iter = cfg.max_iter;
+        if (!checked) {
+            R = residuals(X, Zd, Zb, Yd, Yb); pri_res = R.pri; dua_res = R.dua;
+            check_termination(R, false, status);
+        }
+        const bool has_sol = !(status == LPVMPC_PRIMAL_INFEASIBLE_ || status == LPVMPC_PRIMAL_INFEASIBLE_INACC_ ||
+                               status == LPVMPC_DUAL_INFEASIBLE_ || status == LPVMPC_DUAL_INFEASIBLE_INACC_ ||
+                               status == LPVMPC_NON_CVX_);
+        if (has_sol) obj = objective(X);
+        if (status == LPVMPC_UNSOLVED_) { if (!check_termination(R, true, status)) status = LPVMPC_MAX_ITER_; }
+        if (status == LPVMPC_PRIMAL_INFEASIBLE_ || status == LPVMPC_PRIMAL_INFEASIBLE_INACC_) obj = kInfty;
+        if (status == LPVMPC_DUAL_INFEASIBLE_ || status == LPVMPC_DUAL_INFEASIBLE_INACC_) obj = -kInfty;
+
+        // ---------- polish ----------
+        if (cfg.polish && status == LPVMPC_SOLVED_) status_polish = polish(pri_res, dua_res, obj);
+
+        // ---------- write back (store_solution) ----------
+        const bool sol = has_sol;
+        const double nan = __builtin_nan("");
+        for (int e = lane; e < NS * 8; e += 64) {
+            const int k = e >> 3, r = e & 7;
+            const double v = sol ? D[e] * X[e] : nan;
+            if (r < NX) a.xPred[((size_t)inst * NS + k) * NX + r] = v;
+            else if (r < NB && k < N) a.uPred[((size_t)inst * N + k) * 2 + (r - NX)] = v;
+        }
+        if (lane == 0) {
+            if (a.status) a.status[inst] = status;
+            if (a.iters) a.iters[inst] = iter;
+            if (a.polish) a.polish[inst] = status_polish;
+            if (a.resid) { double *o = a.resid + (size_t)inst * 4; o[0] = pri_res; o[1] = dua_res; o[2] = obj; o[3] = rho; }
+        }
+    }
+
+    // status codes (values of lpvmpc.h / OSQP)
+    static constexpr int LPVMPC_SOLVED_ = 1, LPVMPC_SOLVED_INACC_ = 2, LPVMPC_PRIMAL_INFEASIBLE_INACC_ = 3,
+                         LPVMPC_DUAL_INFEASIBLE_INACC_ = 4, LPVMPC_MAX_ITER_ = -2, LPVMPC_PRIMAL_INFEASIBLE_ = -3,
+                         LPVMPC_DUAL_INFEASIBLE_ = -4, LPVMPC_NON_CVX_ = -7, LPVMPC_UNSOLVED_ = -10;
+
+    // OSQP check_termination
+    __device__ bool check_termination(const Res &R, bool approx, int &status) {
+        double ea = cfg.eps_abs, er = cfg.eps_rel, epi = cfg.eps_prim_inf, edi = cfg.eps_dual_inf;
+        if (R.pri > kInfty || R.dua > kInfty) { status = LPVMPC_NON_CVX_; return true; }
+        if (approx) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+        bool prc = false, drc = false, pic = false, dic = false;
+        const double ep = ea + er * fmax(R.nz, R.nAx);
+        if (R.pri < ep) prc = true; else pic = primal_infeasible(epi);
+        const double ed = ea + er * fmax(R.nq, fmax(R.nAty, R.nPx));
+        if (R.dua < ed) drc = true; else dic = dual_infeasible(edi);
+        if (prc && drc) { status = approx ? LPVMPC_SOLVED_INACC_ : LPVMPC_SOLVED_; return true; }
+        if (pic) { status = approx ? LPVMPC_PRIMAL_INFEASIBLE_INACC_ : LPVMPC_PRIMAL_INFEASIBLE_; return true; }
+        if (dic) { status = approx ? LPVMPC_DUAL_INFEASIBLE_INACC_ : LPVMPC_DUAL_INFEASIBLE_; return true; }
+        return false;
+    }
+    // OSQP compute_rho_estimate (scaled-space norms)
+    __device__ double rho_estimate(const Res &R, double rho) const {
+        const double pr = R.s_pri / (fmax(R.s_z, R.s_Ax) + 1e-10);
+        const double dr = R.s_dua / (fmax(R.s_q, fmax(R.s_Aty, R.s_Px)) + 1e-10);
+        const double rn = rho * sqrt(pr / (dr + 1e-10));
+        return fmin(fmax(rn, kRhoMin), kRhoMax);
+    }
+
+    // ---- polish (OSQP polish.c) on the reduced form ----------------------------------------------
+    // active rows carry weight 1/delta in K_pol = P + delta I + A_act' A_act / delta; W > 0 marks
+    // upper-active, W < 0 lower-active rows (|W| = 1/delta), W = 0 inactive.
+    __device__ int polish(double &pri_res, double &dua_res, double &obj) {
+        const double delta = cfg.delta, dinv = 1.0 / cfg.delta;
+        for (int e = lane; e < NS * 8; e += 64) {
+            const int k = e >> 3, r = e & 7;
+            double wd = 0.0, wb = 0.0;
+            if (r < NX) {
+                const double b = dyn_bound(e);
+                if (Zd[e] - b < -Yd[e]) wd = -dinv; else if (b - Zd[e] < Yd[e]) wd = dinv;
+            }
+            if (r < nbox(k)) {
+                if (Zb[e] - Lo[e] < -Yb[e]) wb = -dinv; else if (Hi[e] - Zb[e] < Yb[e]) wb = dinv;
+            }
+            DYd[e] = wd; DYb[e] = wb;          // signed flags
+            Wd[e] = fabs(wd); Wb[e] = fabs(wb);
+        }
+        sync();
+        factor(delta);
+        // px (DX), py (Yd/Yb are overwritten: ADMM duals are no longer needed)
+        // initial solve: rhs = -q + A'(W b)
+        for (int e = lane; e < NS * 8; e += 64) {
+            ZTd[e] = Wd[e] * dyn_bound(e);
+            ZTb[e] = Wb[e] * (DYb[e] > 0 ? Hi[e] : (DYb[e] < 0 ? Lo[e] : 0.0));
+        }
+        sync();
+        At_mul(ZTd, ZTb, XT);
+        sync();
+        for (int e = lane; e < NS * 8; e += 64) XT[e] -= Qv[e];
+        sync();
+        kkt_solve();
+        for (int e = lane; e < NS * 8; e += 64) DX[e] = XT[e];
+        sync();
+        A_mul(DX, ZTd, ZTb);
+        sync();
+        for (int e = lane; e < NS * 8; e += 64) {
+            Yd[e] = Wd[e] * (ZTd[e] - dyn_bound(e));
+            Yb[e] = Wb[e] * (ZTb[e] - (DYb[e] > 0 ? Hi[e] : (DYb[e] < 0 ? Lo[e] : 0.0)));
+        }
+        sync();
+        for (int it = 0; it < cfg.polish_refine_iter; ++it) {
+            // r1 = -q - P px - A' py ; r2 = b - A px (active rows)
+            P_mul(DX, VT);
+            At_mul(Yd, Yb, AT);
+            A_mul(DX, ZTd, ZTb);
+            sync();
+            for (int e = lane; e < NS * 8; e += 64) {
+                const double r2d = (Wd[e] != 0.0) ? dyn_bound(e) - ZTd[e] : 0.0;
+                const double r2b = (Wb[e] != 0.0) ? (DYb[e] > 0 ? Hi[e] : Lo[e]) - ZTb[e] : 0.0;
+                ZTd[e] = r2d; ZTb[e] = r2b;
+                Zd[e] = Wd[e] * r2d; Zb[e] = Wb[e] * r2b;
+            }
+            sync();
+            At_mul(Zd, Zb, XT);
+            sync();
+            for (int e = lane; e < NS * 8; e += 64) XT[e] += -Qv[e] - VT[e] - AT[e];
+            sync();
+            kkt_solve();
+            A_mul(XT, Zd, Zb);
+            sync();
+            for (int e = lane; e < NS * 8; e += 64) {
+                DX[e] += XT[e];
+                Yd[e] += Wd[e] * (Zd[e] - ZTd[e]);
+                Yb[e] += Wb[e] * (Zb[e] - ZTb[e]);
+            }
+            sync();
+        }
+        // pol_z = A px, project (z, y) on the normal cone
+        A_mul(DX, Zd, Zb);
+        sync();
+        for (int e = lane; e < NS * 8; e += 64) {
+            { const double b = dyn_bound(e), t = Zd[e] + Yd[e], z = clipd(t, b, b); Zd[e] = z; Yd[e] = t - z; }
+            { const double t = Zb[e] + Yb[e], z = clipd(t, Lo[e], Hi[e]); Zb[e] = z; Yb[e] = t - z; }
+        }
+        sync();
+        const double pobj = objective(DX);
+        const Res R = residuals(DX, Zd, Zb, Yd, Yb);
+        const bool good = (R.pri < pri_res && R.dua < dua_res) || (R.pri < pri_res && dua_res < 1e-10) ||
+                          (R.dua < dua_res && pri_res < 1e-10);
+        if (good) {
+            for (int e = lane; e < NS * 8; e += 64) X[e] = DX[e];
+            pri_res = R.pri; dua_res = R.dua; obj = pobj;
+            sync();
+            return 1;
+        }
+        return -1;
+    }
+};
+
+template <int NX>
+__global__ void __launch_bounds__(64) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
+    extern __shared__ double smem[];
+    const int inst = blockIdx.x;
+    if (inst >= a.B) return;
+    Solver<NX> s(*cfgp, smem);
+    s.run(a, inst);
+}
+
+size_t solve_lds_bytes(int N) { return Solver<6>::lds_doubles(N) * sizeof(double); }
+
+hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream) {
+    const size_t lds = solve_lds_bytes(cfg.N);
+    hipError_t err;
+    if (cfg.kind == 0) {
+        err = hipFuncSetAttribute((const void *)admm_solve_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(admm_solve_kernel<6>, dim3(a.B), dim3(64), lds, stream, dcfg, a);
+    } else {
+        err = hipFuncSetAttribute((const void *)admm_solve_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(admm_solve_kernel<5>, dim3(a.B), dim3(64), lds, stream, dcfg, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace lpvmpc

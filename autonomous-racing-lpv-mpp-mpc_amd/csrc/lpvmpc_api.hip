@@ -1,0 +1,350 @@
+// lpvmpc_api.hip -- the C ABI of liblpvmpc.so (declared in include/lpvmpc.h): handle management,
+// workspace, host<->device staging and kernel launches.  No CPU compute path exists here: every
+// compute entry point fails with LPVMPC_E_NODEVICE when no HIP device is usable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lpvmpc.h"
+#include "lpvmpc_device.hpp"
+
+using lpvmpc::DevCfg;
+using lpvmpc::SolveArgs;
+
+static thread_local std::string g_last_error;
+
+struct lpvmpc_handle {
+    lpvmpc_config cfg;
+    DevCfg dev;
+    DevCfg *d_cfg;           // device copy of dev (kernels read the configuration through this pointer)
+    int nx, nb;
+    int cap;                 // workspace capacity (instances)
+    // device workspace
+    double *d_x0, *d_uprev, *d_vel, *d_curv, *d_uold, *d_maxey, *d_AB, *d_states, *d_xPred, *d_uPred, *d_resid;
+    double *d_xlast, *d_delta;
+    int32_t *d_status, *d_iters, *d_polish;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    bool timing;
+    double last_ms;
+    std::string err;
+};
+
+static int fail(lpvmpc_handle *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    g_last_error = buf;
+    return code;
+}
+#define HIP_TRY(h, expr)                                                                            \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return fail(h, LPVMPC_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int lpvmpc_version(void) { return LPVMPC_VERSION; }
+
+extern "C" void lpvmpc_default_config(int32_t kind, lpvmpc_config *c) {
+    std::memset(c, 0, sizeof(*c));
+    c->kind = kind; c->device = 0;
+    c->lf = 0.125; c->lr = 0.125; c->m = 1.98; c->Iz = 0.03; c->Cf = 60.0; c->Cr = 60.0; c->mu = 0.05;
+    c->max_vel = 5.0; c->min_vel = 0.9;
+    if (kind == LPVMPC_KIND_CONTROLLER) {
+        c->N = 20; c->dt = 1.0 / 30.0;
+        const double q[6] = {400.0, 1.0, 1.0, 20.0, 0.0, 1100.0};    // racing tuning, controllerMain.py:146-148
+        for (int i = 0; i < 6; ++i) c->Q[i * 6 + i] = q[i];
+        c->dR[0] = 100.0; c->dR[1] = 45.0;
+    } else {
+        c->N = 30; c->dt = 0.05;
+        const double q[5] = {0.000000000000088, 9.703658572659423, 0.5, -0.000000000213635, 0.153591566469547};
+        for (int i = 0; i < 5; ++i) c->Q[i * 5 + i] = q[i];           // plannerMain.py:96
+        const double l[5] = {-1.00702414775175, -0.187661946033823, 0.0, -0.0, 0.0329493219494661};
+        for (int i = 0; i < 5; ++i) c->L_cf[i] = l[i];                // plannerMain.py:97
+        c->R[0] = 0.8; c->dR[0] = 6.0; c->dR[1] = 6.0;               // plannerMain.py:98-99
+    }
+    c->ctrl_vx_min = 0.01; c->ctrl_delta_max = 0.249; c->ctrl_a_max = 4.0; c->ctrl_a_min_abs = 1.0;
+    const double xmin[5] = {0.9, -1, -2, -0.2, -0.8}, xmax[5] = {5.0, 1, 2, 0.2, 0.8};
+    for (int i = 0; i < 5; ++i) { c->plan_xmin[i] = xmin[i]; c->plan_xmax[i] = xmax[i]; }
+    c->plan_umin[0] = -0.249; c->plan_umin[1] = -0.7; c->plan_umax[0] = 0.249; c->plan_umax[1] = 2.0;
+    c->rho = 0.1; c->sigma = 1e-6; c->alpha = 1.6; c->eps_abs = 1e-3; c->eps_rel = 1e-3;
+    c->eps_prim_inf = 1e-4; c->eps_dual_inf = 1e-4; c->polish_delta = 1e-6; c->adaptive_rho_tolerance = 5.0;
+    c->max_iter = 4000; c->check_termination = 25; c->scaling = 10; c->adaptive_rho = 1;
+    c->adaptive_rho_interval = 25; c->polish = 1; c->polish_refine_iter = 3;
+    c->track_rows = 0;
+}
+
+static void free_ws(lpvmpc_handle *h) {
+    void *ptrs[] = {h->d_x0, h->d_uprev, h->d_vel, h->d_curv, h->d_uold, h->d_maxey, h->d_AB, h->d_states,
+                    h->d_xPred, h->d_uPred, h->d_resid, h->d_xlast, h->d_delta, h->d_status, h->d_iters, h->d_polish};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    h->d_x0 = h->d_uprev = h->d_vel = h->d_curv = h->d_uold = h->d_maxey = h->d_AB = h->d_states = nullptr;
+    h->d_xPred = h->d_uPred = h->d_resid = h->d_xlast = h->d_delta = nullptr;
+    h->d_status = h->d_iters = h->d_polish = nullptr;
+    h->cap = 0;
+}
+
+static int ensure_ws(lpvmpc_handle *h, int B) {
+    if (B <= h->cap) return LPVMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    free_ws(h);
+    const size_t N = h->cfg.N, nx = h->nx, nb = h->nb, b = B;
+#define ALLOC(p, n) HIP_TRY(h, hipMalloc((void **)&(p), (n)))
+    ALLOC(h->d_x0, b * nx * 8); ALLOC(h->d_uprev, b * N * 2 * 8); ALLOC(h->d_vel, b * (N + 1) * 8);
+    ALLOC(h->d_curv, b * (N + 1) * 8); ALLOC(h->d_uold, b * 2 * 8); ALLOC(h->d_maxey, b * 8);
+    ALLOC(h->d_AB, b * N * nx * nb * 8); ALLOC(h->d_states, b * N * nx * 8);
+    ALLOC(h->d_xPred, b * (N + 1) * nx * 8); ALLOC(h->d_uPred, b * N * 2 * 8); ALLOC(h->d_resid, b * 4 * 8);
+    ALLOC(h->d_xlast, b * N * 6 * 8); ALLOC(h->d_delta, b * N * 8);
+    ALLOC(h->d_status, b * 4); ALLOC(h->d_iters, b * 4); ALLOC(h->d_polish, b * 4);
+#undef ALLOC
+    h->cap = B;
+    return LPVMPC_OK;
+}
+
+extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
+    if (!cfg) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: cfg is NULL"); return nullptr; }
+    if (cfg->kind != LPVMPC_KIND_CONTROLLER && cfg->kind != LPVMPC_KIND_PLANNER) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: bad kind %d", cfg->kind); return nullptr; }
+    if (cfg->N < 2 || cfg->N > LPVMPC_MAX_N) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: N=%d outside [2,%d]", cfg->N, LPVMPC_MAX_N); return nullptr; }
+    if (cfg->track_rows < 0 || cfg->track_rows > LPVMPC_MAX_TRACK_ROWS) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: track_rows=%d outside [0,%d]", cfg->track_rows, LPVMPC_MAX_TRACK_ROWS); return nullptr; }
+    if (!(cfg->dt > 0) || !(cfg->rho > 0) || !(cfg->sigma > 0) || !(cfg->alpha > 0 && cfg->alpha < 2) || !(cfg->polish_delta > 0)) {
+        fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: dt, rho, sigma, polish_delta must be > 0 and 0 < alpha < 2"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fail(nullptr, LPVMPC_E_NODEVICE, "lpvmpc_create: no HIP device available (there is no CPU fallback)"); return nullptr; }
+    if (cfg->device < 0 || cfg->device >= ndev) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: device %d of %d", cfg->device, ndev); return nullptr; }
+    lpvmpc_handle *h = new (std::nothrow) lpvmpc_handle();
+    if (!h) { fail(nullptr, LPVMPC_E_NOMEM, "out of host memory"); return nullptr; }
+    h->cfg = *cfg;
+    h->nx = cfg->kind == LPVMPC_KIND_CONTROLLER ? 6 : 5; h->nb = h->nx + 2;
+    h->d_cfg = nullptr; h->cap = 0; h->timing = false; h->last_ms = -1.0; h->stream = nullptr; h->ev0 = h->ev1 = nullptr;
+    h->d_x0 = h->d_uprev = h->d_vel = h->d_curv = h->d_uold = h->d_maxey = h->d_AB = h->d_states = nullptr;
+    h->d_xPred = h->d_uPred = h->d_resid = h->d_xlast = h->d_delta = nullptr;
+    h->d_status = h->d_iters = h->d_polish = nullptr;
+    DevCfg &d = h->dev;
+    std::memset(&d, 0, sizeof(d));
+    d.kind = cfg->kind; d.N = cfg->N; d.track_rows = cfg->track_rows; d.max_iter = cfg->max_iter;
+    d.check_termination = cfg->check_termination; d.scaling = cfg->scaling; d.adaptive_rho = cfg->adaptive_rho;
+    d.adaptive_rho_interval = cfg->adaptive_rho_interval; d.polish = cfg->polish; d.polish_refine_iter = cfg->polish_refine_iter;
+    d.dt = cfg->dt; d.lf = cfg->lf; d.lr = cfg->lr; d.m = cfg->m; d.Iz = cfg->Iz; d.Cf = cfg->Cf; d.Cr = cfg->Cr; d.mu = cfg->mu;
+    d.max_vel = cfg->max_vel; d.min_vel = cfg->min_vel;
+    std::memcpy(d.Q, cfg->Q, sizeof(d.Q)); std::memcpy(d.R, cfg->R, sizeof(d.R));
+    std::memcpy(d.dR, cfg->dR, sizeof(d.dR)); std::memcpy(d.Lcf, cfg->L_cf, sizeof(d.Lcf));
+    const double inf = INFINITY;
+    if (cfg->kind == LPVMPC_KIND_CONTROLLER) {
+        // rows: -vx <= -vx_min, vx <= max_vel, d <= dmax, -d <= dmax, a <= amax, -a <= amin   (CTRL:334-348)
+        const double hi[6] = {-cfg->ctrl_vx_min, cfg->max_vel, cfg->ctrl_delta_max, cfg->ctrl_delta_max, cfg->ctrl_a_max, cfg->ctrl_a_min_abs};
+        for (int r = 0; r < 6; ++r) { d.box_lo[r] = -inf; d.box_hi[r] = hi[r]; }
+    } else {
+        for (int r = 0; r < 5; ++r) { d.box_lo[r] = cfg->plan_xmin[r]; d.box_hi[r] = cfg->plan_xmax[r]; }
+        d.box_lo[0] = cfg->min_vel; d.box_hi[0] = cfg->max_vel;                 // PLAN:176-177
+        for (int r = 0; r < 2; ++r) { d.box_lo[5 + r] = cfg->plan_umin[r]; d.box_hi[5 + r] = cfg->plan_umax[r]; }
+    }
+    d.rho = cfg->rho; d.sigma = cfg->sigma; d.alpha = cfg->alpha; d.eps_abs = cfg->eps_abs; d.eps_rel = cfg->eps_rel;
+    d.eps_prim_inf = cfg->eps_prim_inf; d.eps_dual_inf = cfg->eps_dual_inf; d.delta = cfg->polish_delta;
+    d.rho_tol = cfg->adaptive_rho_tolerance;
+    std::memcpy(d.track, cfg->track, sizeof(double) * 6 * cfg->track_rows);
+    if (hipSetDevice(cfg->device) != hipSuccess) { fail(nullptr, LPVMPC_E_HIP, "hipSetDevice(%d) failed", cfg->device); delete h; return nullptr; }
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { fail(nullptr, LPVMPC_E_HIP, "hipEventCreate failed"); delete h; return nullptr; }
+    if (hipMalloc((void **)&h->d_cfg, sizeof(DevCfg)) != hipSuccess ||
+        hipMemcpy(h->d_cfg, &h->dev, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) {
+        fail(nullptr, LPVMPC_E_HIP, "uploading the configuration failed"); lpvmpc_destroy(h); return nullptr; }
+    const size_t lds = lpvmpc::solve_lds_bytes(cfg->N);
+    if (lds > 160 * 1024) { fail(nullptr, LPVMPC_E_ARG, "N=%d needs %zu B of LDS per instance (> 160 KiB)", cfg->N, lds); lpvmpc_destroy(h); return nullptr; }
+    return h;
+}
+
+extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    free_ws(h);
+    if (h->d_cfg) (void)hipFree(h->d_cfg);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+}
+
+extern "C" const char *lpvmpc_last_error(const lpvmpc_handle *h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+extern "C" int lpvmpc_reserve(lpvmpc_handle *h, int32_t B) {
+    if (!h || B <= 0) return fail(h, LPVMPC_E_ARG, "lpvmpc_reserve: bad arguments");
+    return ensure_ws(h, B);
+}
+
+extern "C" int lpvmpc_set_timing(lpvmpc_handle *h, int32_t on) { if (!h) return LPVMPC_E_ARG; h->timing = on != 0; return LPVMPC_OK; }
+extern "C" double lpvmpc_last_kernel_ms(lpvmpc_handle *h) { return h ? h->last_ms : -1.0; }
+
+// ------------------------------------------------------------------------------------------------
+static int need_track(lpvmpc_handle *h, const char *who) {
+    if (h->cfg.track_rows < 1) return fail(h, LPVMPC_E_ARG, "%s: the handle was created without a track table", who);
+    return LPVMPC_OK;
+}
+
+static int launch_lpv(lpvmpc_handle *h, int B, const double *x0, const double *u_prev, const double *vel_ref,
+                      const double *curv_s, double cf_new, int lap, double *states, double *AB, hipStream_t st) {
+    HIP_TRY(h, lpvmpc::launch_lpv(h->dev, h->d_cfg, B, x0, u_prev, vel_ref, curv_s, cf_new, lap, states, AB, st));
+    return LPVMPC_OK;
+}
+
+static int launch_solve_timed(lpvmpc_handle *h, const SolveArgs &a, hipStream_t st) {
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    HIP_TRY(h, lpvmpc::launch_solve(h->dev, h->d_cfg, a, st));
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
+    return LPVMPC_OK;
+}
+static void fetch_timing(lpvmpc_handle *h) {
+    if (!h->timing) return;
+    float ms = -1.f;
+    if (hipEventSynchronize(h->ev1) == hipSuccess && hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_ms = ms;
+}
+
+static int check_common(lpvmpc_handle *h, int B, const char *who) {
+    if (!h) return fail(nullptr, LPVMPC_E_ARG, "%s: handle is NULL", who);
+    if (B <= 0) return fail(h, LPVMPC_E_ARG, "%s: B=%d", who, B);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    return ensure_ws(h, B);
+}
+
+#define H2D(dst, src, n) HIP_TRY(h, hipMemcpyAsync(dst, src, (n), hipMemcpyHostToDevice, st))
+#define D2H(dst, src, n) HIP_TRY(h, hipMemcpyAsync(dst, src, (n), hipMemcpyDeviceToHost, st))
+
+extern "C" int lpvmpc_lpv_batch(lpvmpc_handle *h, int32_t B, const double *x0, const double *u_prev,
+                                const double *vel_ref, const double *curv_s, double cf_new, int32_t lap,
+                                double *states, double *A, double *Bm) {
+    int rc = check_common(h, B, "lpvmpc_lpv_batch"); if (rc) return rc;
+    const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
+    if (!x0 || !u_prev) return fail(h, LPVMPC_E_ARG, "lpvmpc_lpv_batch: x0 / u_prev is NULL");
+    if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_lpv_batch: controller needs vel_ref");
+    if (ctrl && lap != 0 && !curv_s) return fail(h, LPVMPC_E_ARG, "lpvmpc_lpv_batch: controller with lap != 0 needs curv_ref");
+    if (!ctrl && !curv_s) return fail(h, LPVMPC_E_ARG, "lpvmpc_lpv_batch: planner needs SS");
+    if ((ctrl && lap == 0) || !ctrl) { rc = need_track(h, "lpvmpc_lpv_batch"); if (rc) return rc; }
+    const size_t N = h->cfg.N, nx = h->nx, nb = h->nb, b = B;
+    hipStream_t st = h->stream;
+    H2D(h->d_x0, x0, b * nx * 8); H2D(h->d_uprev, u_prev, b * N * 2 * 8);
+    if (ctrl) H2D(h->d_vel, vel_ref, b * (N + 1) * 8);
+    if (curv_s) H2D(h->d_curv, curv_s, b * (ctrl ? N : N + 1) * 8);
+    rc = launch_lpv(h, B, h->d_x0, h->d_uprev, h->d_vel, h->d_curv, cf_new, lap, h->d_states, h->d_AB, st); if (rc) return rc;
+    std::vector<double> ab;
+    if (A || Bm) { ab.resize(b * N * nx * nb); D2H(ab.data(), h->d_AB, ab.size() * 8); }
+    if (states) D2H(states, h->d_states, b * N * nx * 8);
+    HIP_TRY(h, hipStreamSynchronize(st));
+    if (A || Bm)
+        for (size_t t = 0; t < b * N; ++t)
+            for (size_t r = 0; r < nx; ++r) {
+                const double *row = ab.data() + (t * nx + r) * nb;
+                if (A) for (size_t a = 0; a < nx; ++a) A[(t * nx + r) * nx + a] = row[a];
+                if (Bm) { Bm[(t * nx + r) * 2 + 0] = row[nx]; Bm[(t * nx + r) * 2 + 1] = row[nx + 1]; }
+            }
+    return LPVMPC_OK;
+}
+
+extern "C" int lpvmpc_estimate_abc_batch(lpvmpc_handle *h, int32_t B, const double *xlast, const double *delta,
+                                         double *A, double *Bm) {
+    int rc = check_common(h, B, "lpvmpc_estimate_abc_batch"); if (rc) return rc;
+    if (!xlast || !delta) return fail(h, LPVMPC_E_ARG, "lpvmpc_estimate_abc_batch: NULL input");
+    rc = need_track(h, "lpvmpc_estimate_abc_batch"); if (rc) return rc;
+    const size_t N = h->cfg.N, nx = h->nx, nb = h->nb, b = B;
+    hipStream_t st = h->stream;
+    H2D(h->d_xlast, xlast, b * N * 6 * 8); H2D(h->d_delta, delta, b * N * 8);
+    HIP_TRY(h, lpvmpc::launch_abc(h->dev, h->d_cfg, B, h->d_xlast, h->d_delta, h->d_AB, st));
+    std::vector<double> ab(b * N * nx * nb);
+    D2H(ab.data(), h->d_AB, ab.size() * 8);
+    HIP_TRY(h, hipStreamSynchronize(st));
+    for (size_t t = 0; t < b * N; ++t)
+        for (size_t r = 0; r < nx; ++r) {
+            const double *row = ab.data() + (t * nx + r) * nb;
+            if (A) for (size_t a = 0; a < nx; ++a) A[(t * nx + r) * nx + a] = row[a];
+            if (Bm) { Bm[(t * nx + r) * 2 + 0] = row[nx]; Bm[(t * nx + r) * 2 + 1] = row[nx + 1]; }
+        }
+    return LPVMPC_OK;
+}
+
+static int copy_out(lpvmpc_handle *h, int B, double *xPred, double *uPred, int32_t *status, int32_t *iters,
+                    double *resid, int32_t *polish, hipStream_t st) {
+    const size_t N = h->cfg.N, nx = h->nx, b = B;
+    if (xPred) D2H(xPred, h->d_xPred, b * (N + 1) * nx * 8);
+    if (uPred) D2H(uPred, h->d_uPred, b * N * 2 * 8);
+    if (status) D2H(status, h->d_status, b * 4);
+    if (iters) D2H(iters, h->d_iters, b * 4);
+    if (resid) D2H(resid, h->d_resid, b * 4 * 8);
+    if (polish) D2H(polish, h->d_polish, b * 4);
+    HIP_TRY(h, hipStreamSynchronize(st));
+    fetch_timing(h);
+    return LPVMPC_OK;
+}
+
+extern "C" int lpvmpc_solve_batch_AB(lpvmpc_handle *h, int32_t B, const double *x0, const double *A, const double *Bm,
+                                     const double *vel_ref, const double *u_old, const double *max_ey,
+                                     double *xPred, double *uPred, int32_t *status, int32_t *iters, double *resid,
+                                     int32_t *polish) {
+    int rc = check_common(h, B, "lpvmpc_solve_batch_AB"); if (rc) return rc;
+    const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
+    if (!x0 || !A || !Bm) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_AB: x0 / A / B is NULL");
+    if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_AB: controller needs vel_ref");
+    if (!ctrl && !max_ey) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_AB: planner needs max_ey");
+    const size_t N = h->cfg.N, nx = h->nx, nb = h->nb, b = B;
+    std::vector<double> ab(b * N * nx * nb);
+    for (size_t t = 0; t < b * N; ++t)
+        for (size_t r = 0; r < nx; ++r) {
+            double *row = ab.data() + (t * nx + r) * nb;
+            for (size_t a = 0; a < nx; ++a) row[a] = A[(t * nx + r) * nx + a];
+            row[nx] = Bm[(t * nx + r) * 2 + 0]; row[nx + 1] = Bm[(t * nx + r) * 2 + 1];
+        }
+    hipStream_t st = h->stream;
+    H2D(h->d_x0, x0, b * nx * 8); H2D(h->d_AB, ab.data(), ab.size() * 8);
+    if (ctrl) H2D(h->d_vel, vel_ref, b * (N + 1) * 8);
+    if (u_old) H2D(h->d_uold, u_old, b * 2 * 8);
+    if (!ctrl) H2D(h->d_maxey, max_ey, b * 8);
+    SolveArgs a{B, h->d_x0, h->d_AB, ctrl ? h->d_vel : nullptr, u_old ? h->d_uold : nullptr, ctrl ? nullptr : h->d_maxey,
+                h->d_xPred, h->d_uPred, h->d_status, h->d_iters, h->d_polish, h->d_resid};
+    rc = launch_solve_timed(h, a, st); if (rc) return rc;
+    return copy_out(h, B, xPred, uPred, status, iters, resid, polish, st);
+}
+
+extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double *x0, const double *u_prev,
+                                      const double *vel_ref, const double *curv_s, const double *u_old,
+                                      const double *max_ey, double cf_new, int32_t lap, double *xPred, double *uPred,
+                                      int32_t *status, int32_t *iters, double *resid, int32_t *polish, void *stream) {
+    int rc = check_common(h, B, "lpvmpc_solve_batch_dev"); if (rc) return rc;
+    const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
+    if (!x0 || !u_prev || !xPred || !uPred) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_dev: NULL x0 / u_prev / xPred / uPred");
+    if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_dev: controller needs vel_ref");
+    if (ctrl && lap != 0 && !curv_s) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_dev: controller with lap != 0 needs curv_ref");
+    if (!ctrl && (!curv_s || !max_ey)) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_dev: planner needs SS and max_ey");
+    if ((ctrl && lap == 0) || !ctrl) { rc = need_track(h, "lpvmpc_solve_batch_dev"); if (rc) return rc; }
+    hipStream_t st = (hipStream_t)stream;
+    rc = launch_lpv(h, B, x0, u_prev, vel_ref, curv_s, cf_new, lap, nullptr, h->d_AB, st); if (rc) return rc;
+    SolveArgs a{B, x0, h->d_AB, ctrl ? vel_ref : nullptr, u_old, ctrl ? nullptr : max_ey, xPred, uPred, status, iters, polish, resid};
+    return launch_solve_timed(h, a, st);
+}
+
+extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0, const double *u_prev,
+                                  const double *vel_ref, const double *curv_s, const double *u_old,
+                                  const double *max_ey, double cf_new, int32_t lap, double *xPred, double *uPred,
+                                  int32_t *status, int32_t *iters, double *resid, int32_t *polish) {
+    int rc = check_common(h, B, "lpvmpc_solve_batch"); if (rc) return rc;
+    const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
+    if (!x0 || !u_prev) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch: x0 / u_prev is NULL");
+    if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch: controller needs vel_ref");
+    if (ctrl && lap != 0 && !curv_s) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch: controller with lap != 0 needs curv_ref");
+    if (!ctrl && (!curv_s || !max_ey)) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch: planner needs SS and max_ey");
+    const size_t N = h->cfg.N, nx = h->nx, b = B;
+    hipStream_t st = h->stream;
+    H2D(h->d_x0, x0, b * nx * 8); H2D(h->d_uprev, u_prev, b * N * 2 * 8);
+    if (ctrl) H2D(h->d_vel, vel_ref, b * (N + 1) * 8);
+    if (curv_s) H2D(h->d_curv, curv_s, b * (ctrl ? N : N + 1) * 8);
+    if (u_old) H2D(h->d_uold, u_old, b * 2 * 8);
+    if (!ctrl) H2D(h->d_maxey, max_ey, b * 8);
+    rc = lpvmpc_solve_batch_dev(h, B, h->d_x0, h->d_uprev, ctrl ? h->d_vel : nullptr, curv_s ? h->d_curv : nullptr,
+                                u_old ? h->d_uold : nullptr, ctrl ? nullptr : h->d_maxey, cf_new, lap, h->d_xPred,
+                                h->d_uPred, h->d_status, h->d_iters, h->d_resid, h->d_polish, (void *)st);
+    if (rc) return rc;
+    return copy_out(h, B, xPred, uPred, status, iters, resid, polish, st);
+}

@@ -1,0 +1,62 @@
+// lpvmpc_device.hpp -- device-side configuration shared by the kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lpvmpc {
+
+constexpr int kMaxSeg = 16;   // rows of the track table kept in the kernel argument block
+constexpr int kTS = 72;       // LDS stride (doubles) of one 8x8 tile: 64 + 8 pad => stage tiles start 16 banks apart
+
+// OSQP constants (0.6.x), see oracle/osqp_ref.c header
+constexpr double kInfty = 1e30;
+constexpr double kRhoMin = 1e-6, kRhoMax = 1e6, kRhoEqOverIneq = 1e3, kRhoTol = 1e-4;
+constexpr double kMinScaling = 1e-4, kMaxScaling = 1e4;
+
+struct DevCfg {
+    int32_t kind, N, track_rows, max_iter;
+    int32_t check_termination, scaling, adaptive_rho, adaptive_rho_interval;
+    int32_t polish, polish_refine_iter, pad0, pad1;
+    double dt, lf, lr, m, Iz, Cf, Cr, mu, max_vel, min_vel;
+    double Q[36], R[4], dR[2], Lcf[6];
+    double box_lo[8], box_hi[8];   // per-stage box rows, unscaled (planner row 3 = ey is per instance)
+    double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, delta, rho_tol;
+    double track[kMaxSeg * 6];
+};
+
+// Piecewise-constant curvature lookup, reference UTIL:31-50 (Curvature).  Same comparisons
+// (s >= start && s < start + len) in float64.  Where the reference raises (no segment contains s:
+// s < 0 or s on a zero-length closing segment) this returns the first / last segment's curvature.
+__device__ inline double track_curvature(const DevCfg &c, double s) {
+    const int rows = c.track_rows;
+    const double L = c.track[(rows - 1) * 6 + 3] + c.track[(rows - 1) * 6 + 4];
+    for (int it = 0; it < 1000000 && s > L; ++it) s -= L;
+    for (int i = 0; i < rows; ++i) {
+        const double st = c.track[i * 6 + 3], ln = c.track[i * 6 + 4];
+        if (s >= st && s < st + ln) return c.track[i * 6 + 5];
+    }
+    return s < 0.0 ? c.track[5] : c.track[(rows - 1) * 6 + 5];
+}
+
+// arguments of the solve kernel (device pointers)
+struct SolveArgs {
+    int B;
+    const double *x0;       // [B][NX]
+    const double *AB;       // [B][N][NX][NX+2]
+    const double *vel_ref;  // [B][N+1]   controller
+    const double *u_old;    // [B][2] or null
+    const double *max_ey;   // [B]        planner
+    double *xPred;          // [B][N+1][NX]
+    double *uPred;          // [B][N][2]
+    int32_t *status, *iters, *polish;
+    double *resid;          // [B][4]
+};
+
+// host-side launchers (defined next to their kernels)
+size_t solve_lds_bytes(int N);
+hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream);
+hipError_t launch_lpv(const DevCfg &cfg, const DevCfg *dcfg, int B, const double *x0, const double *u_prev, const double *vel_ref,
+                      const double *curv_s, double cf_new, int lap, double *states, double *AB, hipStream_t stream);
+hipError_t launch_abc(const DevCfg &cfg, const DevCfg *dcfg, int B, const double *xlast, const double *delta, double *AB, hipStream_t stream);
+
+}  // namespace lpvmpc

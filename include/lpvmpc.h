@@ -1,0 +1,181 @@
+/*
+ * lpvmpc.h -- C ABI of liblpvmpc.so: batched LPV-MPC / LPV-MPP solve path on MI355X (gfx950).
+ *
+ * The reference (euge2838/Autonomous-Racing-LPV-MPP-MPC) has no FFI for this path: its boundary is
+ * two Python classes that call numpy/scipy and the third-party OSQP wheel.  Each entry point below
+ * names the reference interface it replaces (paths relative to workspace/src/barc/src):
+ *   CTRL = ControllerObject/PathFollowingLPVMPC.py     PLAN = PlannerObject/LPV_MPC_Planner.py
+ *   UTIL = Utilities/utilities.py                      TRACK = Utilities/trackInitialization.py
+ *
+ * Conventions
+ *   - plain C, no exceptions across the boundary; every int-returning call gives 0 on success or a
+ *     negative LPVMPC_E_* code, and lpvmpc_last_error() returns a message for the last failure;
+ *   - all arrays are float64, row-major ("C order"), instance-major: [B][...];
+ *   - the caller owns every buffer; nothing passed in is retained after the call returns;
+ *   - one handle per (device, stream); a handle is not thread-safe, different handles are;
+ *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
+ *     LPVMPC_E_NODEVICE.
+ *
+ * Decision vector per instance: z = [x_0 .. x_N, u_0 .. u_{N-1}]  (CTRL:479-492, PLAN:434-445)
+ *   controller nx = 6  [vx vy wz epsi s ey]   (CTRL:712-718)
+ *   planner    nx = 5  [vx vy wz ey epsi]     (PLAN:288-292)
+ *   inputs     nu = 2  [delta a]
+ */
+#ifndef LPVMPC_H
+#define LPVMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPVMPC_VERSION 100            /* 0.1.0 */
+
+#define LPVMPC_KIND_CONTROLLER 0      /* PathFollowingLPV_MPC  (CTRL:30-258) */
+#define LPVMPC_KIND_PLANNER    1      /* LPV_MPC_Planner       (PLAN:29-320) */
+
+#define LPVMPC_MAX_TRACK_ROWS 16
+#define LPVMPC_MAX_N          64
+
+/* error codes */
+#define LPVMPC_OK            0
+#define LPVMPC_E_ARG        -1
+#define LPVMPC_E_NODEVICE   -2
+#define LPVMPC_E_HIP        -3
+#define LPVMPC_E_NOMEM      -4
+
+/* per-instance solver status, numerically equal to OSQP's status_val (CTRL:320-324, PLAN:214-216) */
+#define LPVMPC_SOLVED                        1
+#define LPVMPC_SOLVED_INACCURATE             2
+#define LPVMPC_PRIMAL_INFEASIBLE_INACCURATE  3
+#define LPVMPC_DUAL_INFEASIBLE_INACCURATE    4
+#define LPVMPC_MAX_ITER_REACHED             -2
+#define LPVMPC_PRIMAL_INFEASIBLE            -3
+#define LPVMPC_DUAL_INFEASIBLE              -4
+#define LPVMPC_NON_CVX                      -7
+#define LPVMPC_UNSOLVED                    -10
+
+typedef struct lpvmpc_config {
+    int32_t kind;            /* LPVMPC_KIND_* */
+    int32_t N;               /* horizon (ctor arg N, CTRL:35 / PLAN:34) */
+    int32_t device;          /* HIP device ordinal */
+    int32_t reserved0;
+    double  dt;              /* sample time (ctor arg dt) */
+    /* vehicle parameters the reference reads from ROS (CTRL:38-48, PLAN:70-82) */
+    double  lf, lr, m, Iz, Cf, Cr, mu;
+    double  max_vel, min_vel;
+    /* weights (ctor args Q, R, dR, L_cf); Q is nx*nx row-major in the first nx*nx slots */
+    double  Q[36];
+    double  R[4];
+    double  dR[2];
+    double  L_cf[6];         /* planner only (PLAN:163) */
+    /* hard-coded limits of the reference, exposed: controller CTRL:334-348, planner PLAN:173-177 */
+    double  ctrl_vx_min;     /* 0.01  */
+    double  ctrl_delta_max;  /* 0.249 */
+    double  ctrl_a_max;      /* 4.0   */
+    double  ctrl_a_min_abs;  /* 1.0   (a >= -1.0) */
+    double  plan_xmin[5];    /* [min_vel -1 -2 -max_ey -0.8]; slots 0 and 3 are overwritten from min_vel / max_ey */
+    double  plan_xmax[5];
+    double  plan_umin[2];    /* [-0.249 -0.7] */
+    double  plan_umax[2];    /* [ 0.249  2.0] */
+    /* OSQP settings (defaults of the 0.6.x series; the reference passes only polish=True) */
+    double  rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+    double  polish_delta, adaptive_rho_tolerance;
+    int32_t max_iter, check_termination, scaling, adaptive_rho, adaptive_rho_interval;
+    int32_t polish, polish_refine_iter, reserved1;
+    /* track table = Map.PointAndTangent (TRACK:88-202): rows [x y psi cum_s seg_len curvature] */
+    int32_t track_rows;
+    int32_t reserved2;
+    double  track[LPVMPC_MAX_TRACK_ROWS * 6];
+} lpvmpc_config;
+
+typedef struct lpvmpc_handle lpvmpc_handle;
+
+/* library / ABI version (LPVMPC_VERSION). */
+int lpvmpc_version(void);
+
+/* Fill *cfg with the reference's launch-file and hard-coded defaults for `kind`
+ * (MAIN_LAUNCH.launch:5-11,40-44; controllerMain.py:139-150; plannerMain.py:96-99). */
+void lpvmpc_default_config(int32_t kind, lpvmpc_config *cfg);
+
+/* Replaces the constructors PathFollowingLPV_MPC.__init__ (CTRL:35-84) and
+ * LPV_MPC_Planner.__init__ (PLAN:34-82).  Returns NULL on failure (see lpvmpc_last_error(NULL)). */
+lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg);
+void lpvmpc_destroy(lpvmpc_handle *h);
+const char *lpvmpc_last_error(const lpvmpc_handle *h);
+
+/* Pre-size the device workspace for batches up to B (otherwise grown on demand). */
+int lpvmpc_reserve(lpvmpc_handle *h, int32_t B);
+
+/*
+ * LPV evaluation + horizon roll-out.  Replaces LPVPrediction (CTRL:166-258 / PLAN:242-320).
+ *   x0       [B][nx]
+ *   u_prev   [B][N][2]       previous input prediction (uPred)
+ *   vel_ref  [B][N+1]        controller: vx scheduling (CTRL:200); entry N unused here.  NULL for planner
+ *   curv_s   controller: curv_ref [B][N] used when lap != 0 (CTRL:196-198), may be NULL when lap == 0;
+ *            planner:    SS [B][N+1]  (PLAN:270-271)
+ *   cf_new   controller: Cf = Cr = cf_new (CTRL:172-173); ignored for the planner
+ *   lap      controller: LapNumber (0 -> curvature from the map at the rolled-out s)
+ * outputs (any may be NULL):
+ *   states   [B][N][nx]      STATES_vec
+ *   A        [B][N][nx][nx]  Atv      Bm [B][N][nx][2]  Btv       (Ctv is identically zero, CTRL:236-241)
+ */
+int lpvmpc_lpv_batch(lpvmpc_handle *h, int32_t B, const double *x0, const double *u_prev,
+                     const double *vel_ref, const double *curv_s, double cf_new, int32_t lap,
+                     double *states, double *A, double *Bm);
+
+/* Seed-mode linearisation along a given trajectory.  Replaces _EstimateABC (CTRL:732-809 / PLAN:519-591).
+ *   xlast [B][N][6]  controller columns [vx vy wz epsi s ey]; planner columns [vx vy wz ey epsi s]
+ *   delta [B][N]     steering angle per stage */
+int lpvmpc_estimate_abc_batch(lpvmpc_handle *h, int32_t B, const double *xlast, const double *delta,
+                              double *A, double *Bm);
+
+/*
+ * QP build + OSQP-ADMM solve with caller-supplied LPV matrices.  Replaces
+ * PathFollowingLPV_MPC.solve(x0, ., uPred, ., vel_ref, A_L, B_L, C_L, .) (CTRL:89-162 incl. _buildMatEqConst,
+ * _buildMatCost, _buildMatIneqConst, osqp_solve_qp) and LPV_MPC_Planner.solve (PLAN:86-236).
+ *   x0      [B][nx]
+ *   A       [B][N][nx][nx]   Bm [B][N][nx][2]
+ *   vel_ref [B][N+1]   controller tracking reference: entries 0..N-1 = vel_ref[i], entry N = vel_ref[-1]
+ *                      (CTRL:434-438); NULL for the planner
+ *   u_old   [B][2]     [OldSteering[0], OldAccelera[0]] (CTRL:395, PLAN:114); NULL = zeros
+ *   max_ey  [B]        planner lateral bound (solve arg max_ey, PLAN:176-177); NULL for the controller
+ * outputs:
+ *   xPred [B][N+1][nx], uPred [B][N][2]  (NaN for instances without a solution, as OSQP returns)
+ *   status [B], iters [B]  (may be NULL)
+ *   resid  [B][4] = {pri_res, dua_res, obj_val, rho_final}  (may be NULL)
+ *   polish [B]    = OSQP status_polish (1 accepted, -1 rejected, 0 not run)  (may be NULL)
+ */
+int lpvmpc_solve_batch_AB(lpvmpc_handle *h, int32_t B, const double *x0, const double *A, const double *Bm,
+                          const double *vel_ref, const double *u_old, const double *max_ey,
+                          double *xPred, double *uPred, int32_t *status, int32_t *iters, double *resid,
+                          int32_t *polish);
+
+/* Fused tick: lpvmpc_lpv_batch followed by lpvmpc_solve_batch_AB with x0 as the initial state
+ * (the call pair controllerMain.py:361-363 / plannerMain.py:175-176), without the host round trip. */
+int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0, const double *u_prev,
+                       const double *vel_ref, const double *curv_s, const double *u_old, const double *max_ey,
+                       double cf_new, int32_t lap,
+                       double *xPred, double *uPred, int32_t *status, int32_t *iters, double *resid,
+                       int32_t *polish);
+
+/* Same as lpvmpc_solve_batch but every pointer is a DEVICE pointer and the work is enqueued on `stream`
+ * (a hipStream_t; NULL = default stream) without synchronising.  Used by the closed-loop / bench paths. */
+int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double *x0, const double *u_prev,
+                           const double *vel_ref, const double *curv_s, const double *u_old, const double *max_ey,
+                           double cf_new, int32_t lap,
+                           double *xPred, double *uPred, int32_t *status, int32_t *iters, double *resid,
+                           int32_t *polish, void *stream);
+
+/* Timing of the last *_dev / host call's solve kernel measured with HIP events on the launch stream:
+ * returns milliseconds, or a negative value if unavailable.  (bench.py roofline leg.) */
+double lpvmpc_last_kernel_ms(lpvmpc_handle *h);
+
+/* Enable (1) / disable (0) per-launch HIP-event timing of the solve kernel (off by default). */
+int lpvmpc_set_timing(lpvmpc_handle *h, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPVMPC_H */

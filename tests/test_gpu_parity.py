@@ -1,0 +1,143 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(liblpvmpc.so via ctypes), against the CPU oracle and the golden vectors.
+
+Tolerances (float64 path):
+  * LPV evaluation / roll-out vs golden:   1e-11 relative to the largest magnitude of the compared array
+    (device sin/cos and fused-multiply-add differ from numpy by a few ulp; the roll-out amplifies them).
+  * QP solution vs the oracle's OSQP restatement on identical data: 1e-6 absolute on xPred/uPred when both
+    polished (both then sit on the active-set optimum), 2e-4 otherwise (un-polished ADMM iterates at
+    eps = 1e-3; the two implementations factor different-but-equivalent KKT forms);
+    iteration counts and status codes must match exactly.
+"""
+import numpy as np
+import pytest
+
+from oracle import kkt_cert, lpv_ref as L, osqp_ref as O
+from tests._golden import cases, load
+
+pytestmark = pytest.mark.gpu
+
+P = dict(L.DEFAULT_PARAMS)
+
+
+@pytest.fixture(scope="module")
+def lpvmpc():
+    import lpvmpc as m
+    return m
+
+
+def relclose(a, b, tol):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    assert a.shape == b.shape
+    scale = max(1.0, float(np.max(np.abs(b))))
+    err = float(np.max(np.abs(a - b)))
+    assert err <= tol * scale, "max err %.3e > %.1e * %.3e" % (err, tol, scale)
+
+
+def ctrl_engine(lpvmpc, c, track):
+    return lpvmpc.BatchedSolver("controller", int(c["N"]), float(c["dt"]), c["Q"], c["R"], c["dR"], track=track)
+
+
+def vfull(c):
+    N = int(c["N"])
+    v = np.asarray(c["vel_ref"], float).reshape(-1)
+    return np.concatenate([v[:N], v[-1:]])
+
+
+@pytest.mark.parametrize("name", ["ctrl_n10_cfg1", "ctrl_n20_oval"])
+def test_controller_lpv_matches_golden(lpvmpc, name):
+    tab = lpvmpc.Map("oval", 0.2).PointAndTangent
+    for c in cases(name):
+        eng = ctrl_engine(lpvmpc, c, tab)
+        S, A, B = eng.lpv(c["x0"][None], c["u_prev"][None], vfull(c)[None], c["curv_ref"][None],
+                          cf_new=float(c["cf_new"]), lap=int(c["lap"]))
+        relclose(S[0], c["states"], 1e-11); relclose(A[0], c["A"], 1e-11); relclose(B[0], c["B"], 1e-11)
+        eng.close()
+
+
+@pytest.mark.parametrize("name", ["plan_n30_lshape", "plan_n40_lshape"])
+def test_planner_lpv_matches_golden(lpvmpc, name):
+    tab = lpvmpc.Map("L_shape", 0.2).PointAndTangent
+    for c in cases(name):
+        eng = lpvmpc.BatchedSolver("planner", int(c["N"]), float(c["dt"]), c["Q"], c["R"], c["dR"], L_cf=c["L_cf"], track=tab)
+        S, A, B = eng.lpv(c["x0"][None], c["u_prev"][None], None, c["SS"][None])
+        relclose(S[0], c["states"], 1e-10); relclose(A[0], c["A"], 1e-10); relclose(B[0], c["B"], 1e-10)
+        eng.close()
+
+
+def test_seed_mode_matches_golden(lpvmpc):
+    g = load("seed_mode")
+    eng = lpvmpc.BatchedSolver("controller", 20, 1 / 30.0, np.eye(6), np.eye(2), np.ones(2),
+                               track=lpvmpc.Map("oval", 0.2).PointAndTangent)
+    A, B = eng.estimate_abc(g["ctrl_xx"][None, :20], g["ctrl_uu"][None, :20, 0])
+    relclose(A[0], g["ctrl_A"], 1e-12); relclose(B[0], g["ctrl_B"], 1e-12)
+    eng.close()
+    eng = lpvmpc.BatchedSolver("planner", 30, 0.05, np.eye(5), np.eye(2), np.ones(2), L_cf=np.zeros(5),
+                               track=lpvmpc.Map("L_shape", 0.2).PointAndTangent)
+    A, B = eng.estimate_abc(g["plan_xx"][None, :30], g["plan_uu"][None, :30])
+    relclose(A[0], g["plan_A"], 1e-12); relclose(B[0], g["plan_B"], 1e-12)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["ctrl_n10_cfg1", "ctrl_n20_oval"])
+def test_controller_solve_matches_oracle_and_optimum(lpvmpc, name):
+    tab = lpvmpc.Map("oval", 0.2).PointAndTangent
+    for i, c in enumerate(cases(name)):
+        N = int(c["N"])
+        eng = ctrl_engine(lpvmpc, c, tab)
+        out = eng.solve_AB(c["x0"][None], c["A"][None], c["B"][None], vfull(c)[None], c["old_u"][None])
+        eng.close()
+        assert int(out["status"][0]) == int(c["status_orc"]), (name, i)
+        assert int(out["iters"][0]) == int(c["iter_orc"]), (name, i, out["iters"][0], c["iter_orc"])
+        assert int(out["polish"][0]) == int(c["polish_orc"]), (name, i)
+        xP, uP, _ = L.unpack_solution(c["x_orc"], 6, 2, N)
+        tol = 1e-6 if int(c["polish_orc"]) == 1 else 2e-4
+        assert np.max(np.abs(out["xPred"][0] - xP)) <= tol * max(1.0, np.max(np.abs(xP))), (name, i)
+        assert np.max(np.abs(out["uPred"][0] - uP)) <= tol, (name, i)
+        # independent check: KKT residuals of the returned primal point with the certified multipliers
+        z = np.concatenate([out["xPred"][0].reshape(-1), out["uPred"][0].reshape(-1)])
+        ok, info = kkt_cert.osqp_termination_ok(c["P"], c["q"], c["Aqp"], np.where(c["l"] < -1e29, -np.inf, c["l"]),
+                                                c["u"], z, c["y_orc"])
+        assert ok, info
+
+
+@pytest.mark.parametrize("name", ["plan_n30_lshape", "plan_n40_lshape"])
+def test_planner_solve_matches_oracle(lpvmpc, name):
+    tab = lpvmpc.Map("L_shape", 0.2).PointAndTangent
+    for i, c in enumerate(cases(name)):
+        N = int(c["N"])
+        eng = lpvmpc.BatchedSolver("planner", N, float(c["dt"]), c["Q"], c["R"], c["dR"], L_cf=c["L_cf"], track=tab)
+        out = eng.solve_AB(c["x0"][None], c["A"][None], c["B"][None], None, np.zeros((1, 2)), max_ey=float(c["max_ey"]))
+        eng.close()
+        assert int(out["status"][0]) == int(c["status_orc"]), (name, i, out["status"][0], c["status_orc"], out["iters"][0], c["iter_orc"])
+        assert int(out["iters"][0]) == int(c["iter_orc"]), (name, i, out["iters"][0], c["iter_orc"])
+        if not np.all(np.isfinite(c["x_orc"])):
+            assert np.all(np.isnan(out["xPred"][0])) and np.all(np.isnan(out["uPred"][0]))
+            continue
+        assert int(out["polish"][0]) == int(c["polish_orc"]), (name, i)
+        xP, uP, _ = L.unpack_solution(c["x_orc"], 5, 2, N)
+        tol = 1e-6 if int(c["polish_orc"]) == 1 else 2e-4
+        assert np.max(np.abs(out["xPred"][0] - xP)) <= tol * max(1.0, np.max(np.abs(xP))), (name, i)
+        assert np.max(np.abs(out["uPred"][0] - uP)) <= tol, (name, i)
+
+
+def test_fused_batch_cfg2_against_oracle(lpvmpc):
+    """BASELINE cfg 2 shape (controller N=20, random x0 on the oval), B = 256: every instance solved,
+    a sample re-solved by the oracle from scratch (LPV evaluation + assembly + OSQP restatement)."""
+    from lpvmpc import workloads
+    B = 256
+    w = workloads.controller_batch(B, N=20, seed=0)
+    eng = workloads.make_solver(w)
+    out = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"])
+    eng.close()
+    assert np.all(out["status"] == 1), np.unique(out["status"], return_counts=True)
+    for b in range(0, B, 8):
+        S, A, Bm = L.ctrl_lpv_prediction(P, w["dt"], w["N"], w["track"], w["x0"][b], w["u_prev"][b], w["vel_ref"][b],
+                                         w["curv_s"][b], w["cf_new"], w["lap"])
+        qp = L.ctrl_build_qp(w["Q"], w["R"], w["dR"], w["N"], A, Bm, w["x0"][b], w["u_old"][b], w["vel_ref"][b], P["max_vel"])
+        r = O.solve_qp(qp.P, qp.q, qp.A, qp.l, qp.u)
+        xP, uP, _ = L.unpack_solution(r.x, 6, 2, w["N"])
+        assert int(out["iters"][b]) == r.info.iter, (b, out["iters"][b], r.info.iter)
+        tol = 1e-6 if (r.info.status_polish == 1 and out["polish"][b] == 1) else 2e-4
+        assert np.max(np.abs(out["xPred"][b] - xP)) <= tol * max(1.0, np.max(np.abs(xP))), b
+        assert np.max(np.abs(out["uPred"][b] - uP)) <= tol, b
