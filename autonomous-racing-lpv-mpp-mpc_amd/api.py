@@ -124,6 +124,12 @@ class BatchedSolver:
     def last_kernel_ms(self):
         return float(self._lib.lpvmpc_last_kernel_ms(self._h))
 
+    def kernel_time_stats(self):
+        """(total_ms, launches) of the solve kernel since set_timing(True)."""
+        tot, n = C.c_double(0.0), C.c_int32(0)
+        self._chk(self._lib.lpvmpc_kernel_time_stats(self._h, C.byref(tot), C.byref(n)))
+        return tot.value, n.value
+
     # -- host-array entry points ------------------------------------------------------------------
     def lpv(self, x0, u_prev, vel_ref=None, curv_s=None, cf_new=60.0, lap=1):
         """Batched LPVPrediction.  Returns (states [B,N,nx], A [B,N,nx,nx], Bm [B,N,nx,2])."""

@@ -31,13 +31,50 @@ __device__ inline double wave_max(double v) {
     for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m));
     return v;
 }
+// ---- cross-lane primitives (CDNA4) ------------------------------------------------------------
+// A tile element [i][j] lives in lane 8*i+j.  Summing over j stays inside an 8-lane group: two quad
+// permutes and a half-row mirror, all DPP modifiers on v_mov (a 64-bit value moves as two dwords).
+// Summing over i crosses 16-lane DPP rows: row_ror:8 for lane^8, then v_permlane16_swap /
+// v_permlane32_swap (gfx950) for lane^16 / lane^32.  -DLPVMPC_USE_SHFL selects plain ds_bpermute
+// shuffles instead (validation only).
+template <int CTRL>
+__device__ inline double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double xor16_sum(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ inline double xor32_sum(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
 // all-reduce over the column index j (lane bits 0..2) / the row index i (lane bits 3..5) of a tile
 __device__ inline double red_j(double v) {
+#ifdef LPVMPC_USE_SHFL
     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+#else
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror (quads are uniform by now)
+#endif
     return v;
 }
 __device__ inline double red_i(double v) {
+#ifdef LPVMPC_USE_SHFL
     v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+#else
+    v += dpp_mov<0x128>(v);   // row_ror:8  == lane ^ 8
+    v = xor16_sum(v);
+    v = xor32_sum(v);
+#endif
     return v;
 }
 __device__ inline double limit_scaling(double v) {
@@ -234,8 +271,14 @@ struct Solver {
     }
 
     // ---- block tridiagonal factorisation of K = P + sig I + A' diag(W) A --------------------------
+    // K = L S L' (L unit block-lower bidiagonal, S block diagonal).  Each pivot block is factored
+    // S_k = C C' (Cholesky) and only the TRIANGULAR factor is inverted; with G = K_{k,k-1} C_{k-1}^-T
+    // the next pivot is S_k = K_kk - G G' (a symmetric product of accurately known factors), which
+    // keeps the factorisation accurate for the 1/delta-weighted polish system (cond ~ 1e9), where a
+    // Schur complement formed through an explicit S^-1 loses ~7 digits.  Stored for the solve:
+    // S_k^-1 = C^-T C^-1 (tS) and L_k = G C_{k-1}^-1 (tL; transposed for odd k, see kkt_solve).
     __device__ void factor(double sig) {
-        double sinv_prev = 0.0;
+        double cinv_prev = 0.0;
         for (int k = 0; k <= N; ++k) {
             const int nv = nvar(k);
             double kd;
@@ -262,36 +305,56 @@ struct Solver {
                     if (ti < NX) ko = -Wd[k * 8 + ti] * (Ed[k * 8 + ti] * D[k * 8 + ti]) * tA[(k - 1) * kTS + ti * 8 + tj];
                     else if (ti == tj && ti < nv) ko = c * D[k * 8 + ti] * (-2.0 * cfg.dR[ti - NX]) * D[(k - 1) * 8 + ti];
                 }
-                // L = Koff * Sinv_prev ; S = Kd - L * Koff'
+                double g = 0.0;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) l += __shfl(ko, ti * 8 + t) * __shfl(sinv_prev, t * 8 + tj);
+                for (int t = 0; t < 8; ++t) g += __shfl(ko, ti * 8 + t) * __shfl(cinv_prev, tj * 8 + t);   // G = Koff C^-T
 #pragma unroll
-                for (int t = 0; t < 8; ++t) s -= __shfl(l, ti * 8 + t) * __shfl(ko, tj * 8 + t);
+                for (int t = 0; t < 8; ++t) s -= __shfl(g, ti * 8 + t) * __shfl(g, tj * 8 + t);             // S = Kd - G G'
+#pragma unroll
+                for (int t = 0; t < 8; ++t) l += __shfl(g, ti * 8 + t) * __shfl(cinv_prev, t * 8 + tj);     // L = G C^-1
             }
-            tL[k * kTS + lane] = l;
-            // Gauss-Jordan inverse of the SPD pivot block
+            tL[k * kTS + ((k & 1) ? (tj * 8 + ti) : lane)] = l;
+            // Cholesky S = C C' (lower)
+            double cf = 0.0;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const double p = __shfl(s, t * 9), rowt = __shfl(s, t * 8 + tj), colt = __shfl(s, ti * 8 + t);
-                const double pinv = 1.0 / p, rr = rowt * pinv;
-                if (ti == t) s = (tj == t) ? pinv : rr;
-                else s = (tj == t) ? -colt * pinv : s - colt * rr;
+                const double d = __shfl(s, t * 9);
+                const double rs = 1.0 / sqrt(d);
+                const double cit = __shfl(s, ti * 8 + t) * rs, cjt = __shfl(s, tj * 8 + t) * rs;
+                if (tj == t && ti >= t) cf = cit;
+                if (ti > t && tj > t) s -= cit * cjt;
             }
-            tS[k * kTS + lane] = s;
-            sinv_prev = s;
+            // C^-1 by Gauss-Jordan on the triangular factor (= forward substitution)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const double p = __shfl(cf, t * 9), rowt = __shfl(cf, t * 8 + tj), colt = __shfl(cf, ti * 8 + t);
+                const double pinv = 1.0 / p, rr = rowt * pinv;
+                if (ti == t) cf = (tj == t) ? pinv : rr;
+                else cf = (tj == t) ? -colt * pinv : cf - colt * rr;
+            }
+            double sinv = 0.0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) sinv += __shfl(cf, t * 8 + ti) * __shfl(cf, t * 8 + tj);           // S^-1 = C^-T C^-1
+            tS[k * kTS + lane] = sinv;
+            cinv_prev = cf;
         }
         sync();
     }
 
     // ---- XT <- K^-1 XT ---------------------------------------------------------------------------
+    // Stage vectors alternate between "column form" (component ti, even stages) and "row form"
+    // (component tj, odd stages); L_k is stored transposed for odd k, so every step of the two sweeps is
+    // one tile product followed by one all-reduce, with no lane transposition on the dependent chain.
     __device__ void kkt_solve() {
         // forward: y_k = b_k - L_k y_{k-1}
-        double yj = XT[tj];
-        for (int k = 1; k <= N; ++k) {
-            const double t = red_j(tL[k * kTS + lane] * yj);
-            const double yi = XT[k * 8 + ti] - t;
-            yj = __shfl(yi, tj * 8);
-            if (tj == 0) XT[k * 8 + ti] = yi;
+        double yc = XT[ti], yr = 0.0;
+        for (int k = 1; k <= N; k += 2) {
+            yr = XT[k * 8 + tj] - red_i(tL[k * kTS + lane] * yc);                    // odd k: tile holds L_k[tj][ti]
+            if (ti == 0) XT[k * 8 + tj] = yr;
+            if (k + 1 <= N) {
+                yc = XT[(k + 1) * 8 + ti] - red_j(tL[(k + 1) * kTS + lane] * yr);   // even k: tile holds L_k[ti][tj]
+                if (tj == 0) XT[(k + 1) * 8 + ti] = yc;
+            }
         }
         sync();
         // v_k = Sinv_k y_k
@@ -301,13 +364,16 @@ struct Solver {
         }
         sync();
         // backward: x_k = v_k - L_{k+1}' x_{k+1}
-        double xi = VT[N * 8 + ti];
+        double xc = VT[N * 8 + ti], xr = VT[N * 8 + tj];
         if (lane < 8) XT[N * 8 + lane] = VT[N * 8 + lane];
         for (int k = N - 1; k >= 0; --k) {
-            const double t = red_i(tL[(k + 1) * kTS + lane] * xi);
-            const double xj = VT[k * 8 + tj] - t;
-            xi = __shfl(xj, ti);
-            if (ti == 0) XT[k * 8 + tj] = xj;
+            if (((k + 1) & 1) == 0) {       // L_{k+1}[ti][tj] * x_{k+1}[ti], summed over ti -> row form (k is odd)
+                xr = VT[k * 8 + tj] - red_i(tL[(k + 1) * kTS + lane] * xc);
+                if (ti == 0) XT[k * 8 + tj] = xr;
+            } else {                        // tile holds L_{k+1}[tj][ti]; times x_{k+1}[tj], summed over tj -> column form
+                xc = VT[k * 8 + ti] - red_j(tL[(k + 1) * kTS + lane] * xr);
+                if (tj == 0) XT[k * 8 + ti] = xc;
+            }
         }
         sync();
     }

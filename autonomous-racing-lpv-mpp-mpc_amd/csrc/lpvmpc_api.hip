@@ -30,7 +30,8 @@ struct lpvmpc_handle {
     double *d_xlast, *d_delta;
     int32_t *d_status, *d_iters, *d_polish;
     hipStream_t stream;
-    hipEvent_t ev0, ev1;
+    std::vector<hipEvent_t> ev0, ev1;   // ring of event pairs around the solve-kernel launches
+    int ev_count;                       // pairs recorded since timing was (re)enabled
     bool timing;
     double last_ms;
     std::string err;
@@ -124,7 +125,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     if (!h) { fail(nullptr, LPVMPC_E_NOMEM, "out of host memory"); return nullptr; }
     h->cfg = *cfg;
     h->nx = cfg->kind == LPVMPC_KIND_CONTROLLER ? 6 : 5; h->nb = h->nx + 2;
-    h->d_cfg = nullptr; h->cap = 0; h->timing = false; h->last_ms = -1.0; h->stream = nullptr; h->ev0 = h->ev1 = nullptr;
+    h->d_cfg = nullptr; h->cap = 0; h->timing = false; h->last_ms = -1.0; h->stream = nullptr; h->ev_count = 0;
     h->d_x0 = h->d_uprev = h->d_vel = h->d_curv = h->d_uold = h->d_maxey = h->d_AB = h->d_states = nullptr;
     h->d_xPred = h->d_uPred = h->d_resid = h->d_xlast = h->d_delta = nullptr;
     h->d_status = h->d_iters = h->d_polish = nullptr;
@@ -152,7 +153,6 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     d.rho_tol = cfg->adaptive_rho_tolerance;
     std::memcpy(d.track, cfg->track, sizeof(double) * 6 * cfg->track_rows);
     if (hipSetDevice(cfg->device) != hipSuccess) { fail(nullptr, LPVMPC_E_HIP, "hipSetDevice(%d) failed", cfg->device); delete h; return nullptr; }
-    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { fail(nullptr, LPVMPC_E_HIP, "hipEventCreate failed"); delete h; return nullptr; }
     if (hipMalloc((void **)&h->d_cfg, sizeof(DevCfg)) != hipSuccess ||
         hipMemcpy(h->d_cfg, &h->dev, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) {
         fail(nullptr, LPVMPC_E_HIP, "uploading the configuration failed"); lpvmpc_destroy(h); return nullptr; }
@@ -166,8 +166,8 @@ extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     free_ws(h);
     if (h->d_cfg) (void)hipFree(h->d_cfg);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -178,8 +178,39 @@ extern "C" int lpvmpc_reserve(lpvmpc_handle *h, int32_t B) {
     return ensure_ws(h, B);
 }
 
-extern "C" int lpvmpc_set_timing(lpvmpc_handle *h, int32_t on) { if (!h) return LPVMPC_E_ARG; h->timing = on != 0; return LPVMPC_OK; }
-extern "C" double lpvmpc_last_kernel_ms(lpvmpc_handle *h) { return h ? h->last_ms : -1.0; }
+static const int kEventRing = 1024;
+
+extern "C" int lpvmpc_set_timing(lpvmpc_handle *h, int32_t on) {
+    if (!h) return LPVMPC_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (on && h->ev0.empty()) {
+        h->ev0.resize(kEventRing); h->ev1.resize(kEventRing);
+        for (int i = 0; i < kEventRing; ++i) { HIP_TRY(h, hipEventCreate(&h->ev0[i])); HIP_TRY(h, hipEventCreate(&h->ev1[i])); }
+    }
+    h->timing = on != 0; h->ev_count = 0; h->last_ms = -1.0;
+    return LPVMPC_OK;
+}
+
+extern "C" int lpvmpc_kernel_time_stats(lpvmpc_handle *h, double *total_ms, int32_t *count) {
+    if (!h || !total_ms || !count) return LPVMPC_E_ARG;
+    const int n = h->ev_count < kEventRing ? h->ev_count : kEventRing;
+    double tot = 0.0;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventSynchronize(h->ev1[i]));
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0[i], h->ev1[i]));
+        tot += ms; h->last_ms = ms;
+    }
+    *total_ms = tot; *count = n;
+    return LPVMPC_OK;
+}
+
+extern "C" double lpvmpc_last_kernel_ms(lpvmpc_handle *h) {
+    if (!h) return -1.0;
+    double tot; int32_t n;
+    if (lpvmpc_kernel_time_stats(h, &tot, &n) != LPVMPC_OK || n == 0) return -1.0;
+    return h->last_ms;
+}
 
 // ------------------------------------------------------------------------------------------------
 static int need_track(lpvmpc_handle *h, const char *who) {
@@ -194,15 +225,11 @@ static int launch_lpv(lpvmpc_handle *h, int B, const double *x0, const double *u
 }
 
 static int launch_solve_timed(lpvmpc_handle *h, const SolveArgs &a, hipStream_t st) {
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    const int slot = h->ev_count % kEventRing;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0[slot], st));
     HIP_TRY(h, lpvmpc::launch_solve(h->dev, h->d_cfg, a, st));
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, st));
+    if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev1[slot], st)); h->ev_count++; }
     return LPVMPC_OK;
-}
-static void fetch_timing(lpvmpc_handle *h) {
-    if (!h->timing) return;
-    float ms = -1.f;
-    if (hipEventSynchronize(h->ev1) == hipSuccess && hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_ms = ms;
 }
 
 static int check_common(lpvmpc_handle *h, int B, const char *who) {
@@ -276,7 +303,6 @@ static int copy_out(lpvmpc_handle *h, int B, double *xPred, double *uPred, int32
     if (resid) D2H(resid, h->d_resid, b * 4 * 8);
     if (polish) D2H(polish, h->d_polish, b * 4);
     HIP_TRY(h, hipStreamSynchronize(st));
-    fetch_timing(h);
     return LPVMPC_OK;
 }
 

@@ -168,12 +168,17 @@ int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double *x0, const 
                            double *xPred, double *uPred, int32_t *status, int32_t *iters, double *resid,
                            int32_t *polish, void *stream);
 
-/* Timing of the last *_dev / host call's solve kernel measured with HIP events on the launch stream:
- * returns milliseconds, or a negative value if unavailable.  (bench.py roofline leg.) */
-double lpvmpc_last_kernel_ms(lpvmpc_handle *h);
-
-/* Enable (1) / disable (0) per-launch HIP-event timing of the solve kernel (off by default). */
+/* Enable (1) / disable (0) HIP-event timing of the solve kernel: while enabled every launch of the
+ * ADMM solve kernel is bracketed by an event pair recorded on the launch stream (no host sync).
+ * Enabling resets the statistics.  (bench.py roofline leg.) */
 int lpvmpc_set_timing(lpvmpc_handle *h, int32_t on);
+
+/* Sum of the solve-kernel durations (ms) and the number of launches recorded since timing was enabled
+ * (at most the last 1024).  Synchronises with the recorded events. */
+int lpvmpc_kernel_time_stats(lpvmpc_handle *h, double *total_ms, int32_t *count);
+
+/* Duration (ms) of the most recent timed solve-kernel launch, negative if none. */
+double lpvmpc_last_kernel_ms(lpvmpc_handle *h);
 
 #ifdef __cplusplus
 }

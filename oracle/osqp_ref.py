@@ -124,3 +124,31 @@ def solve_qp(P, q, A, l, u, perm="rcm", **settings):
                              obj_val=info.obj_val, pri_res=info.pri_res, dua_res=info.dua_res,
                              rho_updates=info.rho_updates, rho_estimate=info.rho_estimate,
                              rho_final=info.rho_final))
+
+
+def ctrl_tick_batch(w, nthreads=1, params=None):
+    """Whole controller tick (LPV roll-out + QP assembly + OSQP restatement) for a batch, in C
+    (oracle/lpv_ref.c).  ``w`` is a workload dict (keys N, dt, Q, R, dR, track, x0, u_prev, vel_ref,
+    curv_s, u_old, cf_new, lap).  Returns dict(xPred, uPred, status, iters)."""
+    from .lpv_ref import DEFAULT_PARAMS
+    p = dict(DEFAULT_PARAMS)
+    if params:
+        p.update(params)
+    pv = np.array([p["lf"], p["lr"], p["m"], p["Iz"], p["Cf"], p["Cr"], p["mu"], p["max_vel"]], dtype=np.float64)
+    N = int(w["N"])
+    x0 = np.ascontiguousarray(w["x0"], np.float64); B = x0.shape[0]
+    arrs = dict(Q=np.ascontiguousarray(w["Q"], np.float64), R=np.ascontiguousarray(w["R"], np.float64),
+                dR=np.ascontiguousarray(w["dR"], np.float64), track=np.ascontiguousarray(w["track"], np.float64),
+                u_prev=np.ascontiguousarray(w["u_prev"], np.float64), vel_ref=np.ascontiguousarray(w["vel_ref"], np.float64),
+                curv=np.ascontiguousarray(w["curv_s"] if w["curv_s"] is not None else np.zeros((B, N)), np.float64),
+                u_old=np.ascontiguousarray(w["u_old"], np.float64))
+    xPred = np.empty((B, N + 1, 6)); uPred = np.empty((B, N, 2))
+    status = np.empty(B, np.int32); iters = np.empty(B, np.int32)
+    d = C.c_double
+    f = lib().oracle_ctrl_tick_batch
+    f.restype = C.c_int
+    f(C.c_int(B), C.c_int(N), d(float(w["dt"])), _ptr(pv, d), _ptr(arrs["Q"], d), _ptr(arrs["R"], d), _ptr(arrs["dR"], d),
+      _ptr(arrs["track"], d), C.c_int(arrs["track"].shape[0]), _ptr(x0, d), _ptr(arrs["u_prev"], d), _ptr(arrs["vel_ref"], d),
+      _ptr(arrs["curv"], d), _ptr(arrs["u_old"], d), d(float(w["cf_new"])), C.c_int(int(w["lap"])),
+      _ptr(xPred, d), _ptr(uPred, d), _ptr(status, C.c_int), _ptr(iters, C.c_int), C.c_int(int(nthreads)))
+    return dict(xPred=xPred, uPred=uPred, status=status, iters=iters)
