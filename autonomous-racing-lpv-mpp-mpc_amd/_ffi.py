@@ -59,7 +59,7 @@ class LpvMpcError(RuntimeError):
 EXPORTS = ("lpvmpc_version", "lpvmpc_default_config", "lpvmpc_create", "lpvmpc_destroy", "lpvmpc_last_error",
            "lpvmpc_reserve", "lpvmpc_lpv_batch", "lpvmpc_estimate_abc_batch", "lpvmpc_solve_batch_AB",
            "lpvmpc_solve_batch", "lpvmpc_solve_batch_dev", "lpvmpc_last_kernel_ms", "lpvmpc_set_timing",
-           "lpvmpc_kernel_time_stats")
+           "lpvmpc_kernel_time_stats", "lpvmpc_set_option")
 
 _lib = None
 
@@ -94,6 +94,8 @@ def load():
     lib.lpvmpc_last_kernel_ms.argtypes = [vp]
     lib.lpvmpc_last_kernel_ms.restype = _d
     lib.lpvmpc_set_timing.argtypes = [vp, _i]
+    lib.lpvmpc_set_option.argtypes = [vp, C.c_char_p, _i]
+    lib.lpvmpc_set_option.restype = C.c_int
     lib.lpvmpc_kernel_time_stats.argtypes = [vp, P(_d), P(_i)]
     lib.lpvmpc_kernel_time_stats.restype = C.c_int
     for name in ("lpvmpc_reserve", "lpvmpc_lpv_batch", "lpvmpc_estimate_abc_batch", "lpvmpc_solve_batch_AB",

@@ -118,6 +118,9 @@ class BatchedSolver:
     def reserve(self, B):
         self._chk(self._lib.lpvmpc_reserve(self._h, int(B)))
 
+    def set_option(self, name, value):
+        self._chk(self._lib.lpvmpc_set_option(self._h, name.encode(), int(value)))
+
     def set_timing(self, on=True):
         self._chk(self._lib.lpvmpc_set_timing(self._h, 1 if on else 0))
 

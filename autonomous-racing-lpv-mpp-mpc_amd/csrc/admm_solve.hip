@@ -15,8 +15,12 @@
 // pivots (S_k^-1) so that a solve is 3 tile mat-vecs per stage.  Tile element [i][j] lives in lane
 // 8*i+j; reductions across i or j are wave shuffles.
 //
-// LDS layout per instance (doubles): three tile arrays [NS][72] (S^-1, L, scaled [A|B]) and 21 vectors
-// [NS][8] (NS = N+1), all padded to 8 per stage so that index = 8*stage + component.
+// Two instantiations per model: Solver<NX, NT> with a compile-time horizon NT keeps the factor tiles
+// (S_k^-1, L_k: 2 doubles per stage per lane) in REGISTERS and fully unrolls the two KKT sweeps;
+// Solver<NX, 0> takes the horizon at run time and keeps those tiles in LDS.
+// LDS per instance (doubles): scaled [A|B] tiles [NS][72] and 19 vectors [NS][8] (NS = N+1, everything
+// padded to 8 per stage so that index = 8*stage + component): 37.7 KB at N = 20, i.e. 4 instances per
+// CU (one wavefront per SIMD), which is exactly BASELINE configs[1] (1024 instances) in one residency.
 #include "lpvmpc_device.hpp"
 
 namespace lpvmpc {
@@ -83,48 +87,67 @@ __device__ inline double limit_scaling(double v) {
 }
 __device__ inline double clipd(double t, double lo, double hi) { return t < lo ? lo : (t > hi ? hi : t); }
 
-template <int NX>
+#ifdef LPVMPC_STAMPS
+#define STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[slot] += t_ - tlast; tlast = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
+template <int NX, int NT>
 struct Solver {
+#ifdef LPVMPC_STAMPS
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
     static constexpr int NB = NX + 2;
     static constexpr bool kCtrl = (NX == 6);
+    static constexpr bool kReg = (NT > 0);          // factor tiles in registers, horizon known at compile time
+    static constexpr int kRS = kReg ? NT + 1 : 1;
 
     const DevCfg &cfg;
     const int N, NS, lane, ti, tj;
-    // tiles
+    // tiles: scaled [A|B] always in LDS; S^-1 and L in LDS (run-time horizon) or registers (kReg)
     double *tS, *tL, *tA;
+    double rS[kRS], rL[kRS];
     // variable-space vectors
     double *X, *Qv, *D, *XT, *DX, *VT, *AT;
-    // dynamics rows / box rows
-    double *Zd, *Yd, *Ed, *ZTd, *Wd, *DYd;
-    double *Zb, *Yb, *Eb, *ZTb, *Wb, *DYb, *Lo, *Hi;
+    // dynamics rows / box rows (ZT*: scratch rows; DY*: delta_y, or the active-set flags during polish)
+    double *Zd, *Yd, *Ed, *ZTd, *DYd;
+    double *Zb, *Yb, *Eb, *ZTb, *DYb, *Lo, *Hi;
     double *beq;   // [8] scaled x0 (bounds of the stage-0 dynamics rows)
     double c, cinv;
+    // row weights: ADMM rho classes (OSQP set_rho_vec) or, while polishing, |flag| = 1/delta on active rows
+    bool pol;
+    double rho, rho_eq, rinv, rinv_eq;
 
-    __device__ Solver(const DevCfg &cf, double *smem)
-        : cfg(cf), N(cf.N), NS(cf.N + 1), lane(threadIdx.x), ti(threadIdx.x >> 3), tj(threadIdx.x & 7) {
+    __device__ __forceinline__ Solver(const DevCfg &cf, double *smem)
+        : cfg(cf), N(kReg ? NT : cf.N), NS((kReg ? NT : cf.N) + 1), lane(threadIdx.x), ti(threadIdx.x >> 3), tj(threadIdx.x & 7) {
         double *p = smem;
-        tS = p; p += NS * kTS; tL = p; p += NS * kTS; tA = p; p += NS * kTS;
+        tA = p; p += NS * kTS;
+        tS = tL = nullptr;
+        if (!kReg) { tS = p; p += NS * kTS; tL = p; p += NS * kTS; }
         const int V = NS * 8;
         X = p; p += V; Qv = p; p += V; D = p; p += V; XT = p; p += V; DX = p; p += V; VT = p; p += V; AT = p; p += V;
-        Zd = p; p += V; Yd = p; p += V; Ed = p; p += V; ZTd = p; p += V; Wd = p; p += V; DYd = p; p += V;
-        Zb = p; p += V; Yb = p; p += V; Eb = p; p += V; ZTb = p; p += V; Wb = p; p += V; DYb = p; p += V;
+        Zd = p; p += V; Yd = p; p += V; Ed = p; p += V; ZTd = p; p += V; DYd = p; p += V;
+        Zb = p; p += V; Yb = p; p += V; Eb = p; p += V; ZTb = p; p += V; DYb = p; p += V;
         Lo = p; p += V; Hi = p; p += V;
         beq = p; p += 8;
-        c = 1.0; cinv = 1.0;
+        c = 1.0; cinv = 1.0; pol = false; rho = rho_eq = rinv = rinv_eq = 0.0;
     }
-    static __host__ __device__ size_t lds_doubles(int N) { return (size_t)(N + 1) * (3 * kTS + 21 * 8) + 8; }
+    static __host__ __device__ size_t lds_doubles(int N) {
+        return (size_t)(N + 1) * ((kReg ? 1 : 3) * kTS + 19 * 8) + 8;
+    }
 
     // ---- problem structure ---------------------------------------------------------------------
-    __device__ int nvar(int k) const { return k < N ? NB : NX; }
-    __device__ int nbox(int k) const { return kCtrl ? (k < N ? 6 : 0) : (k < N ? 7 : 5); }
-    __device__ static int box_var(int r) { return kCtrl ? (r < 2 ? 0 : (r < 4 ? 6 : 7)) : r; }
-    __device__ static double box_sign(int r) { return kCtrl ? ((r == 0 || r == 3 || r == 5) ? -1.0 : 1.0) : 1.0; }
-    __device__ static void rows_on(int a, int &first, int &cnt) {
+    __device__ __forceinline__ int nvar(int k) const { return k < N ? NB : NX; }
+    __device__ __forceinline__ int nbox(int k) const { return kCtrl ? (k < N ? 6 : 0) : (k < N ? 7 : 5); }
+    __device__ __forceinline__ static int box_var(int r) { return kCtrl ? (r < 2 ? 0 : (r < 4 ? 6 : 7)) : r; }
+    __device__ __forceinline__ static double box_sign(int r) { return kCtrl ? ((r == 0 || r == 3 || r == 5) ? -1.0 : 1.0) : 1.0; }
+    __device__ __forceinline__ static void rows_on(int a, int &first, int &cnt) {
         if (kCtrl) { first = (a == 0) ? 0 : (a == 6 ? 2 : 4); cnt = (a == 0 || a == 6 || a == 7) ? 2 : 0; }
         else { first = a; cnt = 1; }
     }
     // unscaled Hessian entry inside stage block k (P = 2*M0, CTRL:398-432,464 / PLAN:145-169)
-    __device__ double Pc(int k, int a, int b) const {
+    __device__ __forceinline__ double Pc(int k, int a, int b) const {
         if (a < NX && b < NX) return 2.0 * cfg.Q[a * NX + b];
         if (a >= NX && b >= NX && a < NB && b < NB && k < N) {
             double v = 2.0 * cfg.R[(a - NX) * 2 + (b - NX)];
@@ -134,16 +157,20 @@ struct Solver {
         return 0.0;
     }
     // OSQP constraint classes on scaled bounds (set_rho_vec)
-    __device__ static double rho_of(double lo, double hi, double rho) {
+    __device__ __forceinline__ static double rho_of(double lo, double hi, double rho) {
         if (lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling) return kRhoMin;
         if (hi - lo < kRhoTol) return kRhoEqOverIneq * rho;
         return rho;
     }
-    __device__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ void set_rho(double r) { rho = r; rho_eq = kRhoEqOverIneq * r; rinv = 1.0 / rho; rinv_eq = 1.0 / rho_eq; }
+    // weight of a box row / dynamics row in K = P + sig I + A' diag(W) A
+    __device__ __forceinline__ double w_box(int e) const { return pol ? fabs(DYb[e]) : rho_of(Lo[e], Hi[e], rho); }
+    __device__ __forceinline__ double w_dyn(int e) const { return pol ? fabs(DYd[e]) : rho_eq; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
 
     // ---- operators on the scaled problem ---------------------------------------------------------
     // (dstD, dstB) = A * src
-    __device__ void A_mul(const double *src, double *dstD, double *dstB) const {
+    __device__ __forceinline__ void A_mul(const double *src, double *dstD, double *dstB) const {
         for (int e = lane; e < NS * 8; e += 64) {
             const int k = e >> 3, r = e & 7;
             double v = 0.0;
@@ -163,7 +190,7 @@ struct Solver {
         }
     }
     // dst = A' * (srcD, srcB)
-    __device__ void At_mul(const double *srcD, const double *srcB, double *dst) const {
+    __device__ __forceinline__ void At_mul(const double *srcD, const double *srcB, double *dst) const {
         for (int e = lane; e < NS * 8; e += 64) {
             const int k = e >> 3, a = e & 7;
             double v = 0.0;
@@ -185,7 +212,7 @@ struct Solver {
         }
     }
     // dst = P * src   (P = c D P0 D)
-    __device__ void P_mul(const double *src, double *dst) const {
+    __device__ __forceinline__ void P_mul(const double *src, double *dst) const {
         for (int e = lane; e < NS * 8; e += 64) {
             const int k = e >> 3, a = e & 7;
             double v = 0.0;
@@ -203,7 +230,7 @@ struct Solver {
         }
     }
     // infinity norm of column (k,a) of the scaled Hessian
-    __device__ double P_colnorm(int k, int a) const {
+    __device__ __forceinline__ double P_colnorm(int k, int a) const {
         const int nv = nvar(k);
         if (a >= nv) return 0.0;
         double cn = 0.0;
@@ -217,7 +244,7 @@ struct Solver {
     }
 
     // ---- Ruiz equilibration (OSQP scale_data) ----------------------------------------------------
-    __device__ void scale_data() {
+    __device__ __forceinline__ void scale_data() {
         const int ntrue = NS * NX + N * 2;
         for (int it = 0; it < cfg.scaling; ++it) {
             // column norms of [P A'; A 0] -> XT (variables), ZTd / ZTb (rows)
@@ -276,8 +303,8 @@ struct Solver {
     // the next pivot is S_k = K_kk - G G' (a symmetric product of accurately known factors), which
     // keeps the factorisation accurate for the 1/delta-weighted polish system (cond ~ 1e9), where a
     // Schur complement formed through an explicit S^-1 loses ~7 digits.  Stored for the solve:
-    // S_k^-1 = C^-T C^-1 (tS) and L_k = G C_{k-1}^-1 (tL; transposed for odd k, see kkt_solve).
-    __device__ void factor(double sig) {
+    // S_k^-1 = C^-T C^-1 (tS / rS) and L_k = G C_{k-1}^-1 (tL / rL; transposed for odd k, see kkt_solve).
+    __device__ __forceinline__ void factor(double sig) {
         double cinv_prev = 0.0;
         for (int k = 0; k <= N; ++k) {
             const int nv = nvar(k);
@@ -288,13 +315,13 @@ struct Solver {
                     kd += sig;
                     int first, cnt; rows_on(ti, first, cnt);
                     for (int t = 0; t < cnt; ++t) { const int r = first + t;
-                        if (r < nbox(k)) { const double s = Eb[k * 8 + r] * D[k * 8 + ti]; kd += Wb[k * 8 + r] * s * s; } }
-                    if (ti < NX) { const double s = Ed[k * 8 + ti] * D[k * 8 + ti]; kd += Wd[k * 8 + ti] * s * s; }
+                        if (r < nbox(k)) { const double s = Eb[k * 8 + r] * D[k * 8 + ti]; kd += w_box(k * 8 + r) * s * s; } }
+                    if (ti < NX) { const double s = Ed[k * 8 + ti] * D[k * 8 + ti]; kd += w_dyn(k * 8 + ti) * s * s; }
                 }
                 if (k < N) {
                     const double *ca = tA + k * kTS + ti, *cb = tA + k * kTS + tj;
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) kd += Wd[(k + 1) * 8 + r] * ca[r * 8] * cb[r * 8];
+                    for (int r = 0; r < NX; ++r) kd += w_dyn((k + 1) * 8 + r) * ca[r * 8] * cb[r * 8];
                 }
             } else kd = (ti == tj) ? 1.0 : 0.0;
             double s = kd, l = 0.0;
@@ -302,7 +329,7 @@ struct Solver {
                 // off-diagonal block: rows = stage k, columns = stage k-1
                 double ko = 0.0;
                 if (tj < NB) {
-                    if (ti < NX) ko = -Wd[k * 8 + ti] * (Ed[k * 8 + ti] * D[k * 8 + ti]) * tA[(k - 1) * kTS + ti * 8 + tj];
+                    if (ti < NX) ko = -w_dyn(k * 8 + ti) * (Ed[k * 8 + ti] * D[k * 8 + ti]) * tA[(k - 1) * kTS + ti * 8 + tj];
                     else if (ti == tj && ti < nv) ko = c * D[k * 8 + ti] * (-2.0 * cfg.dR[ti - NX]) * D[(k - 1) * 8 + ti];
                 }
                 double g = 0.0;
@@ -313,7 +340,6 @@ struct Solver {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) l += __shfl(g, ti * 8 + t) * __shfl(cinv_prev, t * 8 + tj);     // L = G C^-1
             }
-            tL[k * kTS + ((k & 1) ? (tj * 8 + ti) : lane)] = l;
             // Cholesky S = C C' (lower)
             double cf = 0.0;
 #pragma unroll
@@ -335,7 +361,14 @@ struct Solver {
             double sinv = 0.0;
 #pragma unroll
             for (int t = 0; t < 8; ++t) sinv += __shfl(cf, t * 8 + ti) * __shfl(cf, t * 8 + tj);           // S^-1 = C^-T C^-1
-            tS[k * kTS + lane] = sinv;
+            if constexpr (kReg) {
+                const double lt = (k & 1) ? __shfl(l, tj * 8 + ti) : l;      // odd stages keep L_k transposed
+#pragma unroll
+                for (int kk = 0; kk <= NT; ++kk) if (kk == k) { rL[kk] = lt; rS[kk] = sinv; }
+            } else {
+                tL[k * kTS + ((k & 1) ? (tj * 8 + ti) : lane)] = l;
+                tS[k * kTS + lane] = sinv;
+            }
             cinv_prev = cf;
         }
         sync();
@@ -345,7 +378,39 @@ struct Solver {
     // Stage vectors alternate between "column form" (component ti, even stages) and "row form"
     // (component tj, odd stages); L_k is stored transposed for odd k, so every step of the two sweeps is
     // one tile product followed by one all-reduce, with no lane transposition on the dependent chain.
-    __device__ void kkt_solve() {
+    __device__ __forceinline__ void kkt_solve() {
+        if constexpr (kReg) {
+            // forward sweep y_k = b_k - L_k y_{k-1}, with the pivot products v_k = S_k^-1 y_k (off the
+            // dependent chain) issued alongside; only v goes to LDS, y stays in registers.
+            double yc = XT[ti], yr = 0.0;
+#pragma unroll
+            for (int k = 1; k <= NT; ++k) {
+                if (k & 1) {
+                    const double v = red_i(rS[k - 1] * yc);                 // S symmetric: sum over ti -> row form
+                    if (ti == 0) VT[(k - 1) * 8 + tj] = v;
+                    yr = XT[k * 8 + tj] - red_i(rL[k] * yc);
+                } else {
+                    const double v = red_j(rS[k - 1] * yr);
+                    if (tj == 0) VT[(k - 1) * 8 + ti] = v;
+                    yc = XT[k * 8 + ti] - red_j(rL[k] * yr);
+                }
+            }
+            if (NT & 1) { const double v = red_j(rS[NT] * yr); if (tj == 0) VT[NT * 8 + ti] = v; }
+            else        { const double v = red_i(rS[NT] * yc); if (ti == 0) VT[NT * 8 + tj] = v; }
+            sync();
+            STAMP(1);
+            // backward sweep x_k = v_k - L_{k+1}' x_{k+1}
+            double xc = VT[NT * 8 + ti], xr = VT[NT * 8 + tj];
+            if (lane < 8) XT[NT * 8 + lane] = VT[NT * 8 + lane];
+#pragma unroll
+            for (int k = NT - 1; k >= 0; --k) {
+                if (((k + 1) & 1) == 0) { xr = VT[k * 8 + tj] - red_i(rL[k + 1] * xc); if (ti == 0) XT[k * 8 + tj] = xr; }
+                else                    { xc = VT[k * 8 + ti] - red_j(rL[k + 1] * xr); if (tj == 0) XT[k * 8 + ti] = xc; }
+            }
+            sync();
+            STAMP(2);
+            return;
+        }
         // forward: y_k = b_k - L_k y_{k-1}
         double yc = XT[ti], yr = 0.0;
         for (int k = 1; k <= N; k += 2) {
@@ -382,7 +447,7 @@ struct Solver {
     struct Res { double pri, dua, nAx, nz, nPx, nAty, nq, s_pri, s_dua, s_Ax, s_z, s_Px, s_Aty, s_q; };
 
     // (xv, zd/zb, yd/yb) -> residual norms; leaves A x in ZT*, P x in VT, A'y in AT
-    __device__ Res residuals(const double *xv, const double *zd, const double *zb, const double *yd, const double *yb) {
+    __device__ __forceinline__ Res residuals(const double *xv, const double *zd, const double *zb, const double *yd, const double *yb) {
         A_mul(xv, ZTd, ZTb);
         P_mul(xv, VT);
         At_mul(yd, yb, AT);
@@ -411,7 +476,7 @@ struct Solver {
         sync();
         return r;
     }
-    __device__ double objective(const double *xv) {
+    __device__ __forceinline__ double objective(const double *xv) {
         P_mul(xv, VT);
         sync();
         double v = 0.0;
@@ -422,10 +487,10 @@ struct Solver {
     }
 
     // bounds of a dynamics row (equalities: l = u)
-    __device__ double dyn_bound(int e) const { return e < 8 ? beq[e] : 0.0; }
+    __device__ __forceinline__ double dyn_bound(int e) const { return e < 8 ? beq[e] : 0.0; }
 
     // ---- infeasibility certificates (OSQP is_primal_infeasible / is_dual_infeasible) ----------------
-    __device__ bool primal_infeasible(double eps) {
+    __device__ __forceinline__ bool primal_infeasible(double eps) {
         double nd = 0.0;
         for (int e = lane; e < NS * 8; e += 64) {
             // dynamics rows have finite bounds: no projection.  box rows: project on the polar recession cone
@@ -459,7 +524,7 @@ struct Solver {
         }
         return res;
     }
-    __device__ bool dual_infeasible(double eps) {
+    __device__ __forceinline__ bool dual_infeasible(double eps) {
         double nd = 0.0, qdx = 0.0;
         for (int e = lane; e < NS * 8; e += 64) { nd = fmax(nd, fabs(D[e] * DX[e])); qdx += Qv[e] * DX[e]; }
         nd = wave_max(nd); qdx = wave_sum(qdx);
@@ -490,22 +555,70 @@ struct Solver {
         return res;
     }
 
-    // set W (= rho_vec) from the constraint classes
-    __device__ void set_rho_vec(double rho) {
+    // w rows for the next right-hand side: ZT = rho z - y   (kept in ZT* between iterations)
+    __device__ __forceinline__ void recompute_w() {
         for (int e = lane; e < NS * 8; e += 64) {
-            Wd[e] = kRhoEqOverIneq * rho;              // dynamics rows: l == u
-            Wb[e] = rho_of(Lo[e], Hi[e], rho);
+            ZTd[e] = rho_eq * Zd[e] - Yd[e];
+            ZTb[e] = rho_of(Lo[e], Hi[e], rho) * Zb[e] - Yb[e];
+        }
+        sync();
+    }
+    // XT = sigma x - q + A' (rho z - y)        (OSQP compute_rhs, x part, reduced form)
+    __device__ __forceinline__ void build_rhs(double sigma) {
+        At_mul(ZTd, ZTb, XT);
+        for (int e = lane; e < NS * 8; e += 64) XT[e] += sigma * X[e] - Qv[e];     // same lane wrote XT[e]
+        sync();
+    }
+    // z~ = A x~ fused with OSQP update_x / update_z / update_y; leaves rho z - y in ZT*
+    __device__ __forceinline__ void update(double alpha, bool want_delta) {
+        for (int e = lane; e < NS * 8; e += 64) {
+            const int k = e >> 3, r = e & 7;
+            {   // dynamics row (k, r): bounds l = u = b
+                double zt = 0.0;
+                if (r < NX) {
+                    zt = Ed[e] * D[e] * XT[e];
+                    if (k >= 1) {
+                        const double *row = tA + (k - 1) * kTS + r * 8;
+                        const double *sv = XT + (k - 1) * 8;
+#pragma unroll
+                        for (int a = 0; a < NB; ++a) zt -= row[a] * sv[a];
+                    }
+                }
+                const double b = dyn_bound(e);
+                const double zr = alpha * zt + (1.0 - alpha) * Zd[e];
+                const double zn = clipd(zr + rinv_eq * Yd[e], b, b);
+                const double dy = rho_eq * (zr - zn), yn = Yd[e] + dy;
+                Yd[e] = yn; Zd[e] = zn; ZTd[e] = rho_eq * zn - yn;
+                if (want_delta) DYd[e] = dy;
+            }
+            {   // box row (k, r)
+                double zt = 0.0;
+                if (r < nbox(k)) { const int var = k * 8 + box_var(r); zt = box_sign(r) * Eb[e] * D[var] * XT[var]; }
+                const double lo = Lo[e], hi = Hi[e];
+                double w, winv;
+                if (lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling) { w = kRhoMin; winv = 1.0 / kRhoMin; }
+                else if (hi - lo < kRhoTol) { w = rho_eq; winv = rinv_eq; }
+                else { w = rho; winv = rinv; }
+                const double zr = alpha * zt + (1.0 - alpha) * Zb[e];
+                const double zn = clipd(zr + winv * Yb[e], lo, hi);
+                const double dy = w * (zr - zn), yn = Yb[e] + dy;
+                Yb[e] = yn; Zb[e] = zn; ZTb[e] = w * zn - yn;
+                if (want_delta) DYb[e] = dy;
+            }
+            const double xo = X[e], xn = alpha * XT[e] + (1.0 - alpha) * xo;
+            X[e] = xn;
+            if (want_delta) DX[e] = xn - xo;
         }
         sync();
     }
 
     // ---- the whole solve --------------------------------------------------------------------------
-    __device__ void run(const SolveArgs &a, int inst) {
+    __device__ __forceinline__ void run(const SolveArgs &a, int inst) {
         // ---------- load + build the unscaled problem ----------
         for (int e = lane; e < NS * kTS; e += 64) { tA[e] = 0.0; }
         for (int e = lane; e < NS * 8; e += 64) {
-            X[e] = 0; D[e] = 1.0; DX[e] = 0; Zd[e] = 0; Yd[e] = 0; Ed[e] = 1.0; DYd[e] = 0;
-            Zb[e] = 0; Yb[e] = 0; Eb[e] = 1.0; DYb[e] = 0; Lo[e] = 0; Hi[e] = 0; Qv[e] = 0;
+            X[e] = 0; D[e] = 1.0; DX[e] = 0; Zd[e] = 0; Yd[e] = 0; Ed[e] = 1.0; DYd[e] = 0; ZTd[e] = 0;
+            Zb[e] = 0; Yb[e] = 0; Eb[e] = 1.0; DYb[e] = 0; Lo[e] = 0; Hi[e] = 0; Qv[e] = 0; ZTb[e] = 0;
         }
         sync();
         {
@@ -541,59 +654,36 @@ struct Solver {
         for (int e = lane; e < NS * 8; e += 64) { Qv[e] *= c * D[e]; Lo[e] *= Eb[e]; Hi[e] *= Eb[e]; }
         if (lane < 8) beq[lane] *= Ed[lane];
         sync();
-        double rho = fmin(fmax(cfg.rho, kRhoMin), kRhoMax);
-        set_rho_vec(rho);
+        set_rho(fmin(fmax(cfg.rho, kRhoMin), kRhoMax));
         factor(cfg.sigma);
+        recompute_w();                      // cold start: x = z = y = 0
 
         // ---------- ADMM ----------
         const double alpha = cfg.alpha, sigma = cfg.sigma;
-        int status = LPVMPC_UNSOLVED_, iter = 0, rho_updates = 0, status_polish = 0;
+        int status = LPVMPC_UNSOLVED_, iter = 0, status_polish = 0;
         double pri_res = 0, dua_res = 0, obj = __builtin_nan("");
         Res R = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         bool checked = false;
         for (iter = 1; iter <= cfg.max_iter; ++iter) {
-            // rhs = sigma x - q + A'(rho z - y)
-            for (int e = lane; e < NS * 8; e += 64) { ZTd[e] = Wd[e] * Zd[e] - Yd[e]; ZTb[e] = Wb[e] * Zb[e] - Yb[e]; }
-            sync();
-            At_mul(ZTd, ZTb, XT);
-            sync();
-            for (int e = lane; e < NS * 8; e += 64) XT[e] += sigma * X[e] - Qv[e];
-            sync();
-            kkt_solve();
-            A_mul(XT, ZTd, ZTb);           // z~ = A x~
-            sync();
-            for (int e = lane; e < NS * 8; e += 64) {
-                const double xn = alpha * XT[e] + (1.0 - alpha) * X[e];
-                DX[e] = xn - X[e]; X[e] = xn;
-                {   // dynamics rows
-                    const double w = Wd[e], winv = 1.0 / w, b = dyn_bound(e);
-                    const double zr = alpha * ZTd[e] + (1.0 - alpha) * Zd[e];
-                    const double zn = clipd(zr + winv * Yd[e], b, b);
-                    const double dy = w * (zr - zn);
-                    Yd[e] += dy; Zd[e] = zn; DYd[e] = dy;
-                }
-                {   // box rows
-                    const double w = Wb[e], winv = 1.0 / w;
-                    const double zr = alpha * ZTb[e] + (1.0 - alpha) * Zb[e];
-                    const double zn = clipd(zr + winv * Yb[e], Lo[e], Hi[e]);
-                    const double dy = w * (zr - zn);
-                    Yb[e] += dy; Zb[e] = zn; DYb[e] = dy;
-                }
-            }
-            sync();
             checked = cfg.check_termination > 0 && (iter % cfg.check_termination == 0);
-            bool have_info = false;
-            if (checked) {
-                R = residuals(X, Zd, Zb, Yd, Yb); have_info = true;
+            const bool adapt = cfg.adaptive_rho && cfg.adaptive_rho_interval > 0 && (iter % cfg.adaptive_rho_interval == 0);
+#ifdef LPVMPC_STAMPS
+            tlast = __builtin_amdgcn_s_memtime();
+#endif
+            build_rhs(sigma);
+            STAMP(0);
+            kkt_solve();
+            update(alpha, checked);         // delta_x / delta_y are only read by the infeasibility tests
+            STAMP(3);
+            if (checked || adapt) {
+                R = residuals(X, Zd, Zb, Yd, Yb);
                 pri_res = R.pri; dua_res = R.dua;
-                if (check_termination(R, false, status)) break;
-            }
-            if (cfg.adaptive_rho && cfg.adaptive_rho_interval > 0 && (iter % cfg.adaptive_rho_interval == 0)) {
-                if (!have_info) { R = residuals(X, Zd, Zb, Yd, Yb); pri_res = R.pri; dua_res = R.dua; }
-                const double rn = rho_estimate(R, rho);
-                if (rn > rho * cfg.rho_tol || rn < rho / cfg.rho_tol) {
-                    rho = rn; set_rho_vec(rho); factor(sigma); ++rho_updates;
+                if (checked && check_termination(R, false, status)) break;
+                if (adapt) {
+                    const double rn = rho_estimate(R, rho);
+                    if (rn > rho * cfg.rho_tol || rn < rho / cfg.rho_tol) { set_rho(rn); factor(sigma); }
                 }
+                recompute_w();              // the residual evaluation used ZT* as scratch (and rho may have changed)
             }
         }
         if (iter > cfg.max_iter) iter = cfg.max_iter;
@@ -609,6 +699,7 @@ struct Solver {
         if (status == LPVMPC_PRIMAL_INFEASIBLE_ || status == LPVMPC_PRIMAL_INFEASIBLE_INACC_) obj = kInfty;
         if (status == LPVMPC_DUAL_INFEASIBLE_ || status == LPVMPC_DUAL_INFEASIBLE_INACC_) obj = -kInfty;
 
+        const double rho_admm = rho;
         // ---------- polish ----------
         if (cfg.polish && status == LPVMPC_SOLVED_) status_polish = polish(pri_res, dua_res, obj);
 
@@ -621,11 +712,20 @@ struct Solver {
             if (r < NX) a.xPred[((size_t)inst * NS + k) * NX + r] = v;
             else if (r < NB && k < N) a.uPred[((size_t)inst * N + k) * 2 + (r - NX)] = v;
         }
+#ifdef LPVMPC_STAMPS
+        if (lane == 0 && a.resid) {     // diagnostic build: resid carries per-iteration cycle counts instead
+            double *o = a.resid + (size_t)inst * 4;
+            o[0] = (double)stamp[0] / iter; o[1] = (double)stamp[1] / iter; o[2] = (double)stamp[2] / iter; o[3] = (double)stamp[3] / iter;
+            if (a.status) a.status[inst] = status;
+            if (a.iters) a.iters[inst] = iter;
+            return;
+        }
+#endif
         if (lane == 0) {
             if (a.status) a.status[inst] = status;
             if (a.iters) a.iters[inst] = iter;
             if (a.polish) a.polish[inst] = status_polish;
-            if (a.resid) { double *o = a.resid + (size_t)inst * 4; o[0] = pri_res; o[1] = dua_res; o[2] = obj; o[3] = rho; }
+            if (a.resid) { double *o = a.resid + (size_t)inst * 4; o[0] = pri_res; o[1] = dua_res; o[2] = obj; o[3] = rho_admm; }
         }
     }
 
@@ -635,7 +735,7 @@ struct Solver {
                          LPVMPC_DUAL_INFEASIBLE_ = -4, LPVMPC_NON_CVX_ = -7, LPVMPC_UNSOLVED_ = -10;
 
     // OSQP check_termination
-    __device__ bool check_termination(const Res &R, bool approx, int &status) {
+    __device__ __forceinline__ bool check_termination(const Res &R, bool approx, int &status) {
         double ea = cfg.eps_abs, er = cfg.eps_rel, epi = cfg.eps_prim_inf, edi = cfg.eps_dual_inf;
         if (R.pri > kInfty || R.dua > kInfty) { status = LPVMPC_NON_CVX_; return true; }
         if (approx) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
@@ -650,7 +750,7 @@ struct Solver {
         return false;
     }
     // OSQP compute_rho_estimate (scaled-space norms)
-    __device__ double rho_estimate(const Res &R, double rho) const {
+    __device__ __forceinline__ double rho_estimate(const Res &R, double rho) const {
         const double pr = R.s_pri / (fmax(R.s_z, R.s_Ax) + 1e-10);
         const double dr = R.s_dua / (fmax(R.s_q, fmax(R.s_Aty, R.s_Px)) + 1e-10);
         const double rn = rho * sqrt(pr / (dr + 1e-10));
@@ -660,7 +760,7 @@ struct Solver {
     // ---- polish (OSQP polish.c) on the reduced form ----------------------------------------------
     // active rows carry weight 1/delta in K_pol = P + delta I + A_act' A_act / delta; W > 0 marks
     // upper-active, W < 0 lower-active rows (|W| = 1/delta), W = 0 inactive.
-    __device__ int polish(double &pri_res, double &dua_res, double &obj) {
+    __device__ __forceinline__ int polish(double &pri_res, double &dua_res, double &obj) {
         const double delta = cfg.delta, dinv = 1.0 / cfg.delta;
         for (int e = lane; e < NS * 8; e += 64) {
             const int k = e >> 3, r = e & 7;
@@ -672,16 +772,16 @@ struct Solver {
             if (r < nbox(k)) {
                 if (Zb[e] - Lo[e] < -Yb[e]) wb = -dinv; else if (Hi[e] - Zb[e] < Yb[e]) wb = dinv;
             }
-            DYd[e] = wd; DYb[e] = wb;          // signed flags
-            Wd[e] = fabs(wd); Wb[e] = fabs(wb);
+            DYd[e] = wd; DYb[e] = wb;          // signed flags: w_dyn / w_box read |flag| while pol is set
         }
         sync();
+        pol = true;
         factor(delta);
         // px (DX), py (Yd/Yb are overwritten: ADMM duals are no longer needed)
         // initial solve: rhs = -q + A'(W b)
         for (int e = lane; e < NS * 8; e += 64) {
-            ZTd[e] = Wd[e] * dyn_bound(e);
-            ZTb[e] = Wb[e] * (DYb[e] > 0 ? Hi[e] : (DYb[e] < 0 ? Lo[e] : 0.0));
+            ZTd[e] = fabs(DYd[e]) * dyn_bound(e);
+            ZTb[e] = fabs(DYb[e]) * (DYb[e] > 0 ? Hi[e] : (DYb[e] < 0 ? Lo[e] : 0.0));
         }
         sync();
         At_mul(ZTd, ZTb, XT);
@@ -694,8 +794,8 @@ struct Solver {
         A_mul(DX, ZTd, ZTb);
         sync();
         for (int e = lane; e < NS * 8; e += 64) {
-            Yd[e] = Wd[e] * (ZTd[e] - dyn_bound(e));
-            Yb[e] = Wb[e] * (ZTb[e] - (DYb[e] > 0 ? Hi[e] : (DYb[e] < 0 ? Lo[e] : 0.0)));
+            Yd[e] = fabs(DYd[e]) * (ZTd[e] - dyn_bound(e));
+            Yb[e] = fabs(DYb[e]) * (ZTb[e] - (DYb[e] > 0 ? Hi[e] : (DYb[e] < 0 ? Lo[e] : 0.0)));
         }
         sync();
         for (int it = 0; it < cfg.polish_refine_iter; ++it) {
@@ -705,10 +805,10 @@ struct Solver {
             A_mul(DX, ZTd, ZTb);
             sync();
             for (int e = lane; e < NS * 8; e += 64) {
-                const double r2d = (Wd[e] != 0.0) ? dyn_bound(e) - ZTd[e] : 0.0;
-                const double r2b = (Wb[e] != 0.0) ? (DYb[e] > 0 ? Hi[e] : Lo[e]) - ZTb[e] : 0.0;
+                const double r2d = (DYd[e] != 0.0) ? dyn_bound(e) - ZTd[e] : 0.0;
+                const double r2b = (DYb[e] != 0.0) ? (DYb[e] > 0 ? Hi[e] : Lo[e]) - ZTb[e] : 0.0;
                 ZTd[e] = r2d; ZTb[e] = r2b;
-                Zd[e] = Wd[e] * r2d; Zb[e] = Wb[e] * r2b;
+                Zd[e] = fabs(DYd[e]) * r2d; Zb[e] = fabs(DYb[e]) * r2b;
             }
             sync();
             At_mul(Zd, Zb, XT);
@@ -720,8 +820,8 @@ struct Solver {
             sync();
             for (int e = lane; e < NS * 8; e += 64) {
                 DX[e] += XT[e];
-                Yd[e] += Wd[e] * (Zd[e] - ZTd[e]);
-                Yb[e] += Wb[e] * (Zb[e] - ZTb[e]);
+                Yd[e] += fabs(DYd[e]) * (Zd[e] - ZTd[e]);
+                Yb[e] += fabs(DYb[e]) * (Zb[e] - ZTb[e]);
             }
             sync();
         }
@@ -747,30 +847,47 @@ struct Solver {
     }
 };
 
-template <int NX>
+template <int NX, int NT>
 __global__ void __launch_bounds__(64) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
     extern __shared__ double smem[];
     const int inst = blockIdx.x;
     if (inst >= a.B) return;
-    Solver<NX> s(*cfgp, smem);
+    Solver<NX, NT> s(*cfgp, smem);
     s.run(a, inst);
 }
 
-size_t solve_lds_bytes(int N) { return Solver<6>::lds_doubles(N) * sizeof(double); }
-
-hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream) {
-    const size_t lds = solve_lds_bytes(cfg.N);
-    hipError_t err;
-    if (cfg.kind == 0) {
-        err = hipFuncSetAttribute((const void *)admm_solve_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+template <int NX, int NT>
+static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream) {
+    const size_t lds = Solver<NX, NT>::lds_doubles(cfg.N) * sizeof(double);
+    static bool attr_set = false;      // per instantiation; the attribute is per function, set once
+    if (!attr_set) {
+        hipError_t err = hipFuncSetAttribute((const void *)admm_solve_kernel<NX, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(admm_solve_kernel<6>, dim3(a.B), dim3(64), lds, stream, dcfg, a);
-    } else {
-        err = hipFuncSetAttribute((const void *)admm_solve_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(admm_solve_kernel<5>, dim3(a.B), dim3(64), lds, stream, dcfg, a);
+        attr_set = true;
     }
+    hipLaunchKernelGGL((admm_solve_kernel<NX, NT>), dim3(a.B), dim3(64), lds, stream, dcfg, a);
     return hipGetLastError();
+}
+
+// 1 if (kind, N) has a register-tile instantiation
+int solve_has_fast_path(int kind, int N) {
+    return (kind == 0 && (N == 20 || N == 10)) || (kind == 1 && (N == 30 || N == 40));
+}
+
+size_t solve_lds_bytes(int kind, int N) {
+    const bool fast = solve_has_fast_path(kind, N) != 0;
+    return (size_t)(N + 1) * ((fast ? 1 : 3) * kTS + 19 * 8) * sizeof(double) + 8 * sizeof(double);
+}
+
+hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream, int force_generic) {
+    if (cfg.kind == 0) {
+        if (!force_generic && cfg.N == 20) return launch_one<6, 20>(cfg, dcfg, a, stream);
+        if (!force_generic && cfg.N == 10) return launch_one<6, 10>(cfg, dcfg, a, stream);
+        return launch_one<6, 0>(cfg, dcfg, a, stream);
+    }
+    if (!force_generic && cfg.N == 30) return launch_one<5, 30>(cfg, dcfg, a, stream);
+    if (!force_generic && cfg.N == 40) return launch_one<5, 40>(cfg, dcfg, a, stream);
+    return launch_one<5, 0>(cfg, dcfg, a, stream);
 }
 
 }  // namespace lpvmpc

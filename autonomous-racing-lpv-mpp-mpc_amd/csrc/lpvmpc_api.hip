@@ -33,6 +33,7 @@ struct lpvmpc_handle {
     std::vector<hipEvent_t> ev0, ev1;   // ring of event pairs around the solve-kernel launches
     int ev_count;                       // pairs recorded since timing was (re)enabled
     bool timing;
+    int force_generic;                  // 1: always use the run-time-horizon kernel (validation)
     double last_ms;
     std::string err;
 };
@@ -125,7 +126,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     if (!h) { fail(nullptr, LPVMPC_E_NOMEM, "out of host memory"); return nullptr; }
     h->cfg = *cfg;
     h->nx = cfg->kind == LPVMPC_KIND_CONTROLLER ? 6 : 5; h->nb = h->nx + 2;
-    h->d_cfg = nullptr; h->cap = 0; h->timing = false; h->last_ms = -1.0; h->stream = nullptr; h->ev_count = 0;
+    h->d_cfg = nullptr; h->cap = 0; h->force_generic = 0; h->timing = false; h->last_ms = -1.0; h->stream = nullptr; h->ev_count = 0;
     h->d_x0 = h->d_uprev = h->d_vel = h->d_curv = h->d_uold = h->d_maxey = h->d_AB = h->d_states = nullptr;
     h->d_xPred = h->d_uPred = h->d_resid = h->d_xlast = h->d_delta = nullptr;
     h->d_status = h->d_iters = h->d_polish = nullptr;
@@ -156,7 +157,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     if (hipMalloc((void **)&h->d_cfg, sizeof(DevCfg)) != hipSuccess ||
         hipMemcpy(h->d_cfg, &h->dev, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) {
         fail(nullptr, LPVMPC_E_HIP, "uploading the configuration failed"); lpvmpc_destroy(h); return nullptr; }
-    const size_t lds = lpvmpc::solve_lds_bytes(cfg->N);
+    const size_t lds = lpvmpc::solve_lds_bytes(cfg->kind, cfg->N);
     if (lds > 160 * 1024) { fail(nullptr, LPVMPC_E_ARG, "N=%d needs %zu B of LDS per instance (> 160 KiB)", cfg->N, lds); lpvmpc_destroy(h); return nullptr; }
     return h;
 }
@@ -172,6 +173,12 @@ extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
 }
 
 extern "C" const char *lpvmpc_last_error(const lpvmpc_handle *h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+extern "C" int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value) {
+    if (!h || !name) return fail(h, LPVMPC_E_ARG, "lpvmpc_set_option: bad arguments");
+    if (std::strcmp(name, "force_generic_kernel") == 0) { h->force_generic = value != 0; return LPVMPC_OK; }
+    return fail(h, LPVMPC_E_ARG, "lpvmpc_set_option: unknown option '%s'", name);
+}
 
 extern "C" int lpvmpc_reserve(lpvmpc_handle *h, int32_t B) {
     if (!h || B <= 0) return fail(h, LPVMPC_E_ARG, "lpvmpc_reserve: bad arguments");
@@ -227,7 +234,7 @@ static int launch_lpv(lpvmpc_handle *h, int B, const double *x0, const double *u
 static int launch_solve_timed(lpvmpc_handle *h, const SolveArgs &a, hipStream_t st) {
     const int slot = h->ev_count % kEventRing;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0[slot], st));
-    HIP_TRY(h, lpvmpc::launch_solve(h->dev, h->d_cfg, a, st));
+    HIP_TRY(h, lpvmpc::launch_solve(h->dev, h->d_cfg, a, st, h->force_generic));
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev1[slot], st)); h->ev_count++; }
     return LPVMPC_OK;
 }

@@ -53,8 +53,9 @@ struct SolveArgs {
 };
 
 // host-side launchers (defined next to their kernels)
-size_t solve_lds_bytes(int N);
-hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream);
+int solve_has_fast_path(int kind, int N);
+size_t solve_lds_bytes(int kind, int N);
+hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream, int force_generic);
 hipError_t launch_lpv(const DevCfg &cfg, const DevCfg *dcfg, int B, const double *x0, const double *u_prev, const double *vel_ref,
                       const double *curv_s, double cf_new, int lap, double *states, double *AB, hipStream_t stream);
 hipError_t launch_abc(const DevCfg &cfg, const DevCfg *dcfg, int B, const double *xlast, const double *delta, double *AB, hipStream_t stream);

@@ -105,6 +105,11 @@ lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg);
 void lpvmpc_destroy(lpvmpc_handle *h);
 const char *lpvmpc_last_error(const lpvmpc_handle *h);
 
+/* Runtime options.  "force_generic_kernel" (0/1): solve with the run-time-horizon kernel even when a
+ * specialised (compile-time horizon, register-resident factor) instantiation exists -- used by the tests
+ * to cross-check the two kernels. */
+int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value);
+
 /* Pre-size the device workspace for batches up to B (otherwise grown on demand). */
 int lpvmpc_reserve(lpvmpc_handle *h, int32_t B);
 

@@ -141,3 +141,23 @@ def test_fused_batch_cfg2_against_oracle(lpvmpc):
         tol = 1e-6 if (r.info.status_polish == 1 and out["polish"][b] == 1) else 2e-4
         assert np.max(np.abs(out["xPred"][b] - xP)) <= tol * max(1.0, np.max(np.abs(xP))), b
         assert np.max(np.abs(out["uPred"][b] - uP)) <= tol, b
+
+
+def test_specialised_and_generic_kernels_agree(lpvmpc):
+    """The compile-time-horizon kernel (factor tiles in registers) and the run-time-horizon kernel (tiles in
+    LDS) run the same arithmetic: identical iteration counts / statuses, solutions equal to round-off."""
+    from lpvmpc import workloads
+    for w in (workloads.controller_batch(128, N=20, seed=5), workloads.planner_batch(64, N=30, seed=6)):
+        outs = []
+        for generic in (0, 1):
+            eng = workloads.make_solver(w)
+            eng.set_option("force_generic_kernel", generic)
+            outs.append(eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], w["max_ey"], w["cf_new"], w["lap"]))
+            eng.close()
+        a, b = outs
+        assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"])
+        assert np.array_equal(a["polish"], b["polish"])
+        ok = a["status"] > 0
+        ok &= np.all(np.isfinite(a["xPred"]).reshape(len(ok), -1), axis=1)
+        assert np.max(np.abs(a["xPred"][ok] - b["xPred"][ok])) < 1e-9
+        assert np.max(np.abs(a["uPred"][ok] - b["uPred"][ok])) < 1e-9
