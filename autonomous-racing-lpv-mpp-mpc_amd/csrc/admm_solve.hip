@@ -44,8 +44,9 @@ __device__ inline double wave_max(double v) {
 template <int CTRL>
 __device__ inline double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    // every lane has a valid source under these controls; bound_ctrl lets the destination start undefined
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 __device__ inline double xor16_sum(double v) {
@@ -81,6 +82,26 @@ __device__ inline double red_i(double v) {
 #endif
     return v;
 }
+// two independent all-reduces of the same kind, interleaved step by step (fills the DPP hazard slots
+// and the dependent-add latency of one with the other)
+__device__ inline void red_j2(double &a, double &b) {
+#ifdef LPVMPC_USE_SHFL
+    a = red_j(a); b = red_j(b);
+#else
+    double ta = dpp_mov<0xB1>(a), tb = dpp_mov<0xB1>(b); a += ta; b += tb;
+    ta = dpp_mov<0x4E>(a); tb = dpp_mov<0x4E>(b); a += ta; b += tb;
+    ta = dpp_mov<0x141>(a); tb = dpp_mov<0x141>(b); a += ta; b += tb;
+#endif
+}
+__device__ inline void red_i2(double &a, double &b) {
+#ifdef LPVMPC_USE_SHFL
+    a = red_i(a); b = red_i(b);
+#else
+    double ta = dpp_mov<0x128>(a), tb = dpp_mov<0x128>(b); a += ta; b += tb;
+    a = xor16_sum(a); b = xor16_sum(b);
+    a = xor32_sum(a); b = xor32_sum(b);
+#endif
+}
 __device__ inline double limit_scaling(double v) {
     v = v < kMinScaling ? 1.0 : v;
     return v > kMaxScaling ? kMaxScaling : v;
@@ -114,10 +135,16 @@ struct Solver {
     double *Zd, *Yd, *Ed, *ZTd, *DYd;
     double *Zb, *Yb, *Eb, *ZTb, *DYb, *Lo, *Hi;
     double *beq;   // [8] scaled x0 (bounds of the stage-0 dynamics rows)
+    double *SINK;  // [64 + 8 NS] write-only dump for the lanes that do not own a result (avoids exec masking)
+    double *Pm;    // [64] unscaled stage Hessian block 2*[Q 0; 0 R + 2 diag(dR)] (LDS copy of the weights)
+    double *dRl;   // [8]  dR[0..1]
     double c, cinv;
     // row weights: ADMM rho classes (OSQP set_rho_vec) or, while polishing, |flag| = 1/delta on active rows
     bool pol;
     double rho, rho_eq, rinv, rinv_eq;
+    // per-lane constants of the compact layout (component = lane & 7 in every 64-element round)
+    int r0, r1, bvar;     // box rows acting on variable tj (7 = none, its coefficient is 0); variable of box row tj
+    double rmask;         // 1 if tj is a real dynamics row
 
     __device__ __forceinline__ Solver(const DevCfg &cf, double *smem)
         : cfg(cf), N(kReg ? NT : cf.N), NS((kReg ? NT : cf.N) + 1), lane(threadIdx.x), ti(threadIdx.x >> 3), tj(threadIdx.x & 7) {
@@ -130,11 +157,13 @@ struct Solver {
         Zd = p; p += V; Yd = p; p += V; Ed = p; p += V; ZTd = p; p += V; DYd = p; p += V;
         Zb = p; p += V; Yb = p; p += V; Eb = p; p += V; ZTb = p; p += V; DYb = p; p += V;
         Lo = p; p += V; Hi = p; p += V;
-        beq = p; p += 8;
+        beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; SINK = p; p += 64 + 8 * NS;
+        { int first, cnt; rows_on(tj, first, cnt); r0 = cnt >= 1 ? first : 7; r1 = cnt >= 2 ? first + 1 : 7; }
+        bvar = box_var(tj); rmask = tj < NX ? 1.0 : 0.0;
         c = 1.0; cinv = 1.0; pol = false; rho = rho_eq = rinv = rinv_eq = 0.0;
     }
     static __host__ __device__ size_t lds_doubles(int N) {
-        return (size_t)(N + 1) * ((kReg ? 1 : 3) * kTS + 19 * 8) + 8;
+        return (size_t)(N + 1) * ((kReg ? 1 : 3) * kTS + 19 * 8 + 8) + 16 + 64 + 8 + 64;
     }
 
     // ---- problem structure ---------------------------------------------------------------------
@@ -146,15 +175,12 @@ struct Solver {
         if (kCtrl) { first = (a == 0) ? 0 : (a == 6 ? 2 : 4); cnt = (a == 0 || a == 6 || a == 7) ? 2 : 0; }
         else { first = a; cnt = 1; }
     }
-    // unscaled Hessian entry inside stage block k (P = 2*M0, CTRL:398-432,464 / PLAN:145-169)
+    // unscaled Hessian entry inside stage block k (P = 2*M0, CTRL:398-432,464 / PLAN:145-169); Pm holds the
+    // block of the stages k < N-1, the last input block has one dR less on its diagonal
     __device__ __forceinline__ double Pc(int k, int a, int b) const {
-        if (a < NX && b < NX) return 2.0 * cfg.Q[a * NX + b];
-        if (a >= NX && b >= NX && a < NB && b < NB && k < N) {
-            double v = 2.0 * cfg.R[(a - NX) * 2 + (b - NX)];
-            if (a == b) v += 2.0 * ((k < N - 1) ? 2.0 : 1.0) * cfg.dR[a - NX];
-            return v;
-        }
-        return 0.0;
+        double v = Pm[a * 8 + b];
+        if (a >= NX) { if (k >= N) v = 0.0; else if (k == N - 1 && a == b) v -= 2.0 * dRl[a - NX]; }
+        return v;
     }
     // OSQP constraint classes on scaled bounds (set_rho_vec)
     __device__ __forceinline__ static double rho_of(double lo, double hi, double rho) {
@@ -169,47 +195,54 @@ struct Solver {
     __device__ __forceinline__ void sync() const { __syncthreads(); }
 
     // ---- operators on the scaled problem ---------------------------------------------------------
+    // After equilibration the products that every A / A' application needs are cached in the two unused
+    // rows of each stage tile:  Eid[k][r] = Ed D (identity part of dynamics row r; 0 for padding) at
+    // tA[k][6][r] and Sb[k][r] = sign Eb D[var] (box row r; 0 when the row does not exist) at tA[k][7][r].
+    // Everything below is branch-free: padding rows / columns carry exact zeros.
+    __device__ __forceinline__ double &Eid(int k, int r) const { return tA[k * kTS + 48 + r]; }
+    __device__ __forceinline__ double &Sb(int k, int r) const { return tA[k * kTS + 56 + r]; }
+    __device__ __forceinline__ void cache_row_coefficients() {
+        for (int e = lane; e < NS * 8; e += 64) {
+            const int k = e >> 3, r = e & 7;
+            Eid(k, r) = r < NX ? Ed[e] * D[e] : 0.0;
+            Sb(k, r) = r < nbox(k) ? box_sign(r) * Eb[e] * D[k * 8 + box_var(r)] : 0.0;
+        }
+        sync();
+    }
+    // dynamics-row product of the previous stage: sum_a [A|B]_{k-1}[r][a] v_{k-1}[a]   (0 for k = 0)
+    __device__ __forceinline__ double prev_stage_dot(int k, const double *v) const {
+        const int kp = k > 0 ? k - 1 : 0;
+        const double *row = tA + kp * kTS + tj * 8, *sv = v + kp * 8;
+        const double r0_ = row[0], r1_ = row[1], r2_ = row[2], r3_ = row[3], r4_ = row[4], r5_ = row[5], r6_ = row[6], r7_ = row[7];
+        const double s0_ = sv[0], s1_ = sv[1], s2_ = sv[2], s3_ = sv[3], s4_ = sv[4], s5_ = sv[5], s6_ = sv[6], s7_ = sv[7];
+        const double acc0 = (r0_ * s0_ + r1_ * s1_) + (r2_ * s2_ + r3_ * s3_);
+        const double acc1 = (r4_ * s4_ + r5_ * s5_) + (r6_ * s6_ + r7_ * s7_);
+        return k > 0 ? acc0 + acc1 : 0.0;
+    }
     // (dstD, dstB) = A * src
     __device__ __forceinline__ void A_mul(const double *src, double *dstD, double *dstB) const {
         for (int e = lane; e < NS * 8; e += 64) {
-            const int k = e >> 3, r = e & 7;
-            double v = 0.0;
-            if (r < NX) {
-                v = Ed[e] * D[e] * src[e];
-                if (k >= 1) {
-                    const double *row = tA + (k - 1) * kTS + r * 8;
-                    const double *s = src + (k - 1) * 8;
-#pragma unroll
-                    for (int a = 0; a < NB; ++a) v -= row[a] * s[a];
-                }
-            }
-            dstD[e] = v;
-            double w = 0.0;
-            if (r < nbox(k)) { const int var = k * 8 + box_var(r); w = box_sign(r) * Eb[e] * D[var] * src[var]; }
-            dstB[e] = w;
+            const int k = e >> 3;
+            dstD[e] = rmask * (Eid(k, tj) * src[e] - prev_stage_dot(k, src));
+            dstB[e] = Sb(k, tj) * src[k * 8 + bvar];
         }
+    }
+    // value of (A' (srcD, srcB))[e]
+    __device__ __forceinline__ double At_elem(int e, const double *srcD, const double *srcB) const {
+        const int k = e >> 3, kn = k < N ? k + 1 : N;         // the stage-N tile is all zero
+        const double *col = tA + k * kTS + tj, *sd = srcD + kn * 8;
+        double c_[NX], d_[NX];
+#pragma unroll
+        for (int r = 0; r < NX; ++r) { c_[r] = col[r * 8]; d_[r] = sd[r]; }
+        const double sb0 = Sb(k, r0), sb1 = Sb(k, r1), w0 = srcB[k * 8 + r0], w1 = srcB[k * 8 + r1], ei = Eid(k, tj), wd = srcD[e];
+        double acc0 = c_[0] * d_[0] + c_[1] * d_[1], acc1 = c_[2] * d_[2] + c_[3] * d_[3];
+#pragma unroll
+        for (int r = 4; r < NX; ++r) acc0 += c_[r] * d_[r];
+        return (sb0 * w0 + sb1 * w1) + (ei * wd - (acc0 + acc1));
     }
     // dst = A' * (srcD, srcB)
     __device__ __forceinline__ void At_mul(const double *srcD, const double *srcB, double *dst) const {
-        for (int e = lane; e < NS * 8; e += 64) {
-            const int k = e >> 3, a = e & 7;
-            double v = 0.0;
-            if (a < nvar(k)) {
-                int first, cnt; rows_on(a, first, cnt);
-                for (int t = 0; t < cnt; ++t) {
-                    const int r = first + t;
-                    if (r < nbox(k)) v += box_sign(r) * Eb[k * 8 + r] * D[e] * srcB[k * 8 + r];
-                }
-                if (a < NX) v += Ed[e] * D[e] * srcD[e];
-                if (k < N) {
-                    const double *col = tA + k * kTS + a;
-                    const double *s = srcD + (k + 1) * 8;
-#pragma unroll
-                    for (int r = 0; r < NX; ++r) v -= col[r * 8] * s[r];
-                }
-            }
-            dst[e] = v;
-        }
+        for (int e = lane; e < NS * 8; e += 64) dst[e] = At_elem(e, srcD, srcB);
     }
     // dst = P * src   (P = c D P0 D)
     __device__ __forceinline__ void P_mul(const double *src, double *dst) const {
@@ -220,7 +253,7 @@ struct Solver {
             if (a < nv) {
                 for (int b = 0; b < nv; ++b) v += Pc(k, a, b) * D[k * 8 + b] * src[k * 8 + b];
                 if (a >= NX) {
-                    const double cpl = -2.0 * cfg.dR[a - NX];
+                    const double cpl = -2.0 * dRl[a - NX];
                     if (k + 1 < N) v += cpl * D[e + 8] * src[e + 8];
                     if (k >= 1) v += cpl * D[e - 8] * src[e - 8];
                 }
@@ -236,7 +269,7 @@ struct Solver {
         double cn = 0.0;
         for (int b = 0; b < nv; ++b) cn = fmax(cn, fabs(Pc(k, a, b)) * D[k * 8 + b]);
         if (a >= NX) {
-            const double cpl = 2.0 * fabs(cfg.dR[a - NX]);
+            const double cpl = 2.0 * fabs(dRl[a - NX]);
             if (k + 1 < N) cn = fmax(cn, cpl * D[(k + 1) * 8 + a]);
             if (k >= 1) cn = fmax(cn, cpl * D[(k - 1) * 8 + a]);
         }
@@ -315,8 +348,8 @@ struct Solver {
                     kd += sig;
                     int first, cnt; rows_on(ti, first, cnt);
                     for (int t = 0; t < cnt; ++t) { const int r = first + t;
-                        if (r < nbox(k)) { const double s = Eb[k * 8 + r] * D[k * 8 + ti]; kd += w_box(k * 8 + r) * s * s; } }
-                    if (ti < NX) { const double s = Ed[k * 8 + ti] * D[k * 8 + ti]; kd += w_dyn(k * 8 + ti) * s * s; }
+                        { const double s = Sb(k, r); kd += w_box(k * 8 + r) * s * s; } }
+                    { const double s = Eid(k, ti); kd += w_dyn(k * 8 + ti) * s * s; }
                 }
                 if (k < N) {
                     const double *ca = tA + k * kTS + ti, *cb = tA + k * kTS + tj;
@@ -329,8 +362,8 @@ struct Solver {
                 // off-diagonal block: rows = stage k, columns = stage k-1
                 double ko = 0.0;
                 if (tj < NB) {
-                    if (ti < NX) ko = -w_dyn(k * 8 + ti) * (Ed[k * 8 + ti] * D[k * 8 + ti]) * tA[(k - 1) * kTS + ti * 8 + tj];
-                    else if (ti == tj && ti < nv) ko = c * D[k * 8 + ti] * (-2.0 * cfg.dR[ti - NX]) * D[(k - 1) * 8 + ti];
+                    if (ti < NX) ko = -w_dyn(k * 8 + ti) * Eid(k, ti) * tA[(k - 1) * kTS + ti * 8 + tj];
+                    else if (ti == tj && ti < nv) ko = c * D[k * 8 + ti] * (-2.0 * dRl[ti - NX]) * D[(k - 1) * 8 + ti];
                 }
                 double g = 0.0;
 #pragma unroll
@@ -380,32 +413,51 @@ struct Solver {
     // one tile product followed by one all-reduce, with no lane transposition on the dependent chain.
     __device__ __forceinline__ void kkt_solve() {
         if constexpr (kReg) {
+            // Results of a reduction are replicated over 8 lanes; the owner lane stores to the vector, the
+            // other seven to SINK (same instruction, no exec masking).  Offsets 8*k are immediates.
+            double *const vrow = (ti == 0) ? VT + tj : SINK + lane;      // row-form results   (component tj)
+            double *const vcol = (tj == 0) ? VT + ti : SINK + lane;      // column-form results (component ti)
+            double *const xrow = (ti == 0) ? XT + tj : SINK + lane;
+            double *const xcol = (tj == 0) ? XT + ti : SINK + lane;
             // forward sweep y_k = b_k - L_k y_{k-1}, with the pivot products v_k = S_k^-1 y_k (off the
             // dependent chain) issued alongside; only v goes to LDS, y stays in registers.
             double yc = XT[ti], yr = 0.0;
+            // right-hand sides are fetched two stages ahead of their use (the loads do not depend on the chain)
+            double bq[3];
+            bq[1] = XT[1 * 8 + tj];
+            bq[2] = (NT >= 2) ? XT[2 * 8 + ti] : 0.0;
 #pragma unroll
             for (int k = 1; k <= NT; ++k) {
+                const double bk = bq[k % 3];
+                if (k + 2 <= NT) bq[(k + 2) % 3] = ((k + 2) & 1) ? XT[(k + 2) * 8 + tj] : XT[(k + 2) * 8 + ti];
                 if (k & 1) {
-                    const double v = red_i(rS[k - 1] * yc);                 // S symmetric: sum over ti -> row form
-                    if (ti == 0) VT[(k - 1) * 8 + tj] = v;
-                    yr = XT[k * 8 + tj] - red_i(rL[k] * yc);
+                    double pv = rS[k - 1] * yc, ch = rL[k] * yc;            // S symmetric: sum over ti -> row form
+                    red_i2(ch, pv);
+                    vrow[(k - 1) * 8] = pv;
+                    yr = bk - ch;
                 } else {
-                    const double v = red_j(rS[k - 1] * yr);
-                    if (tj == 0) VT[(k - 1) * 8 + ti] = v;
-                    yc = XT[k * 8 + ti] - red_j(rL[k] * yr);
+                    double pv = rS[k - 1] * yr, ch = rL[k] * yr;
+                    red_j2(ch, pv);
+                    vcol[(k - 1) * 8] = pv;
+                    yc = bk - ch;
                 }
             }
-            if (NT & 1) { const double v = red_j(rS[NT] * yr); if (tj == 0) VT[NT * 8 + ti] = v; }
-            else        { const double v = red_i(rS[NT] * yc); if (ti == 0) VT[NT * 8 + tj] = v; }
+            if (NT & 1) vcol[NT * 8] = red_j(rS[NT] * yr);
+            else        vrow[NT * 8] = red_i(rS[NT] * yc);
             sync();
             STAMP(1);
             // backward sweep x_k = v_k - L_{k+1}' x_{k+1}
             double xc = VT[NT * 8 + ti], xr = VT[NT * 8 + tj];
-            if (lane < 8) XT[NT * 8 + lane] = VT[NT * 8 + lane];
+            if (NT & 1) xrow[NT * 8] = xr; else xcol[NT * 8] = xc;
+            double vq[3];
+            vq[(NT - 1) % 3] = ((NT - 1) & 1) ? VT[(NT - 1) * 8 + tj] : VT[(NT - 1) * 8 + ti];
+            if (NT >= 2) vq[(NT - 2) % 3] = ((NT - 2) & 1) ? VT[(NT - 2) * 8 + tj] : VT[(NT - 2) * 8 + ti];
 #pragma unroll
             for (int k = NT - 1; k >= 0; --k) {
-                if (((k + 1) & 1) == 0) { xr = VT[k * 8 + tj] - red_i(rL[k + 1] * xc); if (ti == 0) XT[k * 8 + tj] = xr; }
-                else                    { xc = VT[k * 8 + ti] - red_j(rL[k + 1] * xr); if (tj == 0) XT[k * 8 + ti] = xc; }
+                const double vk = vq[k % 3];
+                if (k - 2 >= 0) vq[(k - 2) % 3] = ((k - 2) & 1) ? VT[(k - 2) * 8 + tj] : VT[(k - 2) * 8 + ti];
+                if (((k + 1) & 1) == 0) { xr = vk - red_i(rL[k + 1] * xc); xrow[k * 8] = xr; }
+                else                    { xc = vk - red_j(rL[k + 1] * xr); xcol[k * 8] = xc; }
             }
             sync();
             STAMP(2);
@@ -487,7 +539,7 @@ struct Solver {
     }
 
     // bounds of a dynamics row (equalities: l = u)
-    __device__ __forceinline__ double dyn_bound(int e) const { return e < 8 ? beq[e] : 0.0; }
+    __device__ __forceinline__ double dyn_bound(int e) const { return beq[e < 8 ? e : 8]; }
 
     // ---- infeasibility certificates (OSQP is_primal_infeasible / is_dual_infeasible) ----------------
     __device__ __forceinline__ bool primal_infeasible(double eps) {
@@ -565,49 +617,35 @@ struct Solver {
     }
     // XT = sigma x - q + A' (rho z - y)        (OSQP compute_rhs, x part, reduced form)
     __device__ __forceinline__ void build_rhs(double sigma) {
-        At_mul(ZTd, ZTb, XT);
-        for (int e = lane; e < NS * 8; e += 64) XT[e] += sigma * X[e] - Qv[e];     // same lane wrote XT[e]
+        for (int e = lane; e < NS * 8; e += 64) XT[e] = At_elem(e, ZTd, ZTb) + (sigma * X[e] - Qv[e]);
         sync();
     }
-    // z~ = A x~ fused with OSQP update_x / update_z / update_y; leaves rho z - y in ZT*
+    // z~ = A x~ fused with OSQP update_x / update_z / update_y; leaves rho z - y in ZT*.
+    // All LDS reads of a round are issued before any of its writes.
     __device__ __forceinline__ void update(double alpha, bool want_delta) {
+        const double oma = 1.0 - alpha;
         for (int e = lane; e < NS * 8; e += 64) {
-            const int k = e >> 3, r = e & 7;
-            {   // dynamics row (k, r): bounds l = u = b
-                double zt = 0.0;
-                if (r < NX) {
-                    zt = Ed[e] * D[e] * XT[e];
-                    if (k >= 1) {
-                        const double *row = tA + (k - 1) * kTS + r * 8;
-                        const double *sv = XT + (k - 1) * 8;
-#pragma unroll
-                        for (int a = 0; a < NB; ++a) zt -= row[a] * sv[a];
-                    }
-                }
-                const double b = dyn_bound(e);
-                const double zr = alpha * zt + (1.0 - alpha) * Zd[e];
-                const double zn = clipd(zr + rinv_eq * Yd[e], b, b);
-                const double dy = rho_eq * (zr - zn), yn = Yd[e] + dy;
-                Yd[e] = yn; Zd[e] = zn; ZTd[e] = rho_eq * zn - yn;
-                if (want_delta) DYd[e] = dy;
-            }
-            {   // box row (k, r)
-                double zt = 0.0;
-                if (r < nbox(k)) { const int var = k * 8 + box_var(r); zt = box_sign(r) * Eb[e] * D[var] * XT[var]; }
-                const double lo = Lo[e], hi = Hi[e];
-                double w, winv;
-                if (lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling) { w = kRhoMin; winv = 1.0 / kRhoMin; }
-                else if (hi - lo < kRhoTol) { w = rho_eq; winv = rinv_eq; }
-                else { w = rho; winv = rinv; }
-                const double zr = alpha * zt + (1.0 - alpha) * Zb[e];
-                const double zn = clipd(zr + winv * Yb[e], lo, hi);
-                const double dy = w * (zr - zn), yn = Yb[e] + dy;
-                Yb[e] = yn; Zb[e] = zn; ZTb[e] = w * zn - yn;
-                if (want_delta) DYb[e] = dy;
-            }
-            const double xo = X[e], xn = alpha * XT[e] + (1.0 - alpha) * xo;
+            const int k = e >> 3;
+            const double xt = XT[e], xo = X[e];
+            const double zd = Zd[e], yd = Yd[e], zb = Zb[e], yb = Yb[e], lo = Lo[e], hi = Hi[e];
+            const double b = dyn_bound(e), sb = Sb(k, tj), xv = XT[k * 8 + bvar], ei = Eid(k, tj);
+            const double dot = prev_stage_dot(k, XT);
+            // dynamics row (k, tj): bounds l = u = b
+            const double ztd = rmask * (ei * xt - dot);
+            const double zrd = alpha * ztd + oma * zd;
+            const double znd = clipd(zrd + rinv_eq * yd, b, b);
+            const double dyd = rho_eq * (zrd - znd), ynd = yd + dyd;
+            // box row (k, tj)
+            const bool loose = lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling, eq = hi - lo < kRhoTol;
+            const double w = loose ? kRhoMin : (eq ? rho_eq : rho), winv = loose ? 1.0 / kRhoMin : (eq ? rinv_eq : rinv);
+            const double zrb = alpha * (sb * xv) + oma * zb;
+            const double znb = clipd(zrb + winv * yb, lo, hi);
+            const double dyb = w * (zrb - znb), ynb = yb + dyb;
+            const double xn = alpha * xt + oma * xo;
+            Yd[e] = ynd; Zd[e] = znd; ZTd[e] = rho_eq * znd - ynd;
+            Yb[e] = ynb; Zb[e] = znb; ZTb[e] = w * znb - ynb;
             X[e] = xn;
-            if (want_delta) DX[e] = xn - xo;
+            if (want_delta) { DYd[e] = dyd; DYb[e] = dyb; DX[e] = xn - xo; }
         }
         sync();
     }
@@ -615,6 +653,16 @@ struct Solver {
     // ---- the whole solve --------------------------------------------------------------------------
     __device__ __forceinline__ void run(const SolveArgs &a, int inst) {
         // ---------- load + build the unscaled problem ----------
+        {   // weights -> LDS (the configuration block itself stays in global memory)
+            double v = 0.0;
+            if (ti < NX && tj < NX) v = 2.0 * cfg.Q[ti * NX + tj];
+            else if (ti >= NX && tj >= NX && ti < NB && tj < NB) {
+                v = 2.0 * cfg.R[(ti - NX) * 2 + (tj - NX)];
+                if (ti == tj) v += 4.0 * cfg.dR[ti - NX];
+            }
+            Pm[lane] = v;
+            if (lane < 8) dRl[lane] = lane < 2 ? cfg.dR[lane] : 0.0;
+        }
         for (int e = lane; e < NS * kTS; e += 64) { tA[e] = 0.0; }
         for (int e = lane; e < NS * 8; e += 64) {
             X[e] = 0; D[e] = 1.0; DX[e] = 0; Zd[e] = 0; Yd[e] = 0; Ed[e] = 1.0; DYd[e] = 0; ZTd[e] = 0;
@@ -635,7 +683,7 @@ struct Solver {
             // linear cost: controller q = -2 xtrack' M0 (CTRL:434-447); planner q = L_cf (PLAN:163)
             double q = 0.0;
             if (r < NX) {
-                if (kCtrl) q = -2.0 * cfg.Q[0 * NX + r] * a.vel_ref[(size_t)inst * (N + 1) + k];
+                if (kCtrl) q = -cfg.Q[0 * NX + r] * 2.0 * a.vel_ref[(size_t)inst * (N + 1) + k];
                 else q = cfg.Lcf[r];
             } else if (r < NB && k == 0) q = -2.0 * (r == NX ? uo0 : uo1) * cfg.dR[r - NX];   // CTRL:462 / PLAN:167
             Qv[e] = q;
@@ -646,7 +694,7 @@ struct Solver {
                 Lo[e] = fmax(lo, -kInfty); Hi[e] = fmin(hi, kInfty);
             }
         }
-        if (lane < 8) beq[lane] = (lane < NX) ? a.x0[(size_t)inst * NX + lane] : 0.0;
+        if (lane < 16) beq[lane] = (lane < NX) ? a.x0[(size_t)inst * NX + lane] : 0.0;
         sync();
 
         // ---------- setup: scaling, rho, factorisation ----------
@@ -654,6 +702,7 @@ struct Solver {
         for (int e = lane; e < NS * 8; e += 64) { Qv[e] *= c * D[e]; Lo[e] *= Eb[e]; Hi[e] *= Eb[e]; }
         if (lane < 8) beq[lane] *= Ed[lane];
         sync();
+        cache_row_coefficients();
         set_rho(fmin(fmax(cfg.rho, kRhoMin), kRhoMax));
         factor(cfg.sigma);
         recompute_w();                      // cold start: x = z = y = 0
@@ -876,7 +925,7 @@ int solve_has_fast_path(int kind, int N) {
 
 size_t solve_lds_bytes(int kind, int N) {
     const bool fast = solve_has_fast_path(kind, N) != 0;
-    return (size_t)(N + 1) * ((fast ? 1 : 3) * kTS + 19 * 8) * sizeof(double) + 8 * sizeof(double);
+    return ((size_t)(N + 1) * ((fast ? 1 : 3) * kTS + 19 * 8 + 8) + 16 + 64 + 8 + 64) * sizeof(double);
 }
 
 hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream, int force_generic) {

@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU (default: configs[1] = 1024)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="HIP streams the K steps are issued on round-robin (independent batches overlap, so the few "
+                         "slow instances of one batch do not leave the GPU idle); 1 = strictly back-to-back steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -71,17 +74,28 @@ def main():
     eng.reserve(B)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     x0, u_prev, vel_ref, curv, u_old = t(w["x0"]), t(w["u_prev"]), t(w["vel_ref"]), t(w["curv_s"]), t(w["u_old"])
-    xPred = torch.empty((B, N + 1, 6), dtype=torch.float64, device=dev)
-    uPred = torch.empty((B, N, 2), dtype=torch.float64, device=dev)
-    status = torch.empty(B, dtype=torch.int32, device=dev)
-    iters = torch.empty(B, dtype=torch.int32, device=dev)
-    resid = torch.empty((B, 4), dtype=torch.float64, device=dev)
-    polish = torch.empty(B, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # one engine (workspace + output buffers) per stream: steps issued on different streams are independent
+    S = max(1, args.streams)
+    engines = [eng] + [workloads.make_solver(w, device=local_rank) for _ in range(S - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    outs = []
+    for e in engines:
+        e.reserve(B)
+        outs.append(dict(xPred=torch.empty((B, N + 1, 6), dtype=torch.float64, device=dev),
+                         uPred=torch.empty((B, N, 2), dtype=torch.float64, device=dev),
+                         status=torch.empty(B, dtype=torch.int32, device=dev),
+                         iters=torch.empty(B, dtype=torch.int32, device=dev),
+                         resid=torch.empty((B, 4), dtype=torch.float64, device=dev),
+                         polish=torch.empty(B, dtype=torch.int32, device=dev)))
+    iters, status = outs[0]["iters"], outs[0]["status"]
+    counter = [0]
 
     def step():
-        eng.solve_dev(B, x0, u_prev, vel_ref, curv, u_old, None, xPred, uPred, status, iters, resid, polish,
-                      cf_new=w["cf_new"], lap=w["lap"], stream=stream)
+        i = counter[0] % S
+        counter[0] += 1
+        o = outs[i]
+        engines[i].solve_dev(B, x0, u_prev, vel_ref, curv, u_old, None, o["xPred"], o["uPred"], o["status"], o["iters"],
+                             o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"], stream=streams[i].cuda_stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -91,19 +105,24 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    eng.set_timing(True)              # HIP events on the launch stream around every solve-kernel launch
+    for e in engines:
+        e.set_timing(True)            # HIP events on the launch stream around every solve-kernel launch
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    k_ms, k_n = eng.kernel_time_stats()
-    eng.set_timing(False)
+    k_ms = k_n = 0
+    for e in engines:
+        ms_, n_ = e.kernel_time_stats()
+        k_ms += ms_; k_n += n_
+        e.set_timing(False)
 
     # p50 latency of one synchronous batch (outside the timed region)
     lat = []
     for _ in range(min(20, max(5, args.steps))):
+        counter[0] = 0
         torch.cuda.synchronize(); t1 = time.perf_counter(); step(); torch.cuda.synchronize()
         lat.append((time.perf_counter() - t1) * 1e3)
     p50 = float(np.median(lat))
@@ -141,19 +160,22 @@ def main():
                        "mean_admm_iters": float(agg[0].item()) / (B * world),
                        "max_admm_iters_rank0": int(it_host.max()),
                        "solved_fraction": float(agg[1].item()) / (B * world),
-                       "p50_batch_latency_ms": p50},
+                       "p50_batch_latency_ms": p50, "streams": S},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "admm_solve_kernel<6>", "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
                          "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_admm_iteration": bytes_iter,
                          "note": "algorithmic bytes per SURVEY 8(d) (factor + vectors streamed once per ADMM "
-                                 "iteration); the kernel keeps them in LDS, so real HBM traffic is far lower"},
+                                 "iteration); the kernel keeps them in LDS/registers, so real HBM traffic is far lower. "
+                                 "With --streams > 1 launches overlap, so the per-launch duration includes time "
+                                 "spent sharing the GPU with the neighbouring batches"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out), flush=True)
 
-    eng.close()
+    for e in engines:
+        e.close()
     if world > 1:
         dist.destroy_process_group()
 
