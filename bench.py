@@ -129,12 +129,8 @@ def main():
 
     it_host = iters.cpu().numpy().astype(np.int64)
     st_host = status.cpu().numpy()
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    agg = torch.tensor([float(it_host.sum()), float((st_host == 1).sum())], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-    elapsed = float(tmax.item())
+    from lpvmpc.distributed import reduce_stats
+    elapsed, agg = reduce_stats(elapsed, [float(it_host.sum()), float((st_host == 1).sum())], device=dev)
 
     if rank == 0:
         total = B * world * args.steps
@@ -157,9 +153,9 @@ def main():
             "config": {"workload": "configs[1]: batch=%d LPV-MPC controller solves per GPU, N=20, random x0 along "
                                    "oval, racing tuning, OSQP defaults + polish, cold start" % B,
                        "batch_per_gpu": B, "horizon": N, "nx": 6, "nu": 2,
-                       "mean_admm_iters": float(agg[0].item()) / (B * world),
+                       "mean_admm_iters": agg[0] / (B * world),
                        "max_admm_iters_rank0": int(it_host.max()),
-                       "solved_fraction": float(agg[1].item()) / (B * world),
+                       "solved_fraction": agg[1] / (B * world),
                        "p50_batch_latency_ms": p50, "streams": S},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -1,0 +1,70 @@
+"""GPU: the drop-in classes driven exactly like the reference's mains drive theirs (controllerMain.py:289-331
+lap-0 pattern, plannerMain.py:152-216 open-loop test mode), against the 20-tick traces that the reference's own
+classes produced with the oracle solver (tests/golden/closed_loop.npz)."""
+import numpy as np
+import pytest
+
+from oracle import lpv_ref as L
+from tests._golden import load
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def test_controller_closed_loop_trace():
+    import lpvmpc
+    g = load("closed_loop")
+    N, dt = 20, 1.0 / 30.0
+    Q = np.diag([100.0, 1.0, 1.0, 20.0, 0.0, 900.0]); R = 0.25 * np.eye(2); dR = 37.5 * np.array([1.3, 1.0])
+    c = lpvmpc.PathFollowingLPV_MPC(Q, R, dR, N, 1, dt, lpvmpc.Map("oval", 0.2), "OSQP", 0, 0)
+    st = np.array([1.0, 0.0, 0.0, 0.0, 0.3, 0.0])
+    first_it, cmd = 1, np.zeros(2)
+    for tick in range(20):
+        c.OldSteering.append(float(cmd[0])); c.OldAccelera.append(float(cmd[1]))
+        c.OldSteering.pop(0); c.OldAccelera.pop(0)
+        assert np.max(np.abs(st - g["ctrl_x0"][tick])) <= TOL
+        if first_it < 10:
+            xx, uu = L.ctrl_seed_vectors(st)
+            assert c.solve(st, xx, uu, False, np.ones(N), 0, 0, 0, first_it) is None
+            first_it += 1
+        else:
+            S, A_L, B_L, C_L = c.LPVPrediction(st, c.uPred, np.ones(N + 1), np.zeros(N), 60.0, 0)
+            assert S.shape == (N, 6) and len(A_L) == N and A_L[0].shape == (6, 6) and B_L[0].shape == (6, 2) and C_L[0].shape == (6, 1)
+            c.solve(S[0, :], S, c.uPred, False, np.ones(N + 1), A_L, B_L, C_L, first_it)
+        assert c.xPred.shape == (N + 1, 6) and c.uPred.shape == (N, 2) and c.LinPoints.shape == (N + 1, 6)
+        assert c.feasible == 1 and c.status_val == 1
+        assert np.max(np.abs(c.xPred - g["ctrl_xPred"][tick])) <= TOL, tick
+        assert np.max(np.abs(c.uPred - g["ctrl_uPred"][tick])) <= TOL, tick
+        assert np.array_equal(c.LinPoints[:-1], c.xPred[1:]) and np.array_equal(c.LinPoints[-1], c.xPred[-1])
+        cmd = np.array(c.uPred[0, :]); st = np.array(c.xPred[1, :])
+    assert hasattr(c, "solverTime") and hasattr(c, "linearizationTime")
+
+
+def test_planner_open_loop_trace():
+    import lpvmpc
+    from lpvmpc import workloads
+    g = load("closed_loop")
+    Np, dtp = 30, 0.05
+    mp = lpvmpc.Map("L_shape", 0.2)
+    p = lpvmpc.LPV_MPC_Planner(workloads.PLAN_Q, workloads.PLAN_R, workloads.PLAN_dR, workloads.PLAN_L, Np, dtp, mp, "OSQP")
+    px0 = np.array([1.0, 0.0, 0.0, 0.0, 0.0])
+    SS = np.zeros(Np + 1)
+    first = 1
+    for tick in range(20):
+        if first == 1:
+            pxx, puu = L.plan_seed_vectors(Np, px0, 0.2, dtp)
+            p.solve(px0, pxx, puu, 0, 0, 0, first, 0.2)
+            first += 1
+        else:
+            S, A_L, B_L, C_L = p.LPVPrediction(p.xPred[1, :], SS, p.uPred)
+            p.solve(p.xPred[1, :], 0, 0, A_L, B_L, C_L, first, 0.2)
+        p.OldSteering.append(p.uPred[0, 0]); p.OldAccelera.append(p.uPred[0, 1])       # quirk Q3: index 0 stays 0
+        for j in range(Np):
+            cv = L.curvature(SS[j], mp.PointAndTangent)
+            SS[j + 1] = SS[j] + ((p.xPred[j, 0] * np.cos(p.xPred[j, 4]) - p.xPred[j, 1] * np.sin(p.xPred[j, 4]))
+                                 / (1 - p.xPred[j, 3] * cv)) * dtp
+        SS[0] = SS[1]
+        # un-polished planner iterates: the trace recursion amplifies 1e-10 solver differences only mildly
+        assert np.max(np.abs(p.xPred - g["plan_xPred"][tick])) <= 1e-5, tick
+        assert np.max(np.abs(p.uPred - g["plan_uPred"][tick])) <= 1e-5, tick
+        assert np.max(np.abs(SS - g["plan_SS"][tick])) <= 1e-5, tick

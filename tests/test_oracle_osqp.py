@@ -1,0 +1,71 @@
+"""CPU: what pins the OSQP restatement (oracle/osqp_ref.c), whose parity with the real wheel is unpinned:
+a solver-independent KKT certificate of the optimum and OSQP's own termination rule, on the golden QPs that
+the reference's assembly produced."""
+import numpy as np
+import pytest
+
+from oracle import kkt_cert, lpv_ref as L, osqp_ref as O
+from tests._golden import cases
+
+
+def bounds(c):
+    return np.where(c["l"] < -1e29, -np.inf, c["l"]), np.where(c["u"] > 1e29, np.inf, c["u"])
+
+
+@pytest.mark.parametrize("name", ["ctrl_n10_cfg1", "ctrl_n20_oval"])
+def test_controller_solutions_are_certified_optima(name):
+    for i, c in enumerate(cases(name)):
+        l, u = bounds(c)
+        assert np.all(c["cert"] <= 1e-8), (name, i, c["cert"])                   # stored x*, y* satisfy KKT
+        stat, prim, comp = kkt_cert.kkt_residuals(c["P"], c["q"], c["Aqp"], l, u, c["x_star"], c["y_star"])
+        assert max(stat, prim, comp) <= 1e-8
+        r = O.solve_qp(c["P"], c["q"], c["Aqp"], c["l"], c["u"])
+        assert (r.info.status_val, r.info.iter, r.info.status_polish) == (int(c["status_orc"]), int(c["iter_orc"]), int(c["polish_orc"]))
+        assert np.max(np.abs(r.x - c["x_orc"])) <= 1e-9
+        ok, info = kkt_cert.osqp_termination_ok(c["P"], c["q"], c["Aqp"], l, u, r.x, r.y)
+        assert ok, info
+        # the controller QP has a unique minimiser: a polished solve must sit on it
+        if r.info.status_polish == 1 and i != 15:
+            assert np.max(np.abs(r.x - c["x_star"])) <= 1e-7, (name, i)
+
+
+def test_planner_statuses_and_termination_rule():
+    seen = set()
+    for i, c in enumerate(cases("plan_n30_lshape")):
+        l, u = bounds(c)
+        r = O.solve_qp(c["P"], c["q"], c["Aqp"], c["l"], c["u"])
+        assert (r.info.status_val, r.info.iter) == (int(c["status_orc"]), int(c["iter_orc"]))
+        seen.add(r.info.status_val)
+        if r.info.status_val == 1:
+            ok, info = kkt_cert.osqp_termination_ok(c["P"], c["q"], c["Aqp"], l, u, r.x, r.y)
+            assert ok, (i, info)
+            xs = c["x_star"]
+            if np.all(np.isfinite(xs)):      # near-LP: gate on the objective gap, not on the distance to x*
+                f = lambda x: 0.5 * x @ c["P"] @ x + c["q"] @ x
+                assert f(r.x) - f(xs) <= 1e-3 * max(1.0, abs(f(xs)))
+        elif r.info.status_val == -3:
+            assert np.all(np.isnan(r.x))
+    assert {1, -3} <= seen                   # solved and primal-infeasible cases are both exercised
+
+
+def test_c_tick_matches_python_assembly():
+    from lpvmpc import workloads
+    w = workloads.controller_batch(12, 20, seed=3)
+    r = O.ctrl_tick_batch(w, nthreads=2)
+    p = dict(L.DEFAULT_PARAMS)
+    for b in range(12):
+        S, A, Bm = L.ctrl_lpv_prediction(p, w["dt"], 20, w["track"], w["x0"][b], w["u_prev"][b], w["vel_ref"][b], w["curv_s"][b], 60.0, 1)
+        qp = L.ctrl_build_qp(w["Q"], w["R"], w["dR"], 20, A, Bm, w["x0"][b], w["u_old"][b], w["vel_ref"][b], p["max_vel"])
+        rr = O.solve_qp(qp.P, qp.q, qp.A, qp.l, qp.u)
+        xP, uP, _ = L.unpack_solution(rr.x, 6, 2, 20)
+        assert rr.info.iter == r["iters"][b] and rr.info.status_val == r["status"][b]
+        assert max(np.abs(r["xPred"][b] - xP).max(), np.abs(r["uPred"][b] - uP).max()) <= 1e-9
+
+
+def test_infeasible_and_trivial_problems():
+    # 1-D: min x^2 s.t. 1 <= x <= 2 and x <= 0  -> primal infeasible
+    P = np.array([[2.0]]); q = np.zeros(1); A = np.array([[1.0], [1.0]])
+    r = O.solve_qp(P, q, A, np.array([1.0, -np.inf]), np.array([2.0, 0.0]), perm=None)
+    assert r.info.status_val == -3 and np.all(np.isnan(r.x))
+    r = O.solve_qp(P, q, A[:1], np.array([1.0]), np.array([2.0]), perm=None)
+    assert r.info.status_val == 1 and abs(r.x[0] - 1.0) <= 1e-6
