@@ -25,16 +25,6 @@
 
 namespace lpvmpc {
 
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-    return v;
-}
-__device__ inline double wave_max(double v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m));
-    return v;
-}
 // ---- cross-lane primitives (CDNA4) ------------------------------------------------------------
 // A tile element [i][j] lives in lane 8*i+j.  Summing over j stays inside an 8-lane group: two quad
 // permutes and a half-row mirror, all DPP modifiers on v_mov (a 64-bit value moves as two dwords).
@@ -82,6 +72,60 @@ __device__ inline double red_i(double v) {
 #endif
     return v;
 }
+// whole-wavefront all-reduces (sum / max): 8-lane group, row_ror:8, then the two row-crossing swaps
+__device__ inline void xor16_pair(double v, double &x, double &y) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    x = __hiloint2double(b[0], a[0]); y = __hiloint2double(b[1], a[1]);
+}
+__device__ inline void xor32_pair(double v, double &x, double &y) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    x = __hiloint2double(b[0], a[0]); y = __hiloint2double(b[1], a[1]);
+}
+__device__ inline double wave_sum(double v) {
+#ifdef LPVMPC_USE_SHFL
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+#else
+    return red_i(red_j(v));
+#endif
+}
+__device__ inline double wave_max(double v) {
+#ifdef LPVMPC_USE_SHFL
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
+#else
+    v = fmax(v, dpp_mov<0xB1>(v)); v = fmax(v, dpp_mov<0x4E>(v)); v = fmax(v, dpp_mov<0x141>(v));
+    v = fmax(v, dpp_mov<0x128>(v));
+    double x, y;
+    xor16_pair(v, x, y); v = fmax(x, y);
+    xor32_pair(v, x, y); v = fmax(x, y);
+    return v;
+#endif
+}
+// value of lane SRC in every lane (uniform source lane): two v_readlane
+template <int SRC>
+__device__ inline double bcast_lane(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC), hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
+    return __hiloint2double(hi, lo);
+}
+// tile element [i][T] in every lane (i, .): broadcast lane T of each 8-lane group, two DPP moves per dword
+template <int T>
+__device__ inline double bcast_row(double v) {
+    constexpr int q = T & 3, QP = q | (q << 2) | (q << 4) | (q << 6);
+    constexpr int BM = (T >> 2) ? 0x5 : 0xA;          // banks (quads of a row) that still hold the other quad's value
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, QP, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, QP, 0xF, 0xF, true);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, BM, false);     // row_half_mirror into the masked banks
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, BM, false);
+    return __hiloint2double(hi, lo);
+}
 // two independent all-reduces of the same kind, interleaved step by step (fills the DPP hazard slots
 // and the dependent-add latency of one with the other)
 __device__ inline void red_j2(double &a, double &b) {
@@ -105,6 +149,13 @@ __device__ inline void red_i2(double &a, double &b) {
 __device__ inline double limit_scaling(double v) {
     v = v < kMinScaling ? 1.0 : v;
     return v > kMaxScaling ? kMaxScaling : v;
+}
+// 1/sqrt(x) to double precision: hardware estimate + two Newton steps (x in [1e-4, 1e4] here)
+__device__ inline double inv_sqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
 }
 __device__ inline double clipd(double t, double lo, double hi) { return t < lo ? lo : (t > hi ? hi : t); }
 
@@ -244,72 +295,72 @@ struct Solver {
     __device__ __forceinline__ void At_mul(const double *srcD, const double *srcB, double *dst) const {
         for (int e = lane; e < NS * 8; e += 64) dst[e] = At_elem(e, srcD, srcB);
     }
+    // row a of the stage-k Hessian block times (D_k .* v_k), plus the slew-rate coupling to the neighbouring
+    // stages; ABS = true gives the infinity norm of the (scaled) column instead.  Branch-free: the Pm row is
+    // zero outside its diagonal block, the stage-N input rows are switched off explicitly.
+    template <bool ABS>
+    __device__ __forceinline__ double P_row(int k, const double *v) const {
+        const int a = tj, e = k * 8 + a;
+        const double2 *pr = reinterpret_cast<const double2 *>(Pm + a * 8);
+        const double2 *dr = reinterpret_cast<const double2 *>(D + k * 8);
+        const double2 *vr = reinterpret_cast<const double2 *>(v + k * 8);
+        const bool inp = a >= NX;
+        const double dadj = (inp && k == N - 1) ? 2.0 * dRl[inp ? a - NX : 0] : 0.0;     // last input block: one dR less
+        double acc = 0.0;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            double2 p = pr[h];
+            const double2 d = dr[h];
+            if (2 * h == a) p.x -= dadj;
+            if (2 * h + 1 == a) p.y -= dadj;
+            if (ABS) { acc = fmax(acc, fabs(p.x) * d.x); acc = fmax(acc, fabs(p.y) * d.y); }
+            else { const double2 x = vr[h]; acc += p.x * d.x * x.x; acc += p.y * d.y * x.y; }
+        }
+        // coupling -2 dR between u_k and u_{k+1} / u_{k-1}
+        const double cpl = inp ? 2.0 * dRl[inp ? a - NX : 0] : 0.0;
+        const int en = (k + 1 < N) ? e + 8 : e, ep = (k >= 1) ? e - 8 : e;
+        const double dn = (k + 1 < N) ? D[en] : 0.0, dp = (k >= 1) ? D[ep] : 0.0;
+        if (ABS) { acc = fmax(acc, fabs(cpl) * dn); acc = fmax(acc, fabs(cpl) * dp); }
+        else acc -= cpl * (dn * v[en] + dp * v[ep]);
+        return (inp && k >= N) ? 0.0 : acc * c * D[e];
+    }
     // dst = P * src   (P = c D P0 D)
     __device__ __forceinline__ void P_mul(const double *src, double *dst) const {
-        for (int e = lane; e < NS * 8; e += 64) {
-            const int k = e >> 3, a = e & 7;
-            double v = 0.0;
-            const int nv = nvar(k);
-            if (a < nv) {
-                for (int b = 0; b < nv; ++b) v += Pc(k, a, b) * D[k * 8 + b] * src[k * 8 + b];
-                if (a >= NX) {
-                    const double cpl = -2.0 * dRl[a - NX];
-                    if (k + 1 < N) v += cpl * D[e + 8] * src[e + 8];
-                    if (k >= 1) v += cpl * D[e - 8] * src[e - 8];
-                }
-                v *= c * D[e];
-            }
-            dst[e] = v;
-        }
+        for (int e = lane; e < NS * 8; e += 64) dst[e] = P_row<false>(e >> 3, src);
     }
-    // infinity norm of column (k,a) of the scaled Hessian
-    __device__ __forceinline__ double P_colnorm(int k, int a) const {
-        const int nv = nvar(k);
-        if (a >= nv) return 0.0;
-        double cn = 0.0;
-        for (int b = 0; b < nv; ++b) cn = fmax(cn, fabs(Pc(k, a, b)) * D[k * 8 + b]);
-        if (a >= NX) {
-            const double cpl = 2.0 * fabs(dRl[a - NX]);
-            if (k + 1 < N) cn = fmax(cn, cpl * D[(k + 1) * 8 + a]);
-            if (k >= 1) cn = fmax(cn, cpl * D[(k - 1) * 8 + a]);
-        }
-        return cn * c * D[k * 8 + a];
-    }
+    // infinity norm of column (k, tj) of the scaled Hessian
+    __device__ __forceinline__ double P_colnorm(int k, int) const { return P_row<true>(k, D); }
 
     // ---- Ruiz equilibration (OSQP scale_data) ----------------------------------------------------
+    // D, E and c are accumulated while the [A|B] tiles stay UNSCALED (entries are multiplied by the current
+    // E and D on the fly when the norms are taken); the tiles are scaled once at the end.
     __device__ __forceinline__ void scale_data() {
         const int ntrue = NS * NX + N * 2;
         for (int it = 0; it < cfg.scaling; ++it) {
-            // column norms of [P A'; A 0] -> XT (variables), ZTd / ZTb (rows)
+            // infinity norms of the columns of [P A'; A 0] -> step factors in XT (variables), ZTd / ZTb (rows)
             for (int e = lane; e < NS * 8; e += 64) {
-                const int k = e >> 3, a = e & 7;
+                const int k = e >> 3, a = tj, kn = k < N ? k + 1 : N, kp = k > 0 ? k - 1 : 0;
+                const double de = D[e], ede = Ed[e], ebe = Eb[e];
+                const double *col = tA + k * kTS + a, *row = tA + kp * kTS + a * 8;
+                double cmax = 0.0, rmax = 0.0;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) cmax = fmax(cmax, fabs(col[r * 8]) * Ed[kn * 8 + r]);      // stage-N tile is zero
+#pragma unroll
+                for (int b = 0; b < NB; ++b) rmax = fmax(rmax, fabs(row[b]) * D[kp * 8 + b]);
                 double dn = 0.0;
                 if (a < nvar(k)) {
-                    dn = P_colnorm(k, a);
-                    int first, cnt; rows_on(a, first, cnt);
-                    for (int t = 0; t < cnt; ++t) { const int r = first + t; if (r < nbox(k)) dn = fmax(dn, Eb[k * 8 + r] * D[e]); }
-                    if (a < NX) dn = fmax(dn, Ed[e] * D[e]);
-                    if (k < N) { const double *col = tA + k * kTS + a;
-#pragma unroll
-                        for (int r = 0; r < NX; ++r) dn = fmax(dn, fabs(col[r * 8])); }
+                    dn = fmax(P_colnorm(k, a), cmax * de);
+                    if (r0 < nbox(k)) dn = fmax(dn, Eb[k * 8 + r0] * de);
+                    if (r1 < nbox(k)) dn = fmax(dn, Eb[k * 8 + r1] * de);
+                    if (a < NX) dn = fmax(dn, ede * de);
                 }
-                XT[e] = 1.0 / sqrt(limit_scaling(dn));
-                double en = 0.0;          // dynamics row (k, r=a)
-                if (a < NX) {
-                    en = Ed[e] * D[e];
-                    if (k >= 1) { const double *row = tA + (k - 1) * kTS + a * 8;
-#pragma unroll
-                        for (int b = 0; b < NB; ++b) en = fmax(en, fabs(row[b])); }
-                }
-                ZTd[e] = 1.0 / sqrt(limit_scaling(en));
-                double bn = 0.0;          // box row (k, r=a)
-                if (a < nbox(k)) bn = Eb[e] * D[k * 8 + box_var(a)];
-                ZTb[e] = 1.0 / sqrt(limit_scaling(bn));
-            }
-            sync();
-            // A <- E A D on the stored [A|B] tiles
-            for (int k = 0; k < N; ++k) {
-                if (ti < NX && tj < NB) tA[k * kTS + lane] *= ZTd[(k + 1) * 8 + ti] * XT[k * 8 + tj];
+                double en = 0.0;          // dynamics row (k, a)
+                if (a < NX) { en = ede * de; if (k >= 1) en = fmax(en, rmax * ede); }
+                double bn = 0.0;          // box row (k, a)
+                if (a < nbox(k)) bn = ebe * D[k * 8 + bvar];
+                XT[e] = inv_sqrt(limit_scaling(dn));
+                ZTd[e] = inv_sqrt(limit_scaling(en));
+                ZTb[e] = inv_sqrt(limit_scaling(bn));
             }
             sync();
             for (int e = lane; e < NS * 8; e += 64) { D[e] *= XT[e]; Ed[e] *= ZTd[e]; Eb[e] *= ZTb[e]; }
@@ -317,17 +368,27 @@ struct Solver {
             // cost normalisation
             double psum = 0.0, qmax = 0.0;
             for (int e = lane; e < NS * 8; e += 64) {
-                const int k = e >> 3, a = e & 7;
-                psum += P_colnorm(k, a);
+                psum += P_colnorm(e >> 3, tj);
                 qmax = fmax(qmax, fabs(c * D[e] * Qv[e]));
             }
             psum = wave_sum(psum) / (double)ntrue;
             qmax = limit_scaling(wave_max(qmax));
-            double ct = limit_scaling(fmax(psum, qmax));
+            const double ct = limit_scaling(fmax(psum, qmax));
             c *= 1.0 / ct;
-            sync();
         }
         cinv = 1.0 / c;
+        // A <- E A D on the stored [A|B] tiles, four stages per trip (all loads before the stores)
+        for (int k0 = 0; k0 < N; k0 += 4) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u < N ? k0 + u : N - 1;
+                v[u] = tA[k * kTS + lane] * (Ed[(k + 1) * 8 + ti] * D[k * 8 + tj]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (k0 + u < N && ti < NX && tj < NB) tA[(k0 + u) * kTS + lane] = v[u];
+        }
+        sync();
     }
 
     // ---- block tridiagonal factorisation of K = P + sig I + A' diag(W) A --------------------------
@@ -338,7 +399,17 @@ struct Solver {
     // Schur complement formed through an explicit S^-1 loses ~7 digits.  Stored for the solve:
     // S_k^-1 = C^-T C^-1 (tS / rS) and L_k = G C_{k-1}^-1 (tL / rL; transposed for odd k, see kkt_solve).
     __device__ __forceinline__ void factor(double sig) {
-        double cinv_prev = 0.0;
+        // 8x8 products go through four 64-double scratch tiles in LDS (the x~ / delta_x vectors are free
+        // whenever a factorisation runs): an operand is written once and each lane then reads one row of each
+        // factor with 16-byte loads.  T0 = K_{k,k-1}, T1 = C_{k-1}^-1, T2 = G, T3 = C_{k-1}^-T (all row-major).
+        double *const T0 = XT, *const T1 = XT + 64, *const T2 = XT + 128, *const T3 = XT + 192;
+        const double2 *const rowi0 = reinterpret_cast<const double2 *>(T0 + ti * 8);
+        const double2 *const rowj1 = reinterpret_cast<const double2 *>(T1 + tj * 8);
+        const double2 *const rowi2 = reinterpret_cast<const double2 *>(T2 + ti * 8);
+        const double2 *const rowj2 = reinterpret_cast<const double2 *>(T2 + tj * 8);
+        const double2 *const rowi3 = reinterpret_cast<const double2 *>(T3 + ti * 8);
+        const double2 *const rowj3 = reinterpret_cast<const double2 *>(T3 + tj * 8);
+        sync();
         for (int k = 0; k <= N; ++k) {
             const int nv = nvar(k);
             double kd;
@@ -365,35 +436,42 @@ struct Solver {
                     if (ti < NX) ko = -w_dyn(k * 8 + ti) * Eid(k, ti) * tA[(k - 1) * kTS + ti * 8 + tj];
                     else if (ti == tj && ti < nv) ko = c * D[k * 8 + ti] * (-2.0 * dRl[ti - NX]) * D[(k - 1) * 8 + ti];
                 }
-                double g = 0.0;
+                T0[lane] = ko;
+                sync();
+                double g = 0.0;                                     // G = Koff C^-T : sum_t Koff[i][t] Cinv[j][t]
 #pragma unroll
-                for (int t = 0; t < 8; ++t) g += __shfl(ko, ti * 8 + t) * __shfl(cinv_prev, tj * 8 + t);   // G = Koff C^-T
+                for (int t = 0; t < 4; ++t) { const double2 a = rowi0[t], b = rowj1[t]; g += a.x * b.x; g += a.y * b.y; }
+                T2[lane] = g;
+                sync();
 #pragma unroll
-                for (int t = 0; t < 8; ++t) s -= __shfl(g, ti * 8 + t) * __shfl(g, tj * 8 + t);             // S = Kd - G G'
-#pragma unroll
-                for (int t = 0; t < 8; ++t) l += __shfl(g, ti * 8 + t) * __shfl(cinv_prev, t * 8 + tj);     // L = G C^-1
+                for (int t = 0; t < 4; ++t) {                       // S = Kd - G G' ;  L = G C^-1 = sum_t G[i][t] Cinv^T[j][t]
+                    const double2 a = rowi2[t], b = rowj2[t], cT = rowj3[t];
+                    s -= a.x * b.x; s -= a.y * b.y;
+                    l += a.x * cT.x; l += a.y * cT.y;
+                }
             }
-            // Cholesky S = C C' (lower)
-            double cf = 0.0;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const double d = __shfl(s, t * 9);
-                const double rs = 1.0 / sqrt(d);
-                const double cit = __shfl(s, ti * 8 + t) * rs, cjt = __shfl(s, tj * 8 + t) * rs;
-                if (tj == t && ti >= t) cf = cit;
-                if (ti > t && tj > t) s -= cit * cjt;
+            // Cholesky S = C C' merged with the forward substitution C W = I: after step t row t of W is final.
+            double w = (ti == tj) ? 1.0 : 0.0;
+#define LPVMPC_CHOL_STEP(T)                                                                                   \
+            {                                                                                                     \
+                const double d = bcast_lane<(T) * 9>(s);                                                          \
+                const double rs = 1.0 / sqrt(d);                                                                  \
+                const double cit = bcast_row<(T)>(s) * rs;                                                        \
+                const double cjt = __shfl(s, (T) * 8 + tj) * rs;                                                  \
+                const double wtj = __shfl(w, (T) * 8 + tj) * rs;                                                  \
+                if (ti > (T) && tj > (T)) s -= cit * cjt;                                                         \
+                if (ti == (T)) w = wtj; else if (ti > (T)) w -= cit * wtj;                                        \
             }
-            // C^-1 by Gauss-Jordan on the triangular factor (= forward substitution)
+            LPVMPC_CHOL_STEP(0) LPVMPC_CHOL_STEP(1) LPVMPC_CHOL_STEP(2) LPVMPC_CHOL_STEP(3)
+            LPVMPC_CHOL_STEP(4) LPVMPC_CHOL_STEP(5) LPVMPC_CHOL_STEP(6) LPVMPC_CHOL_STEP(7)
+#undef LPVMPC_CHOL_STEP
+            // w = C_k^-1.  Publish it (row-major and transposed) for S^-1 below and for the next stage.
+            sync();
+            T1[lane] = w; T3[tj * 8 + ti] = w;
+            sync();
+            double sinv = 0.0;                                      // S^-1 = C^-T C^-1 : sum_t Cinv^T[i][t] Cinv^T[j][t]
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const double p = __shfl(cf, t * 9), rowt = __shfl(cf, t * 8 + tj), colt = __shfl(cf, ti * 8 + t);
-                const double pinv = 1.0 / p, rr = rowt * pinv;
-                if (ti == t) cf = (tj == t) ? pinv : rr;
-                else cf = (tj == t) ? -colt * pinv : cf - colt * rr;
-            }
-            double sinv = 0.0;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) sinv += __shfl(cf, t * 8 + ti) * __shfl(cf, t * 8 + tj);           // S^-1 = C^-T C^-1
+            for (int t = 0; t < 4; ++t) { const double2 a = rowi3[t], b = rowj3[t]; sinv += a.x * b.x; sinv += a.y * b.y; }
             if constexpr (kReg) {
                 const double lt = (k & 1) ? __shfl(l, tj * 8 + ti) : l;      // odd stages keep L_k transposed
 #pragma unroll
@@ -402,7 +480,6 @@ struct Solver {
                 tL[k * kTS + ((k & 1) ? (tj * 8 + ti) : lane)] = l;
                 tS[k * kTS + lane] = sinv;
             }
-            cinv_prev = cf;
         }
         sync();
     }
@@ -898,7 +975,7 @@ struct Solver {
 
 template <int NX, int NT>
 __global__ void __launch_bounds__(64) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
-    extern __shared__ double smem[];
+    extern __shared__ __align__(16) double smem[];
     const int inst = blockIdx.x;
     if (inst >= a.B) return;
     Solver<NX, NT> s(*cfgp, smem);

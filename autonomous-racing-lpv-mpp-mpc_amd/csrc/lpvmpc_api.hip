@@ -115,7 +115,7 @@ static int ensure_ws(lpvmpc_handle *h, int B) {
 extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     if (!cfg) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: cfg is NULL"); return nullptr; }
     if (cfg->kind != LPVMPC_KIND_CONTROLLER && cfg->kind != LPVMPC_KIND_PLANNER) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: bad kind %d", cfg->kind); return nullptr; }
-    if (cfg->N < 2 || cfg->N > LPVMPC_MAX_N) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: N=%d outside [2,%d]", cfg->N, LPVMPC_MAX_N); return nullptr; }
+    if (cfg->N < 8 || cfg->N > LPVMPC_MAX_N) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: N=%d outside [8,%d]", cfg->N, LPVMPC_MAX_N); return nullptr; }
     if (cfg->track_rows < 0 || cfg->track_rows > LPVMPC_MAX_TRACK_ROWS) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: track_rows=%d outside [0,%d]", cfg->track_rows, LPVMPC_MAX_TRACK_ROWS); return nullptr; }
     if (!(cfg->dt > 0) || !(cfg->rho > 0) || !(cfg->sigma > 0) || !(cfg->alpha > 0 && cfg->alpha < 2) || !(cfg->polish_delta > 0)) {
         fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: dt, rho, sigma, polish_delta must be > 0 and 0 < alpha < 2"); return nullptr; }
