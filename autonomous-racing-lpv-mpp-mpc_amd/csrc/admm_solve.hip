@@ -455,7 +455,7 @@ struct Solver {
 #define LPVMPC_CHOL_STEP(T)                                                                                   \
             {                                                                                                     \
                 const double d = bcast_lane<(T) * 9>(s);                                                          \
-                const double rs = 1.0 / sqrt(d);                                                                  \
+                const double rs = inv_sqrt(d);                                                                    \
                 const double cit = bcast_row<(T)>(s) * rs;                                                        \
                 const double cjt = __shfl(s, (T) * 8 + tj) * rs;                                                  \
                 const double wtj = __shfl(w, (T) * 8 + tj) * rs;                                                  \

@@ -137,6 +137,13 @@ def main():
         bytes_launch, bytes_iter = algorithmic_bytes(it_host)
         k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
         achieved = bytes_launch / k_avg_s / 1e9 if k_n else float("nan")
+        traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside bench.py)
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pm.get("batch") == B:
+                traffic = pm["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "MPC solves/sec (N=20, nx=6, nu=2)",
             "value": total / elapsed,
@@ -158,7 +165,7 @@ def main():
                        "solved_fraction": agg[1] / (B * world),
                        "p50_batch_latency_ms": p50, "streams": S},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "admm_solve_kernel<6>", "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
                          "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_admm_iteration": bytes_iter,
                          "note": "algorithmic bytes per SURVEY 8(d) (factor + vectors streamed once per ADMM "
