@@ -169,3 +169,118 @@ int oracle_ctrl_tick_batch(int B, int N, double dt, const double *params, const 
     free(perm);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * planner tick: LPVPrediction PLAN:242-320, _buildMatEqConst PLAN:434-486, cost/bounds/OSQP PLAN:86-236
+ * (equalities first, then the identity box on every variable, PLAN:200-202).
+ * params = [lf lr m Iz Cf Cr mu max_vel min_vel]; states [vx vy wz ey epsi].
+ * ---------------------------------------------------------------------------------------------- */
+static void plan_stage(const double *p, double dt, double vx, double vy, double ey, double epsi, double cur,
+                       double delta, double ab[35]) {
+    const double lf = p[0], lr = p[1], m = p[2], I = p[3], Cf = p[4], Cr = p[5], mu = p[6];
+    const double sd = sin(delta), cd = cos(delta), A1 = 1.0 / (1.0 - ey * cur), A2 = sin(epsi);
+    memset(ab, 0, sizeof(double) * 35);
+    ab[0 * 7 + 0] = 1.0 + dt * (-mu);
+    ab[0 * 7 + 1] = dt * ((sd * Cf) / (m * vx));
+    ab[0 * 7 + 2] = dt * ((sd * Cf * lf) / (m * vx) + vy);
+    ab[1 * 7 + 1] = 1.0 + dt * (-(Cr + Cf * cd) / (m * vx));
+    ab[1 * 7 + 2] = dt * (-(lf * Cf * cd - lr * Cr) / (m * vx) - vx);
+    ab[2 * 7 + 1] = dt * (-(lf * Cf * cd - lr * Cr) / (I * vx));
+    ab[2 * 7 + 2] = 1.0 + dt * (-(lf * lf * Cf * cd + lr * lr * Cr) / (I * vx));
+    ab[3 * 7 + 1] = dt * 1.0; ab[3 * 7 + 3] = 1.0; ab[3 * 7 + 4] = dt * vx;
+    ab[4 * 7 + 0] = dt * (-A1 * cur); ab[4 * 7 + 1] = dt * (A1 * A2 * cur); ab[4 * 7 + 2] = dt * 1.0; ab[4 * 7 + 4] = 1.0;
+    ab[0 * 7 + 5] = dt * (-(sd * Cf) / m); ab[0 * 7 + 6] = dt * 1.0;
+    ab[1 * 7 + 5] = dt * ((cd * Cf) / m);
+    ab[2 * 7 + 5] = dt * ((lf * Cf * cd) / I);
+}
+
+int oracle_plan_tick_batch(int B, int N, double dt, const double *params, const double *Q, const double *R,
+                           const double *dR, const double *Lcf, const double *track, int track_rows,
+                           const double *x0, const double *u_prev, const double *SS, const double *u_old,
+                           const double *max_ey, double *xPred, double *uPred, int *status, int *iters, int nthreads) {
+    const int nx = 5, nu = 2, nz = (N + 1) * nx + N * nu, me = (N + 1) * nx, m = me + nz;
+    const double max_vel = params[7], min_vel = params[8];
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    int *perm = (int *)malloc(sizeof(int) * (nz + m)); int pc = 0;
+    for (int r = 0; r < nx; r++) perm[pc++] = nz + r;
+    for (int k = 0; k <= N; k++) {
+        for (int a = 0; a < nx; a++) { perm[pc++] = k * nx + a; perm[pc++] = nz + me + k * nx + a; }
+        if (k < N) {
+            for (int j = 0; j < nu; j++) { const int v = (N + 1) * nx + k * nu + j; perm[pc++] = v; perm[pc++] = nz + me + v; }
+            for (int r = 0; r < nx; r++) perm[pc++] = nz + (k + 1) * nx + r;
+        }
+    }
+    osqp_ref_settings st; osqp_ref_default_settings(&st);
+#pragma omp parallel
+    {
+        double *AB = (double *)malloc(sizeof(double) * N * 35);
+        int *Pp = (int *)malloc(sizeof(int) * (nz + 1)), *Pi = (int *)malloc(sizeof(int) * (nz * 8));
+        double *Px = (double *)malloc(sizeof(double) * (nz * 8)), *q = (double *)malloc(sizeof(double) * nz);
+        int *Ap = (int *)malloc(sizeof(int) * (nz + 1)), *Ai = (int *)malloc(sizeof(int) * (nz * 10));
+        double *Ax = (double *)malloc(sizeof(double) * (nz * 10));
+        double *l = (double *)malloc(sizeof(double) * m), *u = (double *)malloc(sizeof(double) * m);
+        double *xo = (double *)malloc(sizeof(double) * nz), *yo = (double *)malloc(sizeof(double) * m);
+#pragma omp for schedule(dynamic, 4)
+        for (int b = 0; b < B; b++) {
+            double stt[5]; memcpy(stt, x0 + (size_t)b * 5, sizeof(stt));
+            for (int i = 0; i < N; i++) {
+                const double cur = curvature(track, track_rows, SS[(size_t)b * (N + 1) + i]);
+                const double *uu = u_prev + ((size_t)b * N + i) * 2;
+                double *ab = AB + i * 35;
+                plan_stage(params, dt, stt[0], stt[1], stt[3], stt[4], cur, uu[0], ab);
+                double nxt[5];
+                for (int r = 0; r < 5; r++) {
+                    double acc = 0; for (int a = 0; a < 5; a++) acc += ab[r * 7 + a] * stt[a];
+                    nxt[r] = acc + (ab[r * 7 + 5] * uu[0] + ab[r * 7 + 6] * uu[1]);
+                }
+                memcpy(stt, nxt, sizeof(stt));
+            }
+            int pn = 0;
+            for (int k = 0; k <= N; k++) for (int a = 0; a < nx; a++) {
+                const int col = k * nx + a; Pp[col] = pn;
+                for (int r = 0; r <= a; r++) { const double v = 2.0 * Q[r * nx + a]; if (v != 0.0) { Pi[pn] = k * nx + r; Px[pn++] = v; } }
+                q[col] = Lcf[a];
+            }
+            for (int k = 0; k < N; k++) for (int j = 0; j < nu; j++) {
+                const int col = (N + 1) * nx + k * nu + j; Pp[col] = pn;
+                if (k >= 1) { const double v = -2.0 * dR[j]; if (v != 0.0) { Pi[pn] = col - nu; Px[pn++] = v; } }
+                for (int r = 0; r <= j; r++) {
+                    double v = 2.0 * R[r * nu + j]; if (r == j) v += 2.0 * (k < N - 1 ? 2.0 : 1.0) * dR[j];
+                    if (v != 0.0) { Pi[pn] = (N + 1) * nx + k * nu + r; Px[pn++] = v; }
+                }
+                q[col] = (k == 0) ? -2.0 * (u_old ? u_old[(size_t)b * 2 + j] : 0.0) * dR[j] : 0.0;
+            }
+            Pp[nz] = pn;
+            int an = 0;
+            for (int k = 0; k <= N; k++) for (int a = 0; a < nx; a++) {
+                const int col = k * nx + a; Ap[col] = an;
+                Ai[an] = k * nx + a; Ax[an++] = 1.0;
+                if (k < N) for (int r = 0; r < nx; r++) { const double v = -AB[k * 35 + r * 7 + a]; if (v != 0.0) { Ai[an] = (k + 1) * nx + r; Ax[an++] = v; } }
+                Ai[an] = me + col; Ax[an++] = 1.0;
+            }
+            for (int k = 0; k < N; k++) for (int j = 0; j < nu; j++) {
+                const int col = (N + 1) * nx + k * nu + j; Ap[col] = an;
+                for (int r = 0; r < nx; r++) { const double v = -AB[k * 35 + r * 7 + nx + j]; if (v != 0.0) { Ai[an] = (k + 1) * nx + r; Ax[an++] = v; } }
+                Ai[an] = me + col; Ax[an++] = 1.0;
+            }
+            Ap[nz] = an;
+            for (int r = 0; r < me; r++) l[r] = u[r] = (r < nx) ? x0[(size_t)b * 5 + r] : 0.0;
+            const double mey = max_ey[b];
+            const double xmin[5] = {min_vel, -1, -2, -mey, -0.8}, xmax[5] = {max_vel, 1, 2, mey, 0.8};
+            const double umin[2] = {-0.249, -0.7}, umax[2] = {0.249, 2.0};
+            for (int k = 0; k <= N; k++) for (int a = 0; a < nx; a++) { l[me + k * nx + a] = xmin[a]; u[me + k * nx + a] = xmax[a]; }
+            for (int k = 0; k < N; k++) for (int j = 0; j < nu; j++) { l[me + (N + 1) * nx + k * nu + j] = umin[j]; u[me + (N + 1) * nx + k * nu + j] = umax[j]; }
+            osqp_ref_info info;
+            osqp_ref_solve(nz, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, perm, &st, xo, yo, &info);
+            memcpy(xPred + (size_t)b * (N + 1) * nx, xo, sizeof(double) * (N + 1) * nx);
+            memcpy(uPred + (size_t)b * N * nu, xo + (N + 1) * nx, sizeof(double) * N * nu);
+            if (status) status[b] = info.status_val;
+            if (iters) iters[b] = info.iter;
+        }
+        free(AB); free(Pp); free(Pi); free(Px); free(q); free(Ap); free(Ai); free(Ax); free(l); free(u); free(xo); free(yo);
+    }
+    free(perm);
+    return 0;
+}

@@ -152,3 +152,26 @@ def ctrl_tick_batch(w, nthreads=1, params=None):
       _ptr(arrs["curv"], d), _ptr(arrs["u_old"], d), d(float(w["cf_new"])), C.c_int(int(w["lap"])),
       _ptr(xPred, d), _ptr(uPred, d), _ptr(status, C.c_int), _ptr(iters, C.c_int), C.c_int(int(nthreads)))
     return dict(xPred=xPred, uPred=uPred, status=status, iters=iters)
+
+
+def plan_tick_batch(w, nthreads=1, params=None):
+    """Whole planner tick for a batch in C (oracle/lpv_ref.c); ``w`` as produced by workloads.planner_batch."""
+    from .lpv_ref import DEFAULT_PARAMS
+    p = dict(DEFAULT_PARAMS)
+    if params:
+        p.update(params)
+    pv = np.array([p["lf"], p["lr"], p["m"], p["Iz"], p["Cf"], p["Cr"], p["mu"], p["max_vel"], p["min_vel"]], dtype=np.float64)
+    N = int(w["N"])
+    c = lambda a: np.ascontiguousarray(a, np.float64)
+    x0 = c(w["x0"]); B = x0.shape[0]
+    Q, R, dR, Lcf, track = c(w["Q"]), c(w["R"]), c(w["dR"]), c(w["L_cf"]), c(w["track"])
+    u_prev, SS, u_old, mey = c(w["u_prev"]), c(w["curv_s"]), c(w["u_old"]), c(np.broadcast_to(w["max_ey"], (B,)))
+    xPred = np.empty((B, N + 1, 5)); uPred = np.empty((B, N, 2))
+    status = np.empty(B, np.int32); iters = np.empty(B, np.int32)
+    d = C.c_double
+    f = lib().oracle_plan_tick_batch
+    f.restype = C.c_int
+    f(C.c_int(B), C.c_int(N), d(float(w["dt"])), _ptr(pv, d), _ptr(Q, d), _ptr(R, d), _ptr(dR, d), _ptr(Lcf, d),
+      _ptr(track, d), C.c_int(track.shape[0]), _ptr(x0, d), _ptr(u_prev, d), _ptr(SS, d), _ptr(u_old, d), _ptr(mey, d),
+      _ptr(xPred, d), _ptr(uPred, d), _ptr(status, C.c_int), _ptr(iters, C.c_int), C.c_int(int(nthreads)))
+    return dict(xPred=xPred, uPred=uPred, status=status, iters=iters)

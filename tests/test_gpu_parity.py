@@ -161,3 +161,57 @@ def test_specialised_and_generic_kernels_agree(lpvmpc):
         ok &= np.all(np.isfinite(a["xPred"]).reshape(len(ok), -1), axis=1)
         assert np.max(np.abs(a["xPred"][ok] - b["xPred"][ok])) < 1e-9
         assert np.max(np.abs(a["uPred"][ok] - b["uPred"][ok])) < 1e-9
+
+
+def _agree(out, ref, b, nx, tol_x):
+    assert int(out["status"][b]) == int(ref["status"][b]), (b, out["status"][b], ref["status"][b], out["iters"][b], ref["iters"][b])
+    assert int(out["iters"][b]) == int(ref["iters"][b]), (b, out["iters"][b], ref["iters"][b])
+    if np.all(np.isfinite(ref["xPred"][b])):
+        assert np.max(np.abs(out["xPred"][b] - ref["xPred"][b])) <= tol_x * max(1.0, np.max(np.abs(ref["xPred"][b]))), b
+        assert np.max(np.abs(out["uPred"][b] - ref["uPred"][b])) <= tol_x, b
+    else:
+        assert np.all(np.isnan(out["xPred"][b])) and np.all(np.isnan(out["uPred"][b]))
+
+
+def test_fused_batch_cfg3_planner_against_oracle(lpvmpc):
+    """BASELINE cfg 3 shape (planner N=30, L-shape, seed 1) at B = 4096: statuses are valid OSQP codes for every
+    instance; the first 96 are re-solved by the C oracle tick (same iterations, statuses, solutions)."""
+    from lpvmpc import workloads
+    w = workloads.planner_batch(4096, N=30, seed=1)
+    eng = workloads.make_solver(w)
+    out = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+    eng.close()
+    assert set(np.unique(out["status"])) <= {1, 2, 3, -2, -3}
+    assert np.mean(out["status"] == 1) > 0.7
+    ok = out["status"] > 0
+    # size-independent properties on the full batch: box feasibility of every returned trajectory within OSQP's eps
+    sol = np.isin(out["status"], (1, 2, -2))
+    xP, uP = out["xPred"][sol], out["uPred"][sol]
+    assert np.all(uP[:, :, 0] <= 0.249 + 5e-3) and np.all(uP[:, :, 0] >= -0.249 - 5e-3)
+    assert np.all(uP[:, :, 1] <= 2.0 + 2e-2) and np.all(uP[:, :, 1] >= -0.7 - 2e-2)
+    assert np.max(np.abs(xP[:, 0, :] - w["x0"][sol])) <= 5e-3            # x_0 = x0 equality
+    n = 96
+    sub = {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == 4096 else v) for k, v in w.items()}
+    ref = O.plan_tick_batch(sub, nthreads=8)
+    for b in range(n):
+        _agree(out, ref, b, 5, 1e-5)
+
+
+def test_mixed_cfg4_controller_and_planner_n20(lpvmpc):
+    """BASELINE cfg 4 shape: half controller-style, half planner-style instances, both N = 20 (the planner at
+    N = 20 runs the run-time-horizon kernel)."""
+    from lpvmpc import workloads
+    wc = workloads.controller_batch(2048, N=20, seed=2)
+    wp = workloads.planner_batch(2048, N=20, seed=2)
+    ec, ep = workloads.make_solver(wc), workloads.make_solver(wp)
+    oc = ec.solve(wc["x0"], wc["u_prev"], wc["vel_ref"], wc["curv_s"], wc["u_old"], None, wc["cf_new"], wc["lap"])
+    op = ep.solve(wp["x0"], wp["u_prev"], None, wp["curv_s"], wp["u_old"], wp["max_ey"])
+    ec.close(); ep.close()
+    assert np.all(oc["status"] == 1)
+    n = 48
+    subc = {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == 2048 else v) for k, v in wc.items()}
+    subp = {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == 2048 else v) for k, v in wp.items()}
+    rc, rp = O.ctrl_tick_batch(subc, nthreads=8), O.plan_tick_batch(subp, nthreads=8)
+    for b in range(n):
+        _agree(oc, rc, b, 6, 1e-6)
+        _agree(op, rp, b, 5, 1e-5)

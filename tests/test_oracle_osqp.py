@@ -69,3 +69,18 @@ def test_infeasible_and_trivial_problems():
     assert r.info.status_val == -3 and np.all(np.isnan(r.x))
     r = O.solve_qp(P, q, A[:1], np.array([1.0]), np.array([2.0]), perm=None)
     assert r.info.status_val == 1 and abs(r.x[0] - 1.0) <= 1e-6
+
+
+def test_c_planner_tick_matches_python_assembly():
+    from lpvmpc import workloads
+    w = workloads.planner_batch(8, 30, seed=4)
+    r = O.plan_tick_batch(w, nthreads=2)
+    p = dict(L.DEFAULT_PARAMS)
+    for b in range(8):
+        S, A, Bm = L.plan_lpv_prediction(p, w["dt"], 30, w["track"], w["x0"][b], w["curv_s"][b], w["u_prev"][b])
+        qp = L.plan_build_qp(w["Q"], w["R"], w["dR"], w["L_cf"], 30, A, Bm, w["x0"][b], [0.0, 0.0], 0.2, p["max_vel"], p["min_vel"])
+        rr = O.solve_qp(qp.P, qp.q, qp.A, qp.l, qp.u)
+        assert rr.info.iter == r["iters"][b] and rr.info.status_val == r["status"][b]
+        if np.all(np.isfinite(rr.x)):
+            xP, uP, _ = L.unpack_solution(rr.x, 5, 2, 30)
+            assert max(np.abs(r["xPred"][b] - xP).max(), np.abs(r["uPred"][b] - uP).max()) <= 1e-8
