@@ -830,7 +830,11 @@ struct Solver {
         if (cfg.polish && status == LPVMPC_SOLVED_) status_polish = polish(pri_res, dua_res, obj);
 
         // ---------- write back (store_solution) ----------
-        const bool sol = has_sol;
+        // store_solution: decided on the FINAL status (the approximate check above may have turned an
+        // unsolved run into "primal/dual infeasible inaccurate", which carries no solution)
+        const bool sol = !(status == LPVMPC_PRIMAL_INFEASIBLE_ || status == LPVMPC_PRIMAL_INFEASIBLE_INACC_ ||
+                           status == LPVMPC_DUAL_INFEASIBLE_ || status == LPVMPC_DUAL_INFEASIBLE_INACC_ ||
+                           status == LPVMPC_NON_CVX_);
         const double nan = __builtin_nan("");
         for (int e = lane; e < NS * 8; e += 64) {
             const int k = e >> 3, r = e & 7;
