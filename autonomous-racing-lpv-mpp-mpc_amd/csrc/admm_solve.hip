@@ -22,142 +22,9 @@
 // padded to 8 per stage so that index = 8*stage + component): 37.7 KB at N = 20, i.e. 4 instances per
 // CU (one wavefront per SIMD), which is exactly BASELINE configs[1] (1024 instances) in one residency.
 #include "lpvmpc_device.hpp"
+#include "wave_ops.hpp"
 
 namespace lpvmpc {
-
-// ---- cross-lane primitives (CDNA4) ------------------------------------------------------------
-// A tile element [i][j] lives in lane 8*i+j.  Summing over j stays inside an 8-lane group: two quad
-// permutes and a half-row mirror, all DPP modifiers on v_mov (a 64-bit value moves as two dwords).
-// Summing over i crosses 16-lane DPP rows: row_ror:8 for lane^8, then v_permlane16_swap /
-// v_permlane32_swap (gfx950) for lane^16 / lane^32.  -DLPVMPC_USE_SHFL selects plain ds_bpermute
-// shuffles instead (validation only).
-template <int CTRL>
-__device__ inline double dpp_mov(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    // every lane has a valid source under these controls; bound_ctrl lets the destination start undefined
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ inline double xor16_sum(double v) {
-    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-}
-__device__ inline double xor32_sum(double v) {
-    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-}
-// all-reduce over the column index j (lane bits 0..2) / the row index i (lane bits 3..5) of a tile
-__device__ inline double red_j(double v) {
-#ifdef LPVMPC_USE_SHFL
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-#else
-    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);   // row_half_mirror (quads are uniform by now)
-#endif
-    return v;
-}
-__device__ inline double red_i(double v) {
-#ifdef LPVMPC_USE_SHFL
-    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-#else
-    v += dpp_mov<0x128>(v);   // row_ror:8  == lane ^ 8
-    v = xor16_sum(v);
-    v = xor32_sum(v);
-#endif
-    return v;
-}
-// whole-wavefront all-reduces (sum / max): 8-lane group, row_ror:8, then the two row-crossing swaps
-__device__ inline void xor16_pair(double v, double &x, double &y) {
-    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    x = __hiloint2double(b[0], a[0]); y = __hiloint2double(b[1], a[1]);
-}
-__device__ inline void xor32_pair(double v, double &x, double &y) {
-    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    x = __hiloint2double(b[0], a[0]); y = __hiloint2double(b[1], a[1]);
-}
-__device__ inline double wave_sum(double v) {
-#ifdef LPVMPC_USE_SHFL
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-    return v;
-#else
-    return red_i(red_j(v));
-#endif
-}
-__device__ inline double wave_max(double v) {
-#ifdef LPVMPC_USE_SHFL
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m));
-    return v;
-#else
-    v = fmax(v, dpp_mov<0xB1>(v)); v = fmax(v, dpp_mov<0x4E>(v)); v = fmax(v, dpp_mov<0x141>(v));
-    v = fmax(v, dpp_mov<0x128>(v));
-    double x, y;
-    xor16_pair(v, x, y); v = fmax(x, y);
-    xor32_pair(v, x, y); v = fmax(x, y);
-    return v;
-#endif
-}
-// value of lane SRC in every lane (uniform source lane): two v_readlane
-template <int SRC>
-__device__ inline double bcast_lane(double v) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC), hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
-    return __hiloint2double(hi, lo);
-}
-// tile element [i][T] in every lane (i, .): broadcast lane T of each 8-lane group, two DPP moves per dword
-template <int T>
-__device__ inline double bcast_row(double v) {
-    constexpr int q = T & 3, QP = q | (q << 2) | (q << 4) | (q << 6);
-    constexpr int BM = (T >> 2) ? 0x5 : 0xA;          // banks (quads of a row) that still hold the other quad's value
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, QP, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, QP, 0xF, 0xF, true);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, BM, false);     // row_half_mirror into the masked banks
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, BM, false);
-    return __hiloint2double(hi, lo);
-}
-// two independent all-reduces of the same kind, interleaved step by step (fills the DPP hazard slots
-// and the dependent-add latency of one with the other)
-__device__ inline void red_j2(double &a, double &b) {
-#ifdef LPVMPC_USE_SHFL
-    a = red_j(a); b = red_j(b);
-#else
-    double ta = dpp_mov<0xB1>(a), tb = dpp_mov<0xB1>(b); a += ta; b += tb;
-    ta = dpp_mov<0x4E>(a); tb = dpp_mov<0x4E>(b); a += ta; b += tb;
-    ta = dpp_mov<0x141>(a); tb = dpp_mov<0x141>(b); a += ta; b += tb;
-#endif
-}
-__device__ inline void red_i2(double &a, double &b) {
-#ifdef LPVMPC_USE_SHFL
-    a = red_i(a); b = red_i(b);
-#else
-    double ta = dpp_mov<0x128>(a), tb = dpp_mov<0x128>(b); a += ta; b += tb;
-    a = xor16_sum(a); b = xor16_sum(b);
-    a = xor32_sum(a); b = xor32_sum(b);
-#endif
-}
-__device__ inline double limit_scaling(double v) {
-    v = v < kMinScaling ? 1.0 : v;
-    return v > kMaxScaling ? kMaxScaling : v;
-}
-// 1/sqrt(x) to double precision: hardware estimate + two Newton steps (x in [1e-4, 1e4] here)
-__device__ inline double inv_sqrt(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * (1.5 - 0.5 * x * y * y);
-    y = y * (1.5 - 0.5 * x * y * y);
-    return y;
-}
-__device__ inline double clipd(double t, double lo, double hi) { return t < lo ? lo : (t > hi ? hi : t); }
 
 #ifdef LPVMPC_STAMPS
 #define STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[slot] += t_ - tlast; tlast = __builtin_amdgcn_s_memtime(); } while (0)
@@ -165,7 +32,7 @@ __device__ inline double clipd(double t, double lo, double hi) { return t < lo ?
 #define STAMP(slot) do { } while (0)
 #endif
 
-template <int NX, int NT>
+template <int NX, int NT, int NW>
 struct Solver {
 #ifdef LPVMPC_STAMPS
     unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -173,13 +40,20 @@ struct Solver {
     static constexpr int NB = NX + 2;
     static constexpr bool kCtrl = (NX == 6);
     static constexpr bool kReg = (NT > 0);          // factor tiles in registers, horizon known at compile time
-    static constexpr int kRS = kReg ? NT + 1 : 1;
+    static constexpr bool kTwo = (NW == 2);         // two wavefronts per instance: two-sided ("twisted") elimination
+    static_assert(NW == 1 || (NW == 2 && NT >= 16 && NT % 2 == 0), "two wavefronts need an even compile-time horizon >= 16");
+    static constexpr bool kLastOdd = ((NT / 2 - 1) & 1) != 0;   // parity of the last chain position (both chains have NT/2 stages)
+    static constexpr int kMid = NT / 2;             // NW == 2: wave 0 eliminates stages 0..kMid-1 upwards, wave 1 stages
+    static constexpr int kP0 = kMid, kP1 = NT - kMid;   //         NT..kMid+1 downwards; stage kMid joins the two chains
+    static constexpr int kRS = kReg ? (kTwo ? (kP1 > kP0 ? kP1 : kP0) : NT + 1) : 1;
+    static constexpr int kStride = 64 * NW;
 
     const DevCfg &cfg;
-    const int N, NS, lane, ti, tj;
+    const int N, NS, tid, wv, lane, ti, tj;
     // tiles: scaled [A|B] always in LDS; S^-1 and L in LDS (run-time horizon) or registers (kReg)
     double *tS, *tL, *tA;
     double rS[kRS], rL[kRS];
+    double rSm, rLt, rLb;    // NW == 2: pivot inverse of the middle stage and its two link tiles (wave 0; rLb also wave 1)
     // variable-space vectors
     double *X, *Qv, *D, *XT, *DX, *VT, *AT;
     // dynamics rows / box rows (ZT*: scratch rows; DY*: delta_y, or the active-set flags during polish)
@@ -189,6 +63,7 @@ struct Solver {
     double *SINK;  // [64 + 8 NS] write-only dump for the lanes that do not own a result (avoids exec masking)
     double *Pm;    // [64] unscaled stage Hessian block 2*[Q 0; 0 R + 2 diag(dR)] (LDS copy of the weights)
     double *dRl;   // [8]  dR[0..1]
+    double *RED;   // [64] per-wave partial results of block-wide reductions / chain hand-over (NW == 2)
     double c, cinv;
     // row weights: ADMM rho classes (OSQP set_rho_vec) or, while polishing, |flag| = 1/delta on active rows
     bool pol;
@@ -198,7 +73,8 @@ struct Solver {
     double rmask;         // 1 if tj is a real dynamics row
 
     __device__ __forceinline__ Solver(const DevCfg &cf, double *smem)
-        : cfg(cf), N(kReg ? NT : cf.N), NS((kReg ? NT : cf.N) + 1), lane(threadIdx.x), ti(threadIdx.x >> 3), tj(threadIdx.x & 7) {
+        : cfg(cf), N(kReg ? NT : cf.N), NS((kReg ? NT : cf.N) + 1), tid(threadIdx.x), wv(threadIdx.x >> 6), lane(threadIdx.x & 63),
+          ti((threadIdx.x & 63) >> 3), tj(threadIdx.x & 7) {
         double *p = smem;
         tA = p; p += NS * kTS;
         tS = tL = nullptr;
@@ -208,13 +84,13 @@ struct Solver {
         Zd = p; p += V; Yd = p; p += V; Ed = p; p += V; ZTd = p; p += V; DYd = p; p += V;
         Zb = p; p += V; Yb = p; p += V; Eb = p; p += V; ZTb = p; p += V; DYb = p; p += V;
         Lo = p; p += V; Hi = p; p += V;
-        beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; SINK = p; p += 64 + 8 * NS;
+        beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; RED = p; p += 64; SINK = p; p += 64 + 8 * NS;
         { int first, cnt; rows_on(tj, first, cnt); r0 = cnt >= 1 ? first : 7; r1 = cnt >= 2 ? first + 1 : 7; }
         bvar = box_var(tj); rmask = tj < NX ? 1.0 : 0.0;
-        c = 1.0; cinv = 1.0; pol = false; rho = rho_eq = rinv = rinv_eq = 0.0;
+        c = 1.0; cinv = 1.0; pol = false; rho = rho_eq = rinv = rinv_eq = 0.0; rSm = rLt = rLb = 0.0;
     }
     static __host__ __device__ size_t lds_doubles(int N) {
-        return (size_t)(N + 1) * ((kReg ? 1 : 3) * kTS + 19 * 8 + 8) + 16 + 64 + 8 + 64;
+        return (size_t)(N + 1) * ((kReg ? 1 : 3) * kTS + 19 * 8 + 8) + 16 + 64 + 8 + 64 + 64;
     }
 
     // ---- problem structure ---------------------------------------------------------------------
@@ -244,6 +120,24 @@ struct Solver {
     __device__ __forceinline__ double w_box(int e) const { return pol ? fabs(DYb[e]) : rho_of(Lo[e], Hi[e], rho); }
     __device__ __forceinline__ double w_dyn(int e) const { return pol ? fabs(DYd[e]) : rho_eq; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // wave-local ordering of LDS traffic (one wavefront executes its DS instructions in order; this only stops
+    // the compiler from moving them across)
+    __device__ __forceinline__ void wsync() const {
+        if constexpr (kTwo) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    }
+    // all-reduce over the whole instance (one or two wavefronts); both waves combine in the same order, so
+    // every lane of the block sees bit-identical results and takes identical branches
+    __device__ __forceinline__ double bsum(double v) const {
+        v = wave_sum(v);
+        if constexpr (kTwo) { if (lane == 0) RED[wv] = v; __syncthreads(); v = RED[0] + RED[1]; __syncthreads(); }
+        return v;
+    }
+    __device__ __forceinline__ double bmax(double v) const {
+        v = wave_max(v);
+        if constexpr (kTwo) { if (lane == 0) RED[wv] = v; __syncthreads(); v = fmax(RED[0], RED[1]); __syncthreads(); }
+        return v;
+    }
 
     // ---- operators on the scaled problem ---------------------------------------------------------
     // After equilibration the products that every A / A' application needs are cached in the two unused
@@ -253,7 +147,7 @@ struct Solver {
     __device__ __forceinline__ double &Eid(int k, int r) const { return tA[k * kTS + 48 + r]; }
     __device__ __forceinline__ double &Sb(int k, int r) const { return tA[k * kTS + 56 + r]; }
     __device__ __forceinline__ void cache_row_coefficients() {
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * 8; e += kStride) {
             const int k = e >> 3, r = e & 7;
             Eid(k, r) = r < NX ? Ed[e] * D[e] : 0.0;
             Sb(k, r) = r < nbox(k) ? box_sign(r) * Eb[e] * D[k * 8 + box_var(r)] : 0.0;
@@ -272,7 +166,7 @@ struct Solver {
     }
     // (dstD, dstB) = A * src
     __device__ __forceinline__ void A_mul(const double *src, double *dstD, double *dstB) const {
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * 8; e += kStride) {
             const int k = e >> 3;
             dstD[e] = rmask * (Eid(k, tj) * src[e] - prev_stage_dot(k, src));
             dstB[e] = Sb(k, tj) * src[k * 8 + bvar];
@@ -293,7 +187,7 @@ struct Solver {
     }
     // dst = A' * (srcD, srcB)
     __device__ __forceinline__ void At_mul(const double *srcD, const double *srcB, double *dst) const {
-        for (int e = lane; e < NS * 8; e += 64) dst[e] = At_elem(e, srcD, srcB);
+        for (int e = tid; e < NS * 8; e += kStride) dst[e] = At_elem(e, srcD, srcB);
     }
     // row a of the stage-k Hessian block times (D_k .* v_k), plus the slew-rate coupling to the neighbouring
     // stages; ABS = true gives the infinity norm of the (scaled) column instead.  Branch-free: the Pm row is
@@ -326,7 +220,7 @@ struct Solver {
     }
     // dst = P * src   (P = c D P0 D)
     __device__ __forceinline__ void P_mul(const double *src, double *dst) const {
-        for (int e = lane; e < NS * 8; e += 64) dst[e] = P_row<false>(e >> 3, src);
+        for (int e = tid; e < NS * 8; e += kStride) dst[e] = P_row<false>(e >> 3, src);
     }
     // infinity norm of column (k, tj) of the scaled Hessian
     __device__ __forceinline__ double P_colnorm(int k, int) const { return P_row<true>(k, D); }
@@ -338,7 +232,7 @@ struct Solver {
         const int ntrue = NS * NX + N * 2;
         for (int it = 0; it < cfg.scaling; ++it) {
             // infinity norms of the columns of [P A'; A 0] -> step factors in XT (variables), ZTd / ZTb (rows)
-            for (int e = lane; e < NS * 8; e += 64) {
+            for (int e = tid; e < NS * 8; e += kStride) {
                 const int k = e >> 3, a = tj, kn = k < N ? k + 1 : N, kp = k > 0 ? k - 1 : 0;
                 const double de = D[e], ede = Ed[e], ebe = Eb[e];
                 const double *col = tA + k * kTS + a, *row = tA + kp * kTS + a * 8;
@@ -363,22 +257,22 @@ struct Solver {
                 ZTb[e] = inv_sqrt(limit_scaling(bn));
             }
             sync();
-            for (int e = lane; e < NS * 8; e += 64) { D[e] *= XT[e]; Ed[e] *= ZTd[e]; Eb[e] *= ZTb[e]; }
+            for (int e = tid; e < NS * 8; e += kStride) { D[e] *= XT[e]; Ed[e] *= ZTd[e]; Eb[e] *= ZTb[e]; }
             sync();
             // cost normalisation
             double psum = 0.0, qmax = 0.0;
-            for (int e = lane; e < NS * 8; e += 64) {
+            for (int e = tid; e < NS * 8; e += kStride) {
                 psum += P_colnorm(e >> 3, tj);
                 qmax = fmax(qmax, fabs(c * D[e] * Qv[e]));
             }
-            psum = wave_sum(psum) / (double)ntrue;
-            qmax = limit_scaling(wave_max(qmax));
+            psum = bsum(psum) / (double)ntrue;
+            qmax = limit_scaling(bmax(qmax));
             const double ct = limit_scaling(fmax(psum, qmax));
             c *= 1.0 / ct;
         }
         cinv = 1.0 / c;
         // A <- E A D on the stored [A|B] tiles, four stages per trip (all loads before the stores)
-        for (int k0 = 0; k0 < N; k0 += 4) {
+        for (int k0 = 4 * wv; k0 < N; k0 += 4 * NW) {
             double v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -398,80 +292,151 @@ struct Solver {
     // keeps the factorisation accurate for the 1/delta-weighted polish system (cond ~ 1e9), where a
     // Schur complement formed through an explicit S^-1 loses ~7 digits.  Stored for the solve:
     // S_k^-1 = C^-T C^-1 (tS / rS) and L_k = G C_{k-1}^-1 (tL / rL; transposed for odd k, see kkt_solve).
-    __device__ __forceinline__ void factor(double sig) {
-        // 8x8 products go through four 64-double scratch tiles in LDS (the x~ / delta_x vectors are free
-        // whenever a factorisation runs): an operand is written once and each lane then reads one row of each
-        // factor with 16-byte loads.  T0 = K_{k,k-1}, T1 = C_{k-1}^-1, T2 = G, T3 = C_{k-1}^-T (all row-major).
-        double *const T0 = XT, *const T1 = XT + 64, *const T2 = XT + 128, *const T3 = XT + 192;
+    // diagonal block (stage k) of K, element [ti][tj]; identity on the padding
+    __device__ __forceinline__ double kd_block(int k, double sig) const {
+        const int nv = nvar(k);
+        if (!(ti < nv && tj < nv)) return (ti == tj) ? 1.0 : 0.0;
+        double kd = Pc(k, ti, tj) * c * D[k * 8 + ti] * D[k * 8 + tj];
+        if (ti == tj) {
+            kd += sig;
+            int first, cnt; rows_on(ti, first, cnt);
+            for (int t = 0; t < cnt; ++t) { const int r = first + t; const double sb = Sb(k, r); kd += w_box(k * 8 + r) * sb * sb; }
+            { const double ei = Eid(k, ti); kd += w_dyn(k * 8 + ti) * ei * ei; }
+        }
+        if (k < N) {
+            const double *ca = tA + k * kTS + ti, *cb = tA + k * kTS + tj;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) kd += w_dyn((k + 1) * 8 + r) * ca[r * 8] * cb[r * 8];
+        }
+        return kd;
+    }
+    // off-diagonal block K_{k,k-1}: rows = stage k, columns = stage k-1 (k >= 1), element [ti][tj]
+    __device__ __forceinline__ double ko_down(int k) const {
+        double ko = 0.0;
+        if (tj < NB) {
+            if (ti < NX) ko = -w_dyn(k * 8 + ti) * Eid(k, ti) * tA[(k - 1) * kTS + ti * 8 + tj];
+            else if (ti == tj && ti < nvar(k)) ko = c * D[k * 8 + ti] * (-2.0 * dRl[ti - NX]) * D[(k - 1) * 8 + ti];
+        }
+        return ko;
+    }
+    // off-diagonal block K_{k,k+1} = K_{k+1,k}': rows = stage k, columns = stage k+1 (k < N), element [ti][tj]
+    __device__ __forceinline__ double ko_up(int k) const {
+        double ko = 0.0;
+        if (ti < NB) {
+            if (tj < NX) ko = -w_dyn((k + 1) * 8 + tj) * Eid(k + 1, tj) * tA[k * kTS + tj * 8 + ti];
+            else if (ti == tj && tj < nvar(k + 1)) ko = c * D[(k + 1) * 8 + tj] * (-2.0 * dRl[tj - NX]) * D[k * 8 + tj];
+        }
+        return ko;
+    }
+    // Cholesky S = C C' merged with the forward substitution C W = I (8 pivots); returns W = C^-1 (lower triangular)
+    __device__ __forceinline__ double chol_inverse(double s) const {
+        double w = (ti == tj) ? 1.0 : 0.0;
+#define LPVMPC_CHOL_STEP(T)                                                                                   \
+        {                                                                                                         \
+            const double d = bcast_lane<(T) * 9>(s);                                                              \
+            const double rs = inv_sqrt(d);                                                                        \
+            const double cit = bcast_row<(T)>(s) * rs;                                                            \
+            const double cjt = __shfl(s, (T) * 8 + tj) * rs;                                                      \
+            const double wtj = __shfl(w, (T) * 8 + tj) * rs;                                                      \
+            if (ti > (T) && tj > (T)) s -= cit * cjt;                                                             \
+            if (ti == (T)) w = wtj; else if (ti > (T)) w -= cit * wtj;                                            \
+        }
+        LPVMPC_CHOL_STEP(0) LPVMPC_CHOL_STEP(1) LPVMPC_CHOL_STEP(2) LPVMPC_CHOL_STEP(3)
+        LPVMPC_CHOL_STEP(4) LPVMPC_CHOL_STEP(5) LPVMPC_CHOL_STEP(6) LPVMPC_CHOL_STEP(7)
+#undef LPVMPC_CHOL_STEP
+        return w;
+    }
+    // 8x8 products go through four 64-double scratch tiles per wavefront in LDS (the x~ / delta_x / scratch
+    // vectors are free whenever a factorisation runs): an operand is written once and each lane then reads one
+    // row of each factor with 16-byte loads.  T0 = K_{k,pred}, T1 = C_pred^-1, T2 = G, T3 = C_pred^-T (row-major).
+    // One elimination step: given the coupling block ko to the previously eliminated stage (whose C^-1 sits in
+    // T1/T3), returns s = kd - G G' and l = G C_pred^-1.
+    __device__ __forceinline__ void schur_step(double *T, double ko, double kd, double &s, double &l) const {
+        double *const T0 = T, *const T2 = T + 128;
         const double2 *const rowi0 = reinterpret_cast<const double2 *>(T0 + ti * 8);
-        const double2 *const rowj1 = reinterpret_cast<const double2 *>(T1 + tj * 8);
+        const double2 *const rowj1 = reinterpret_cast<const double2 *>(T + 64 + tj * 8);
         const double2 *const rowi2 = reinterpret_cast<const double2 *>(T2 + ti * 8);
         const double2 *const rowj2 = reinterpret_cast<const double2 *>(T2 + tj * 8);
-        const double2 *const rowi3 = reinterpret_cast<const double2 *>(T3 + ti * 8);
-        const double2 *const rowj3 = reinterpret_cast<const double2 *>(T3 + tj * 8);
+        const double2 *const rowj3 = reinterpret_cast<const double2 *>(T + 192 + tj * 8);
+        T0[lane] = ko;
+        wsync();
+        double g = 0.0;                                     // G = Koff C^-T : sum_t Koff[i][t] Cinv[j][t]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const double2 a = rowi0[t], b = rowj1[t]; g += a.x * b.x; g += a.y * b.y; }
+        T2[lane] = g;
+        wsync();
+        s = kd; l = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                       // S = Kd - G G' ;  L = G C^-1 = sum_t G[i][t] Cinv^T[j][t]
+            const double2 a = rowi2[t], b = rowj2[t], cT = rowj3[t];
+            s -= a.x * b.x; s -= a.y * b.y;
+            l += a.x * cT.x; l += a.y * cT.y;
+        }
+    }
+    // publish W = C^-1 (row-major in T1, transposed in T3) and return S^-1 = C^-T C^-1
+    __device__ __forceinline__ double publish_and_invert(double *T, double w) const {
+        const double2 *const rowi3 = reinterpret_cast<const double2 *>(T + 192 + ti * 8);
+        const double2 *const rowj3 = reinterpret_cast<const double2 *>(T + 192 + tj * 8);
+        wsync();
+        T[64 + lane] = w; T[192 + tj * 8 + ti] = w;
+        wsync();
+        double sinv = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const double2 a = rowi3[t], b = rowj3[t]; sinv += a.x * b.x; sinv += a.y * b.y; }
+        return sinv;
+    }
+    __device__ __forceinline__ void factor(double sig) {
         sync();
+        if constexpr (kTwo) {
+            // ---- two-sided elimination: wave 0 runs stages 0 .. kMid-1 upwards, wave 1 stages N .. kMid+1 downwards ----
+            double *const T = XT + wv * 256;
+            const int P = wv ? kP1 : kP0;
+            for (int p = 0; p < P; ++p) {
+                const int k = wv ? N - p : p;
+                const double kd = kd_block(k, sig);
+                double s = kd, l = 0.0;
+                if (p >= 1) schur_step(T, wv ? ko_up(k) : ko_down(k), kd, s, l);
+                const double w = chol_inverse(s);
+                const double sinv = publish_and_invert(T, w);
+                const double lt = (p & 1) ? __shfl(l, tj * 8 + ti) : l;      // odd chain positions keep L transposed
+#pragma unroll
+                for (int pp = 0; pp < kRS; ++pp) if (pp == p) { rL[pp] = lt; rS[pp] = sinv; }
+            }
+            sync();
+            // ---- middle stage: S_m = K_mm - G_t G_t' - G_b G_b' with both neighbours' C^-1 (wave 0) ----
+            if (wv == 0) {
+                const double kd = kd_block(kMid, sig);
+                double s = kd, lt = 0.0, lb = 0.0, s2;
+                if (kP0 >= 1) { schur_step(T, ko_down(kMid), kd, s, lt); }
+                if (kP1 >= 1) {
+                    // second neighbour: reuse the step with wave 1's published C^-1 (its T1/T3), on wave 0's T0/T2
+                    double *const Tb = XT + 256;
+                    wsync();
+                    // copy wave 1's C^-1 tiles next to our T0/T2 so that schur_step finds them at T+64 / T+192
+                    T[64 + lane] = Tb[64 + lane]; T[192 + lane] = Tb[192 + lane];
+                    wsync();
+                    schur_step(T, ko_up(kMid), s, s2, lb);
+                    s = s2;
+                }
+                const double w = chol_inverse(s);
+                rSm = publish_and_invert(T, w);
+                // link tiles are used with the form of the last chain stage: position P-1 odd -> stored as is
+                rLt = ((kP0 - 1) & 1) ? lt : __shfl(lt, tj * 8 + ti);
+                rLb = ((kP1 - 1) & 1) ? lb : __shfl(lb, tj * 8 + ti);
+                RED[lane] = rLb;                                   // hand the lower link tile to wave 1 (already oriented)
+            }
+            sync();
+            if (wv == 1) rLb = RED[lane];
+            sync();
+            return;
+        }
+        double *const T = XT;
         for (int k = 0; k <= N; ++k) {
-            const int nv = nvar(k);
-            double kd;
-            if (ti < nv && tj < nv) {
-                kd = Pc(k, ti, tj) * c * D[k * 8 + ti] * D[k * 8 + tj];
-                if (ti == tj) {
-                    kd += sig;
-                    int first, cnt; rows_on(ti, first, cnt);
-                    for (int t = 0; t < cnt; ++t) { const int r = first + t;
-                        { const double s = Sb(k, r); kd += w_box(k * 8 + r) * s * s; } }
-                    { const double s = Eid(k, ti); kd += w_dyn(k * 8 + ti) * s * s; }
-                }
-                if (k < N) {
-                    const double *ca = tA + k * kTS + ti, *cb = tA + k * kTS + tj;
-#pragma unroll
-                    for (int r = 0; r < NX; ++r) kd += w_dyn((k + 1) * 8 + r) * ca[r * 8] * cb[r * 8];
-                }
-            } else kd = (ti == tj) ? 1.0 : 0.0;
+            const double kd = kd_block(k, sig);
             double s = kd, l = 0.0;
-            if (k >= 1) {
-                // off-diagonal block: rows = stage k, columns = stage k-1
-                double ko = 0.0;
-                if (tj < NB) {
-                    if (ti < NX) ko = -w_dyn(k * 8 + ti) * Eid(k, ti) * tA[(k - 1) * kTS + ti * 8 + tj];
-                    else if (ti == tj && ti < nv) ko = c * D[k * 8 + ti] * (-2.0 * dRl[ti - NX]) * D[(k - 1) * 8 + ti];
-                }
-                T0[lane] = ko;
-                sync();
-                double g = 0.0;                                     // G = Koff C^-T : sum_t Koff[i][t] Cinv[j][t]
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { const double2 a = rowi0[t], b = rowj1[t]; g += a.x * b.x; g += a.y * b.y; }
-                T2[lane] = g;
-                sync();
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {                       // S = Kd - G G' ;  L = G C^-1 = sum_t G[i][t] Cinv^T[j][t]
-                    const double2 a = rowi2[t], b = rowj2[t], cT = rowj3[t];
-                    s -= a.x * b.x; s -= a.y * b.y;
-                    l += a.x * cT.x; l += a.y * cT.y;
-                }
-            }
-            // Cholesky S = C C' merged with the forward substitution C W = I: after step t row t of W is final.
-            double w = (ti == tj) ? 1.0 : 0.0;
-#define LPVMPC_CHOL_STEP(T)                                                                                   \
-            {                                                                                                     \
-                const double d = bcast_lane<(T) * 9>(s);                                                          \
-                const double rs = inv_sqrt(d);                                                                    \
-                const double cit = bcast_row<(T)>(s) * rs;                                                        \
-                const double cjt = __shfl(s, (T) * 8 + tj) * rs;                                                  \
-                const double wtj = __shfl(w, (T) * 8 + tj) * rs;                                                  \
-                if (ti > (T) && tj > (T)) s -= cit * cjt;                                                         \
-                if (ti == (T)) w = wtj; else if (ti > (T)) w -= cit * wtj;                                        \
-            }
-            LPVMPC_CHOL_STEP(0) LPVMPC_CHOL_STEP(1) LPVMPC_CHOL_STEP(2) LPVMPC_CHOL_STEP(3)
-            LPVMPC_CHOL_STEP(4) LPVMPC_CHOL_STEP(5) LPVMPC_CHOL_STEP(6) LPVMPC_CHOL_STEP(7)
-#undef LPVMPC_CHOL_STEP
-            // w = C_k^-1.  Publish it (row-major and transposed) for S^-1 below and for the next stage.
-            sync();
-            T1[lane] = w; T3[tj * 8 + ti] = w;
-            sync();
-            double sinv = 0.0;                                      // S^-1 = C^-T C^-1 : sum_t Cinv^T[i][t] Cinv^T[j][t]
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { const double2 a = rowi3[t], b = rowj3[t]; sinv += a.x * b.x; sinv += a.y * b.y; }
+            if (k >= 1) schur_step(T, ko_down(k), kd, s, l);
+            const double w = chol_inverse(s);
+            const double sinv = publish_and_invert(T, w);
             if constexpr (kReg) {
                 const double lt = (k & 1) ? __shfl(l, tj * 8 + ti) : l;      // odd stages keep L_k transposed
 #pragma unroll
@@ -488,7 +453,86 @@ struct Solver {
     // Stage vectors alternate between "column form" (component ti, even stages) and "row form"
     // (component tj, odd stages); L_k is stored transposed for odd k, so every step of the two sweeps is
     // one tile product followed by one all-reduce, with no lane transposition on the dependent chain.
+    // ---- two-sided sweeps (NW == 2) -------------------------------------------------------------------
+    // Chain position p of wave w is stage p (w = 0) or N - p (w = 1); even positions use column form, odd ones
+    // row form, L of odd positions is stored transposed -- exactly the single-chain scheme below, run on two
+    // half-length chains at once.  The chains meet at stage kMid (wave 0), then both sweep outwards again.
+    template <bool BOT>
+    __device__ __forceinline__ void twisted_forward() {
+        constexpr int P = BOT ? kP1 : kP0;
+        double *const vrow = (ti == 0) ? VT + tj : SINK + lane;
+        double *const vcol = (tj == 0) ? VT + ti : SINK + lane;
+        auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
+        double yc = XT[stage(0) * 8 + ti], yr = 0.0;
+        double bq[3];
+        bq[1] = XT[stage(1) * 8 + tj];
+        bq[2] = (P > 2) ? XT[stage(2) * 8 + ti] : 0.0;
+#pragma unroll
+        for (int p = 1; p < P; ++p) {
+            const double bk = bq[p % 3];
+            if (p + 2 < P) bq[(p + 2) % 3] = ((p + 2) & 1) ? XT[stage(p + 2) * 8 + tj] : XT[stage(p + 2) * 8 + ti];
+            if (p & 1) {
+                double pv = rS[p - 1] * yc, ch = rL[p] * yc;
+                red_i2(ch, pv);
+                vrow[stage(p - 1) * 8] = pv;
+                yr = bk - ch;
+            } else {
+                double pv = rS[p - 1] * yr, ch = rL[p] * yr;
+                red_j2(ch, pv);
+                vcol[stage(p - 1) * 8] = pv;
+                yc = bk - ch;
+            }
+        }
+        // pivot product of the last chain stage, and its y handed to wave 0 for the middle stage
+        if (kLastOdd) { vcol[stage(P - 1) * 8] = red_j(rS[P - 1] * yr); if (ti == 0) RED[32 + (BOT ? 8 : 0) + tj] = yr; }
+        else          { vrow[stage(P - 1) * 8] = red_i(rS[P - 1] * yc); if (tj == 0) RED[32 + (BOT ? 8 : 0) + ti] = yc; }
+    }
+    __device__ __forceinline__ void twisted_middle() {      // wave 0 only
+        double *const xrow = (ti == 0) ? XT + tj : SINK + lane;
+        double *const xcol = (tj == 0) ? XT + ti : SINK + lane;
+        if (kLastOdd) {     // neighbours' y in row form -> y_m in column form -> x_m in row form
+            const double ym = XT[kMid * 8 + ti] - red_j(rLt * RED[32 + tj] + rLb * RED[40 + tj]);
+            xrow[kMid * 8] = red_i(rSm * ym);
+        } else {
+            const double ym = XT[kMid * 8 + tj] - red_i(rLt * RED[32 + ti] + rLb * RED[40 + ti]);
+            xcol[kMid * 8] = red_j(rSm * ym);
+        }
+    }
+    template <bool BOT>
+    __device__ __forceinline__ void twisted_backward() {
+        constexpr int P = BOT ? kP1 : kP0;
+        double *const xrow = (ti == 0) ? XT + tj : SINK + lane;
+        double *const xcol = (tj == 0) ? XT + ti : SINK + lane;
+        auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
+        const double link = BOT ? rLb : rLt;
+        double xc = 0.0, xr = 0.0;
+        // first step: x_{P-1} = v_{P-1} - L_link' x_m
+        if (kLastOdd) { xr = VT[stage(P - 1) * 8 + tj] - red_i(link * XT[kMid * 8 + ti]); xrow[stage(P - 1) * 8] = xr; }
+        else          { xc = VT[stage(P - 1) * 8 + ti] - red_j(link * XT[kMid * 8 + tj]); xcol[stage(P - 1) * 8] = xc; }
+        double vq[3];
+        if (P >= 2) vq[(P - 2) % 3] = ((P - 2) & 1) ? VT[stage(P - 2) * 8 + tj] : VT[stage(P - 2) * 8 + ti];
+        if (P >= 3) vq[(P - 3) % 3] = ((P - 3) & 1) ? VT[stage(P - 3) * 8 + tj] : VT[stage(P - 3) * 8 + ti];
+#pragma unroll
+        for (int p = P - 2; p >= 0; --p) {
+            const double vk = vq[p % 3];
+            if (p - 2 >= 0) vq[(p - 2) % 3] = ((p - 2) & 1) ? VT[stage(p - 2) * 8 + tj] : VT[stage(p - 2) * 8 + ti];
+            if (((p + 1) & 1) == 0) { xr = vk - red_i(rL[p + 1] * xc); xrow[stage(p) * 8] = xr; }
+            else                    { xc = vk - red_j(rL[p + 1] * xr); xcol[stage(p) * 8] = xc; }
+        }
+    }
+
     __device__ __forceinline__ void kkt_solve() {
+        if constexpr (kTwo) {
+            if (wv == 0) twisted_forward<false>(); else twisted_forward<true>();
+            sync();
+            STAMP(1);
+            if (wv == 0) twisted_middle();
+            sync();
+            if (wv == 0) twisted_backward<false>(); else twisted_backward<true>();
+            sync();
+            STAMP(2);
+            return;
+        }
         if constexpr (kReg) {
             // Results of a reduction are replicated over 8 lanes; the owner lane stores to the vector, the
             // other seven to SINK (same instruction, no exec masking).  Offsets 8*k are immediates.
@@ -582,7 +626,7 @@ struct Solver {
         At_mul(yd, yb, AT);
         sync();
         Res r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * 8; e += kStride) {
             const double eid = 1.0 / Ed[e], eib = 1.0 / Eb[e], di = 1.0 / D[e];
             const double rd = ZTd[e] - zd[e], rb = ZTb[e] - zb[e];
             r.s_pri = fmax(r.s_pri, fmax(fabs(rd), fabs(rb)));
@@ -597,11 +641,21 @@ struct Solver {
             r.s_Aty = fmax(r.s_Aty, fabs(AT[e]));    r.nAty = fmax(r.nAty, fabs(di * AT[e]));
             r.s_q = fmax(r.s_q, fabs(Qv[e]));        r.nq = fmax(r.nq, fabs(di * Qv[e]));
         }
-        r.pri = wave_max(r.pri); r.dua = cinv * wave_max(r.dua);
-        r.nAx = wave_max(r.nAx); r.nz = wave_max(r.nz);
-        r.nPx = cinv * wave_max(r.nPx); r.nAty = cinv * wave_max(r.nAty); r.nq = cinv * wave_max(r.nq);
-        r.s_pri = wave_max(r.s_pri); r.s_dua = wave_max(r.s_dua); r.s_Ax = wave_max(r.s_Ax); r.s_z = wave_max(r.s_z);
-        r.s_Px = wave_max(r.s_Px); r.s_Aty = wave_max(r.s_Aty); r.s_q = wave_max(r.s_q);
+        double m_[14] = {r.pri, r.dua, r.nAx, r.nz, r.nPx, r.nAty, r.nq, r.s_pri, r.s_dua, r.s_Ax, r.s_z, r.s_Px, r.s_Aty, r.s_q};
+#pragma unroll
+        for (int i = 0; i < 14; ++i) m_[i] = wave_max(m_[i]);
+        if constexpr (kTwo) {
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 14; ++i) RED[wv * 16 + i] = m_[i];
+            }
+            sync();
+#pragma unroll
+            for (int i = 0; i < 14; ++i) m_[i] = fmax(RED[i], RED[16 + i]);
+        }
+        r.pri = m_[0]; r.dua = cinv * m_[1]; r.nAx = m_[2]; r.nz = m_[3];
+        r.nPx = cinv * m_[4]; r.nAty = cinv * m_[5]; r.nq = cinv * m_[6];
+        r.s_pri = m_[7]; r.s_dua = m_[8]; r.s_Ax = m_[9]; r.s_z = m_[10]; r.s_Px = m_[11]; r.s_Aty = m_[12]; r.s_q = m_[13];
         sync();
         return r;
     }
@@ -609,8 +663,8 @@ struct Solver {
         P_mul(xv, VT);
         sync();
         double v = 0.0;
-        for (int e = lane; e < NS * 8; e += 64) v += xv[e] * (0.5 * VT[e] + Qv[e]);
-        v = wave_sum(v) * cinv;
+        for (int e = tid; e < NS * 8; e += kStride) v += xv[e] * (0.5 * VT[e] + Qv[e]);
+        v = bsum(v) * cinv;
         sync();
         return v;
     }
@@ -621,7 +675,7 @@ struct Solver {
     // ---- infeasibility certificates (OSQP is_primal_infeasible / is_dual_infeasible) ----------------
     __device__ __forceinline__ bool primal_infeasible(double eps) {
         double nd = 0.0;
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * 8; e += kStride) {
             // dynamics rows have finite bounds: no projection.  box rows: project on the polar recession cone
             double dy = DYb[e];
             const double lo = Lo[e], hi = Hi[e];
@@ -630,23 +684,23 @@ struct Solver {
             DYb[e] = dy;
             nd = fmax(nd, fmax(fabs(Ed[e] * DYd[e]), fabs(Eb[e] * dy)));
         }
-        nd = wave_max(nd);
+        nd = bmax(nd);
         sync();
         bool res = false;
         if (nd > eps) {
             double lhs = 0.0;
-            for (int e = lane; e < NS * 8; e += 64) {
+            for (int e = tid; e < NS * 8; e += kStride) {
                 const double b = dyn_bound(e), dyd = DYd[e], dyb = DYb[e];
                 lhs += b * fmax(dyd, 0.0) + b * fmin(dyd, 0.0);
                 lhs += Hi[e] * fmax(dyb, 0.0) + Lo[e] * fmin(dyb, 0.0);
             }
-            lhs = wave_sum(lhs);
+            lhs = bsum(lhs);
             if (lhs < -eps * nd) {
                 At_mul(DYd, DYb, AT);
                 sync();
                 double na = 0.0;
-                for (int e = lane; e < NS * 8; e += 64) na = fmax(na, fabs(AT[e] / D[e]));
-                na = wave_max(na);
+                for (int e = tid; e < NS * 8; e += kStride) na = fmax(na, fabs(AT[e] / D[e]));
+                na = bmax(na);
                 res = na < eps * nd;
                 sync();
             }
@@ -655,21 +709,21 @@ struct Solver {
     }
     __device__ __forceinline__ bool dual_infeasible(double eps) {
         double nd = 0.0, qdx = 0.0;
-        for (int e = lane; e < NS * 8; e += 64) { nd = fmax(nd, fabs(D[e] * DX[e])); qdx += Qv[e] * DX[e]; }
-        nd = wave_max(nd); qdx = wave_sum(qdx);
+        for (int e = tid; e < NS * 8; e += kStride) { nd = fmax(nd, fabs(D[e] * DX[e])); qdx += Qv[e] * DX[e]; }
+        nd = bmax(nd); qdx = bsum(qdx);
         bool res = false;
         if (nd > eps && qdx < -c * eps * nd) {
             P_mul(DX, VT);
             sync();
             double np = 0.0;
-            for (int e = lane; e < NS * 8; e += 64) np = fmax(np, fabs(VT[e] / D[e]));
-            np = wave_max(np);
+            for (int e = tid; e < NS * 8; e += kStride) np = fmax(np, fabs(VT[e] / D[e]));
+            np = bmax(np);
             sync();
             if (np < c * eps * nd) {
                 A_mul(DX, ZTd, ZTb);
                 sync();
                 double bad = 0.0;
-                for (int e = lane; e < NS * 8; e += 64) {
+                for (int e = tid; e < NS * 8; e += kStride) {
                     const int k = e >> 3, r = e & 7;
                     if (r < NX) { const double v = ZTd[e] / Ed[e]; if (v > eps * nd || v < -eps * nd) bad = 1.0; }
                     if (r < nbox(k)) {
@@ -677,7 +731,7 @@ struct Solver {
                         if ((Hi[e] < kInfty * kMinScaling && v > eps * nd) || (Lo[e] > -kInfty * kMinScaling && v < -eps * nd)) bad = 1.0;
                     }
                 }
-                res = wave_max(bad) == 0.0;
+                res = bmax(bad) == 0.0;
                 sync();
             }
         }
@@ -686,7 +740,7 @@ struct Solver {
 
     // w rows for the next right-hand side: ZT = rho z - y   (kept in ZT* between iterations)
     __device__ __forceinline__ void recompute_w() {
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * 8; e += kStride) {
             ZTd[e] = rho_eq * Zd[e] - Yd[e];
             ZTb[e] = rho_of(Lo[e], Hi[e], rho) * Zb[e] - Yb[e];
         }
@@ -694,14 +748,14 @@ struct Solver {
     }
     // XT = sigma x - q + A' (rho z - y)        (OSQP compute_rhs, x part, reduced form)
     __device__ __forceinline__ void build_rhs(double sigma) {
-        for (int e = lane; e < NS * 8; e += 64) XT[e] = At_elem(e, ZTd, ZTb) + (sigma * X[e] - Qv[e]);
+        for (int e = tid; e < NS * 8; e += kStride) XT[e] = At_elem(e, ZTd, ZTb) + (sigma * X[e] - Qv[e]);
         sync();
     }
     // z~ = A x~ fused with OSQP update_x / update_z / update_y; leaves rho z - y in ZT*.
     // All LDS reads of a round are issued before any of its writes.
     __device__ __forceinline__ void update(double alpha, bool want_delta) {
         const double oma = 1.0 - alpha;
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * 8; e += kStride) {
             const int k = e >> 3;
             const double xt = XT[e], xo = X[e];
             const double zd = Zd[e], yd = Yd[e], zb = Zb[e], yb = Yb[e], lo = Lo[e], hi = Hi[e];
@@ -738,24 +792,24 @@ struct Solver {
                 if (ti == tj) v += 4.0 * cfg.dR[ti - NX];
             }
             Pm[lane] = v;
-            if (lane < 8) dRl[lane] = lane < 2 ? cfg.dR[lane] : 0.0;
+            if (tid < 8) dRl[tid] = tid < 2 ? cfg.dR[tid] : 0.0;
         }
-        for (int e = lane; e < NS * kTS; e += 64) { tA[e] = 0.0; }
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * kTS; e += kStride) { tA[e] = 0.0; }
+        for (int e = tid; e < NS * 8; e += kStride) {
             X[e] = 0; D[e] = 1.0; DX[e] = 0; Zd[e] = 0; Yd[e] = 0; Ed[e] = 1.0; DYd[e] = 0; ZTd[e] = 0;
             Zb[e] = 0; Yb[e] = 0; Eb[e] = 1.0; DYb[e] = 0; Lo[e] = 0; Hi[e] = 0; Qv[e] = 0; ZTb[e] = 0;
         }
         sync();
         {
             const double *src = a.AB + (size_t)inst * N * NX * NB;
-            for (int e = lane; e < N * NX * NB; e += 64) {
+            for (int e = tid; e < N * NX * NB; e += kStride) {
                 const int k = e / (NX * NB), rem = e - k * (NX * NB), r = rem / NB, col = rem - r * NB;
                 tA[k * kTS + r * 8 + col] = src[e];
             }
         }
         const double uo0 = a.u_old ? a.u_old[(size_t)inst * 2 + 0] : 0.0, uo1 = a.u_old ? a.u_old[(size_t)inst * 2 + 1] : 0.0;
         const double mey = (!kCtrl && a.max_ey) ? a.max_ey[inst] : 0.0;
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * 8; e += kStride) {
             const int k = e >> 3, r = e & 7;
             // linear cost: controller q = -2 xtrack' M0 (CTRL:434-447); planner q = L_cf (PLAN:163)
             double q = 0.0;
@@ -771,13 +825,13 @@ struct Solver {
                 Lo[e] = fmax(lo, -kInfty); Hi[e] = fmin(hi, kInfty);
             }
         }
-        if (lane < 16) beq[lane] = (lane < NX) ? a.x0[(size_t)inst * NX + lane] : 0.0;
+        if (tid < 16) beq[tid] = (tid < NX) ? a.x0[(size_t)inst * NX + tid] : 0.0;
         sync();
 
         // ---------- setup: scaling, rho, factorisation ----------
         if (cfg.scaling > 0) scale_data();
-        for (int e = lane; e < NS * 8; e += 64) { Qv[e] *= c * D[e]; Lo[e] *= Eb[e]; Hi[e] *= Eb[e]; }
-        if (lane < 8) beq[lane] *= Ed[lane];
+        for (int e = tid; e < NS * 8; e += kStride) { Qv[e] *= c * D[e]; Lo[e] *= Eb[e]; Hi[e] *= Eb[e]; }
+        if (tid < 8) beq[tid] *= Ed[tid];
         sync();
         cache_row_coefficients();
         set_rho(fmin(fmax(cfg.rho, kRhoMin), kRhoMax));
@@ -836,14 +890,14 @@ struct Solver {
                            status == LPVMPC_DUAL_INFEASIBLE_ || status == LPVMPC_DUAL_INFEASIBLE_INACC_ ||
                            status == LPVMPC_NON_CVX_);
         const double nan = __builtin_nan("");
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * 8; e += kStride) {
             const int k = e >> 3, r = e & 7;
             const double v = sol ? D[e] * X[e] : nan;
             if (r < NX) a.xPred[((size_t)inst * NS + k) * NX + r] = v;
             else if (r < NB && k < N) a.uPred[((size_t)inst * N + k) * 2 + (r - NX)] = v;
         }
 #ifdef LPVMPC_STAMPS
-        if (lane == 0 && a.resid) {     // diagnostic build: resid carries per-iteration cycle counts instead
+        if (tid == 0 && a.resid) {     // diagnostic build: resid carries per-iteration cycle counts instead
             double *o = a.resid + (size_t)inst * 4;
             o[0] = (double)stamp[0] / iter; o[1] = (double)stamp[1] / iter; o[2] = (double)stamp[2] / iter; o[3] = (double)stamp[3] / iter;
             if (a.status) a.status[inst] = status;
@@ -851,7 +905,7 @@ struct Solver {
             return;
         }
 #endif
-        if (lane == 0) {
+        if (tid == 0) {
             if (a.status) a.status[inst] = status;
             if (a.iters) a.iters[inst] = iter;
             if (a.polish) a.polish[inst] = status_polish;
@@ -892,7 +946,7 @@ struct Solver {
     // upper-active, W < 0 lower-active rows (|W| = 1/delta), W = 0 inactive.
     __device__ __forceinline__ int polish(double &pri_res, double &dua_res, double &obj) {
         const double delta = cfg.delta, dinv = 1.0 / cfg.delta;
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * 8; e += kStride) {
             const int k = e >> 3, r = e & 7;
             double wd = 0.0, wb = 0.0;
             if (r < NX) {
@@ -909,21 +963,21 @@ struct Solver {
         factor(delta);
         // px (DX), py (Yd/Yb are overwritten: ADMM duals are no longer needed)
         // initial solve: rhs = -q + A'(W b)
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * 8; e += kStride) {
             ZTd[e] = fabs(DYd[e]) * dyn_bound(e);
             ZTb[e] = fabs(DYb[e]) * (DYb[e] > 0 ? Hi[e] : (DYb[e] < 0 ? Lo[e] : 0.0));
         }
         sync();
         At_mul(ZTd, ZTb, XT);
         sync();
-        for (int e = lane; e < NS * 8; e += 64) XT[e] -= Qv[e];
+        for (int e = tid; e < NS * 8; e += kStride) XT[e] -= Qv[e];
         sync();
         kkt_solve();
-        for (int e = lane; e < NS * 8; e += 64) DX[e] = XT[e];
+        for (int e = tid; e < NS * 8; e += kStride) DX[e] = XT[e];
         sync();
         A_mul(DX, ZTd, ZTb);
         sync();
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * 8; e += kStride) {
             Yd[e] = fabs(DYd[e]) * (ZTd[e] - dyn_bound(e));
             Yb[e] = fabs(DYb[e]) * (ZTb[e] - (DYb[e] > 0 ? Hi[e] : (DYb[e] < 0 ? Lo[e] : 0.0)));
         }
@@ -934,7 +988,7 @@ struct Solver {
             At_mul(Yd, Yb, AT);
             A_mul(DX, ZTd, ZTb);
             sync();
-            for (int e = lane; e < NS * 8; e += 64) {
+            for (int e = tid; e < NS * 8; e += kStride) {
                 const double r2d = (DYd[e] != 0.0) ? dyn_bound(e) - ZTd[e] : 0.0;
                 const double r2b = (DYb[e] != 0.0) ? (DYb[e] > 0 ? Hi[e] : Lo[e]) - ZTb[e] : 0.0;
                 ZTd[e] = r2d; ZTb[e] = r2b;
@@ -943,12 +997,12 @@ struct Solver {
             sync();
             At_mul(Zd, Zb, XT);
             sync();
-            for (int e = lane; e < NS * 8; e += 64) XT[e] += -Qv[e] - VT[e] - AT[e];
+            for (int e = tid; e < NS * 8; e += kStride) XT[e] += -Qv[e] - VT[e] - AT[e];
             sync();
             kkt_solve();
             A_mul(XT, Zd, Zb);
             sync();
-            for (int e = lane; e < NS * 8; e += 64) {
+            for (int e = tid; e < NS * 8; e += kStride) {
                 DX[e] += XT[e];
                 Yd[e] += fabs(DYd[e]) * (Zd[e] - ZTd[e]);
                 Yb[e] += fabs(DYb[e]) * (Zb[e] - ZTb[e]);
@@ -958,7 +1012,7 @@ struct Solver {
         // pol_z = A px, project (z, y) on the normal cone
         A_mul(DX, Zd, Zb);
         sync();
-        for (int e = lane; e < NS * 8; e += 64) {
+        for (int e = tid; e < NS * 8; e += kStride) {
             { const double b = dyn_bound(e), t = Zd[e] + Yd[e], z = clipd(t, b, b); Zd[e] = z; Yd[e] = t - z; }
             { const double t = Zb[e] + Yb[e], z = clipd(t, Lo[e], Hi[e]); Zb[e] = z; Yb[e] = t - z; }
         }
@@ -968,7 +1022,7 @@ struct Solver {
         const bool good = (R.pri < pri_res && R.dua < dua_res) || (R.pri < pri_res && dua_res < 1e-10) ||
                           (R.dua < dua_res && pri_res < 1e-10);
         if (good) {
-            for (int e = lane; e < NS * 8; e += 64) X[e] = DX[e];
+            for (int e = tid; e < NS * 8; e += kStride) X[e] = DX[e];
             pri_res = R.pri; dua_res = R.dua; obj = pobj;
             sync();
             return 1;
@@ -977,25 +1031,25 @@ struct Solver {
     }
 };
 
-template <int NX, int NT>
-__global__ void __launch_bounds__(64) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
+template <int NX, int NT, int NW>
+__global__ void __launch_bounds__(64 * NW, NW) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
     extern __shared__ __align__(16) double smem[];
     const int inst = blockIdx.x;
     if (inst >= a.B) return;
-    Solver<NX, NT> s(*cfgp, smem);
+    Solver<NX, NT, NW> s(*cfgp, smem);
     s.run(a, inst);
 }
 
-template <int NX, int NT>
+template <int NX, int NT, int NW>
 static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream) {
-    const size_t lds = Solver<NX, NT>::lds_doubles(cfg.N) * sizeof(double);
+    const size_t lds = Solver<NX, NT, NW>::lds_doubles(cfg.N) * sizeof(double);
     static bool attr_set = false;      // per instantiation; the attribute is per function, set once
     if (!attr_set) {
-        hipError_t err = hipFuncSetAttribute((const void *)admm_solve_kernel<NX, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t err = hipFuncSetAttribute((const void *)admm_solve_kernel<NX, NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (err != hipSuccess) return err;
         attr_set = true;
     }
-    hipLaunchKernelGGL((admm_solve_kernel<NX, NT>), dim3(a.B), dim3(64), lds, stream, dcfg, a);
+    hipLaunchKernelGGL((admm_solve_kernel<NX, NT, NW>), dim3(a.B), dim3(64 * NW), lds, stream, dcfg, a);
     return hipGetLastError();
 }
 
@@ -1006,18 +1060,21 @@ int solve_has_fast_path(int kind, int N) {
 
 size_t solve_lds_bytes(int kind, int N) {
     const bool fast = solve_has_fast_path(kind, N) != 0;
-    return ((size_t)(N + 1) * ((fast ? 1 : 3) * kTS + 19 * 8 + 8) + 16 + 64 + 8 + 64) * sizeof(double);
+    return ((size_t)(N + 1) * ((fast ? 1 : 3) * kTS + 19 * 8 + 8) + 16 + 64 + 8 + 64 + 64) * sizeof(double);
 }
 
-hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream, int force_generic) {
+// kernel_variant: 0 = best available, 1 = run-time-horizon kernel (factor tiles in LDS), 2 = compile-time horizon
+// with one wavefront per instance (where instantiated)
+hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream, int kernel_variant) {
+    const bool generic = kernel_variant == 1, one_wave = kernel_variant == 2;
     if (cfg.kind == 0) {
-        if (!force_generic && cfg.N == 20) return launch_one<6, 20>(cfg, dcfg, a, stream);
-        if (!force_generic && cfg.N == 10) return launch_one<6, 10>(cfg, dcfg, a, stream);
-        return launch_one<6, 0>(cfg, dcfg, a, stream);
+        if (!generic && cfg.N == 20) return one_wave ? launch_one<6, 20, 1>(cfg, dcfg, a, stream) : launch_one<6, 20, 2>(cfg, dcfg, a, stream);
+        if (!generic && cfg.N == 10) return launch_one<6, 10, 1>(cfg, dcfg, a, stream);
+        return launch_one<6, 0, 1>(cfg, dcfg, a, stream);
     }
-    if (!force_generic && cfg.N == 30) return launch_one<5, 30>(cfg, dcfg, a, stream);
-    if (!force_generic && cfg.N == 40) return launch_one<5, 40>(cfg, dcfg, a, stream);
-    return launch_one<5, 0>(cfg, dcfg, a, stream);
+    if (!generic && cfg.N == 30) return one_wave ? launch_one<5, 30, 1>(cfg, dcfg, a, stream) : launch_one<5, 30, 2>(cfg, dcfg, a, stream);
+    if (!generic && cfg.N == 40) return launch_one<5, 40, 2>(cfg, dcfg, a, stream);
+    return launch_one<5, 0, 1>(cfg, dcfg, a, stream);
 }
 
 }  // namespace lpvmpc

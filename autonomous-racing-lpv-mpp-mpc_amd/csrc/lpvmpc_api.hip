@@ -176,7 +176,8 @@ extern "C" const char *lpvmpc_last_error(const lpvmpc_handle *h) { return h ? h-
 
 extern "C" int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value) {
     if (!h || !name) return fail(h, LPVMPC_E_ARG, "lpvmpc_set_option: bad arguments");
-    if (std::strcmp(name, "force_generic_kernel") == 0) { h->force_generic = value != 0; return LPVMPC_OK; }
+    if (std::strcmp(name, "force_generic_kernel") == 0) { h->force_generic = value != 0 ? 1 : 0; return LPVMPC_OK; }
+    if (std::strcmp(name, "kernel_variant") == 0) { if (value < 0 || value > 2) return fail(h, LPVMPC_E_ARG, "kernel_variant must be 0, 1 or 2"); h->force_generic = value; return LPVMPC_OK; }
     return fail(h, LPVMPC_E_ARG, "lpvmpc_set_option: unknown option '%s'", name);
 }
 

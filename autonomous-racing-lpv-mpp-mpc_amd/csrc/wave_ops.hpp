@@ -1,0 +1,144 @@
+// wave_ops.hpp -- cross-lane primitives shared by the solve kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lpvmpc_device.hpp"
+
+namespace lpvmpc {
+
+// ---- cross-lane primitives (CDNA4) ------------------------------------------------------------
+// A tile element [i][j] lives in lane 8*i+j.  Summing over j stays inside an 8-lane group: two quad
+// permutes and a half-row mirror, all DPP modifiers on v_mov (a 64-bit value moves as two dwords).
+// Summing over i crosses 16-lane DPP rows: row_ror:8 for lane^8, then v_permlane16_swap /
+// v_permlane32_swap (gfx950) for lane^16 / lane^32.  -DLPVMPC_USE_SHFL selects plain ds_bpermute
+// shuffles instead (validation only).
+template <int CTRL>
+__device__ inline double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    // every lane has a valid source under these controls; bound_ctrl lets the destination start undefined
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double xor16_sum(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ inline double xor32_sum(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+// all-reduce over the column index j (lane bits 0..2) / the row index i (lane bits 3..5) of a tile
+__device__ inline double red_j(double v) {
+#ifdef LPVMPC_USE_SHFL
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+#else
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror (quads are uniform by now)
+#endif
+    return v;
+}
+__device__ inline double red_i(double v) {
+#ifdef LPVMPC_USE_SHFL
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+#else
+    v += dpp_mov<0x128>(v);   // row_ror:8  == lane ^ 8
+    v = xor16_sum(v);
+    v = xor32_sum(v);
+#endif
+    return v;
+}
+// whole-wavefront all-reduces (sum / max): 8-lane group, row_ror:8, then the two row-crossing swaps
+__device__ inline void xor16_pair(double v, double &x, double &y) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    x = __hiloint2double(b[0], a[0]); y = __hiloint2double(b[1], a[1]);
+}
+__device__ inline void xor32_pair(double v, double &x, double &y) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    x = __hiloint2double(b[0], a[0]); y = __hiloint2double(b[1], a[1]);
+}
+__device__ inline double wave_sum(double v) {
+#ifdef LPVMPC_USE_SHFL
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+#else
+    return red_i(red_j(v));
+#endif
+}
+__device__ inline double wave_max(double v) {
+#ifdef LPVMPC_USE_SHFL
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
+#else
+    v = fmax(v, dpp_mov<0xB1>(v)); v = fmax(v, dpp_mov<0x4E>(v)); v = fmax(v, dpp_mov<0x141>(v));
+    v = fmax(v, dpp_mov<0x128>(v));
+    double x, y;
+    xor16_pair(v, x, y); v = fmax(x, y);
+    xor32_pair(v, x, y); v = fmax(x, y);
+    return v;
+#endif
+}
+// value of lane SRC in every lane (uniform source lane): two v_readlane
+template <int SRC>
+__device__ inline double bcast_lane(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC), hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
+    return __hiloint2double(hi, lo);
+}
+// tile element [i][T] in every lane (i, .): broadcast lane T of each 8-lane group, two DPP moves per dword
+template <int T>
+__device__ inline double bcast_row(double v) {
+    constexpr int q = T & 3, QP = q | (q << 2) | (q << 4) | (q << 6);
+    constexpr int BM = (T >> 2) ? 0x5 : 0xA;          // banks (quads of a row) that still hold the other quad's value
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, QP, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, QP, 0xF, 0xF, true);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, BM, false);     // row_half_mirror into the masked banks
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, BM, false);
+    return __hiloint2double(hi, lo);
+}
+// two independent all-reduces of the same kind, interleaved step by step (fills the DPP hazard slots
+// and the dependent-add latency of one with the other)
+__device__ inline void red_j2(double &a, double &b) {
+#ifdef LPVMPC_USE_SHFL
+    a = red_j(a); b = red_j(b);
+#else
+    double ta = dpp_mov<0xB1>(a), tb = dpp_mov<0xB1>(b); a += ta; b += tb;
+    ta = dpp_mov<0x4E>(a); tb = dpp_mov<0x4E>(b); a += ta; b += tb;
+    ta = dpp_mov<0x141>(a); tb = dpp_mov<0x141>(b); a += ta; b += tb;
+#endif
+}
+__device__ inline void red_i2(double &a, double &b) {
+#ifdef LPVMPC_USE_SHFL
+    a = red_i(a); b = red_i(b);
+#else
+    double ta = dpp_mov<0x128>(a), tb = dpp_mov<0x128>(b); a += ta; b += tb;
+    a = xor16_sum(a); b = xor16_sum(b);
+    a = xor32_sum(a); b = xor32_sum(b);
+#endif
+}
+__device__ inline double limit_scaling(double v) {
+    v = v < kMinScaling ? 1.0 : v;
+    return v > kMaxScaling ? kMaxScaling : v;
+}
+// 1/sqrt(x) to double precision: hardware estimate + two Newton steps (x in [1e-4, 1e4] here)
+__device__ inline double inv_sqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+__device__ inline double clipd(double t, double lo, double hi) { return t < lo ? lo : (t > hi ? hi : t); }
+
+
+}  // namespace lpvmpc

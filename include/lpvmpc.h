@@ -105,9 +105,10 @@ lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg);
 void lpvmpc_destroy(lpvmpc_handle *h);
 const char *lpvmpc_last_error(const lpvmpc_handle *h);
 
-/* Runtime options.  "force_generic_kernel" (0/1): solve with the run-time-horizon kernel even when a
- * specialised (compile-time horizon, register-resident factor) instantiation exists -- used by the tests
- * to cross-check the two kernels. */
+/* Runtime options.  "kernel_variant": 0 = fastest instantiation for (kind, N) (default), 1 = run-time-horizon
+ * kernel (factor tiles in LDS, any N), 2 = compile-time horizon with ONE wavefront per instance (where it
+ * exists; the default for N = 20 / 30 / 40 uses two wavefronts and a two-sided elimination).
+ * "force_generic_kernel" (0/1) is shorthand for variants 0 / 1.  Used by the tests to cross-check the kernels. */
 int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value);
 
 /* Pre-size the device workspace for batches up to B (otherwise grown on demand). */

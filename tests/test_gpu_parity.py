@@ -143,24 +143,27 @@ def test_fused_batch_cfg2_against_oracle(lpvmpc):
         assert np.max(np.abs(out["uPred"][b] - uP)) <= tol, b
 
 
-def test_specialised_and_generic_kernels_agree(lpvmpc):
-    """The compile-time-horizon kernel (factor tiles in registers) and the run-time-horizon kernel (tiles in
-    LDS) run the same arithmetic: identical iteration counts / statuses, solutions equal to round-off."""
+def test_kernel_variants_agree(lpvmpc):
+    """Three kernels run the same algorithm: variant 0 (default: compile-time horizon, two wavefronts per
+    instance, two-sided elimination), variant 2 (compile-time horizon, one wavefront) and variant 1 (run-time
+    horizon, factor tiles in LDS): identical statuses / polish flags, iteration counts equal (the factorisations
+    differ in elimination order, i.e. in round-off only), solutions equal to 1e-8."""
     from lpvmpc import workloads
     for w in (workloads.controller_batch(128, N=20, seed=5), workloads.planner_batch(64, N=30, seed=6)):
         outs = []
-        for generic in (0, 1):
+        for variant in (0, 1, 2):
             eng = workloads.make_solver(w)
-            eng.set_option("force_generic_kernel", generic)
+            eng.set_option("kernel_variant", variant)
             outs.append(eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], w["max_ey"], w["cf_new"], w["lap"]))
             eng.close()
-        a, b = outs
-        assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"])
-        assert np.array_equal(a["polish"], b["polish"])
-        ok = a["status"] > 0
-        ok &= np.all(np.isfinite(a["xPred"]).reshape(len(ok), -1), axis=1)
-        assert np.max(np.abs(a["xPred"][ok] - b["xPred"][ok])) < 1e-9
-        assert np.max(np.abs(a["uPred"][ok] - b["uPred"][ok])) < 1e-9
+        a = outs[1]
+        for b in (outs[0], outs[2]):
+            assert np.array_equal(a["status"], b["status"]), np.nonzero(a["status"] != b["status"])
+            assert np.array_equal(a["iters"], b["iters"]), (np.nonzero(a["iters"] != b["iters"]), a["iters"][a["iters"] != b["iters"]], b["iters"][a["iters"] != b["iters"]])
+            assert np.array_equal(a["polish"], b["polish"])
+            ok = np.isin(a["status"], (1, 2, -2))
+            assert np.max(np.abs(a["xPred"][ok] - b["xPred"][ok])) < 1e-8
+            assert np.max(np.abs(a["uPred"][ok] - b["uPred"][ok])) < 1e-8
 
 
 def _agree(out, ref, b, nx, tol_x):
