@@ -423,10 +423,11 @@ struct Solver {
                 // link tiles are used with the form of the last chain stage: position P-1 odd -> stored as is
                 rLt = ((kP0 - 1) & 1) ? lt : __shfl(lt, tj * 8 + ti);
                 rLb = ((kP1 - 1) & 1) ? lb : __shfl(lb, tj * 8 + ti);
-                RED[lane] = rLb;                                   // hand the lower link tile to wave 1 (already oriented)
+                RED[lane] = rLb;                                   // hand the lower link tile (already oriented) and the
+                SINK[lane] = rSm;                                  // middle pivot inverse to wave 1
             }
             sync();
-            if (wv == 1) rLb = RED[lane];
+            if (wv == 1) { rLb = RED[lane]; rSm = SINK[lane]; }
             sync();
             return;
         }
@@ -483,19 +484,19 @@ struct Solver {
                 yc = bk - ch;
             }
         }
-        // pivot product of the last chain stage, and its y handed to wave 0 for the middle stage
-        if (kLastOdd) { vcol[stage(P - 1) * 8] = red_j(rS[P - 1] * yr); if (ti == 0) RED[32 + (BOT ? 8 : 0) + tj] = yr; }
-        else          { vrow[stage(P - 1) * 8] = red_i(rS[P - 1] * yc); if (tj == 0) RED[32 + (BOT ? 8 : 0) + ti] = yc; }
-    }
-    __device__ __forceinline__ void twisted_middle() {      // wave 0 only
-        double *const xrow = (ti == 0) ? XT + tj : SINK + lane;
-        double *const xcol = (tj == 0) ? XT + ti : SINK + lane;
-        if (kLastOdd) {     // neighbours' y in row form -> y_m in column form -> x_m in row form
-            const double ym = XT[kMid * 8 + ti] - red_j(rLt * RED[32 + tj] + rLb * RED[40 + tj]);
-            xrow[kMid * 8] = red_i(rSm * ym);
+        // pivot product of the last chain stage, and this chain's contribution L_link y_last to the middle
+        // right-hand side (published for the other wave; both waves then finish the middle stage redundantly)
+        const double link = BOT ? rLb : rLt;
+        if (kLastOdd) {     // y_last in row form -> contribution in column form
+            double pv = rS[P - 1] * yr, cb = link * yr;
+            red_j2(cb, pv);
+            vcol[stage(P - 1) * 8] = pv;
+            if (tj == 0) RED[32 + (BOT ? 8 : 0) + ti] = cb;
         } else {
-            const double ym = XT[kMid * 8 + tj] - red_i(rLt * RED[32 + ti] + rLb * RED[40 + ti]);
-            xcol[kMid * 8] = red_j(rSm * ym);
+            double pv = rS[P - 1] * yc, cb = link * yc;
+            red_i2(cb, pv);
+            vrow[stage(P - 1) * 8] = pv;
+            if (ti == 0) RED[32 + (BOT ? 8 : 0) + tj] = cb;
         }
     }
     template <bool BOT>
@@ -506,9 +507,21 @@ struct Solver {
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         const double link = BOT ? rLb : rLt;
         double xc = 0.0, xr = 0.0;
-        // first step: x_{P-1} = v_{P-1} - L_link' x_m
-        if (kLastOdd) { xr = VT[stage(P - 1) * 8 + tj] - red_i(link * XT[kMid * 8 + ti]); xrow[stage(P - 1) * 8] = xr; }
-        else          { xc = VT[stage(P - 1) * 8 + ti] - red_j(link * XT[kMid * 8 + tj]); xcol[stage(P - 1) * 8] = xc; }
+        // middle stage, computed by both waves: y_m = b_m - (L_t y_{m-1}) - (L_b y_{m+1}),  x_m = S_m^-1 y_m
+        // first chain step: x_{P-1} = v_{P-1} - L_link' x_m
+        if (kLastOdd) {     // contributions / y_m in column form -> x_m in row form -> (via the register transpose) column form
+            const double ym = XT[kMid * 8 + ti] - (RED[32 + ti] + RED[40 + ti]);
+            const double xm_row = red_i(rSm * ym);                          // x_m[tj]
+            if (!BOT) xrow[kMid * 8] = xm_row;
+            const double xm_col = __shfl(xm_row, ti);                       // lane (0, ti) holds x_m[ti]
+            xr = VT[stage(P - 1) * 8 + tj] - red_i(link * xm_col); xrow[stage(P - 1) * 8] = xr;
+        } else {
+            const double ym = XT[kMid * 8 + tj] - (RED[32 + tj] + RED[40 + tj]);
+            const double xm_col = red_j(rSm * ym);                          // x_m[ti]
+            if (!BOT) xcol[kMid * 8] = xm_col;
+            const double xm_row = __shfl(xm_col, tj * 8);                   // lane (tj, 0) holds x_m[tj]
+            xc = VT[stage(P - 1) * 8 + ti] - red_j(link * xm_row); xcol[stage(P - 1) * 8] = xc;
+        }
         double vq[3];
         if (P >= 2) vq[(P - 2) % 3] = ((P - 2) & 1) ? VT[stage(P - 2) * 8 + tj] : VT[stage(P - 2) * 8 + ti];
         if (P >= 3) vq[(P - 3) % 3] = ((P - 3) & 1) ? VT[stage(P - 3) * 8 + tj] : VT[stage(P - 3) * 8 + ti];
@@ -526,8 +539,6 @@ struct Solver {
             if (wv == 0) twisted_forward<false>(); else twisted_forward<true>();
             sync();
             STAMP(1);
-            if (wv == 0) twisted_middle();
-            sync();
             if (wv == 0) twisted_backward<false>(); else twisted_backward<true>();
             sync();
             STAMP(2);
