@@ -42,10 +42,10 @@ def algorithmic_bytes(iters, N=HORIZON, nx=6, nu=2, w=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU (default: configs[1] = 1024)")
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=16,
                     help="HIP streams the K steps are issued on round-robin (independent batches overlap, so the few "
                          "slow instances of one batch do not leave the GPU idle); 1 = strictly back-to-back steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,6 +181,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "admm_solve_kernel<6>", "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
                          "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_admm_iteration": bytes_iter,
+                         "aggregate_algorithmic_GBps": bytes_launch * args.steps * world / elapsed / 1e9,
                          "note": "algorithmic bytes per SURVEY 8(d) (factor + vectors streamed once per ADMM "
                                  "iteration); the kernel keeps them in LDS/registers, so real HBM traffic is far lower. "
                                  "With --streams > 1 launches overlap, so the per-launch duration includes time "

@@ -218,3 +218,34 @@ def test_mixed_cfg4_controller_and_planner_n20(lpvmpc):
     for b in range(n):
         _agree(oc, rc, b, 6, 1e-6)
         _agree(op, rp, b, 5, 1e-5)
+
+
+@pytest.mark.parametrize("N", [8, 12])
+def test_runtime_horizon_kernel_other_N(lpvmpc, N):
+    """Horizons without a specialised instantiation (the reference launch file uses N = 8 for the controller,
+    MAIN_LAUNCH.launch:117) run the run-time-horizon kernel; checked against the C oracle tick."""
+    from lpvmpc import workloads
+    w = workloads.controller_batch(96, N=N, seed=11)
+    eng = workloads.make_solver(w)
+    out = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"])
+    eng.close()
+    ref = O.ctrl_tick_batch(w, nthreads=8)
+    for b in range(96):
+        _agree(out, ref, b, 6, 1e-6)
+
+
+def test_bad_arguments_fail_cleanly(lpvmpc):
+    from lpvmpc import workloads
+    w = workloads.controller_batch(4, N=20, seed=0)
+    with pytest.raises(lpvmpc.LpvMpcError):
+        lpvmpc.BatchedSolver("controller", 4, w["dt"], w["Q"], w["R"], w["dR"], track=w["track"])          # N too small
+    with pytest.raises(lpvmpc.LpvMpcError):
+        lpvmpc.BatchedSolver("controller", 20, w["dt"], w["Q"], w["R"], w["dR"], track=w["track"], rho=-1.0)
+    eng = lpvmpc.BatchedSolver("controller", 20, w["dt"], w["Q"], w["R"], w["dR"])                            # no track table
+    with pytest.raises(lpvmpc.LpvMpcError):
+        eng.solve(w["x0"], w["u_prev"], w["vel_ref"], None, w["u_old"], None, 60.0, 0)                        # lap 0 needs the map
+    with pytest.raises(ValueError):
+        eng.solve(w["x0"], w["u_prev"][:, :5], w["vel_ref"], w["curv_s"], w["u_old"])                        # wrong shape
+    out = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, 60.0, 1)              # lap >= 1 works without a map
+    assert np.all(out["status"] == 1)
+    eng.close()
