@@ -26,11 +26,11 @@ BATCH = 1024              # instances per GPU (configs[1])
 HORIZON = 20
 
 
-def algorithmic_bytes(iters, N=HORIZON, nx=6, nu=2, w=8):
+def algorithmic_bytes(iters, N=HORIZON, nx=6, nu=2, w=8, m_rows=None):
     """bytes_iter = w (F + 3 n_z + 4 m); per solve add w (2F + N(nx^2+nx nu) + in + out)."""
     nb = nx + nu
     n_z = (N + 1) * nx + N * nu
-    m = (N + 1) * nx + 6 * N                      # controller: 126 equality + 120 inequality rows
+    m = m_rows if m_rows is not None else (N + 1) * nx + 6 * N    # controller: 126 equality + 120 inequality rows
     F = (N + 1) * (nb * (nb + 1) // 2 + nb * nb)
     bytes_iter = w * (F + 3 * n_z + 4 * m)
     n_in = nx + N * nu + 2 * (N + 1) + nu
@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--streams", type=int, default=16,
                     help="HIP streams the K steps are issued on round-robin (independent batches overlap, so the few "
                          "slow instances of one batch do not leave the GPU idle); 1 = strictly back-to-back steps")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
+                    help="cfg2 = configs[1] (the headline, default); cfg3 = configs[2]: planner LPV-MPP, N=30, L-shape "
+                         "(use --batch 4096) -- extra measurement, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -70,12 +73,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    B, N = args.batch, HORIZON
-    w = workloads.controller_batch(B, N=N, seed=1000 * rank)      # rank 0 == seed 0 of SURVEY section 8d
+    planner = args.workload == "cfg3"
+    B, N = args.batch, (30 if planner else HORIZON)
+    nx = 5 if planner else 6
+    if planner:
+        w = workloads.planner_batch(B, N=N, seed=1 + 1000 * rank)
+    else:
+        w = workloads.controller_batch(B, N=N, seed=1000 * rank)  # rank 0 == seed 0 of SURVEY section 8d
     eng = workloads.make_solver(w, device=local_rank)
     eng.reserve(B)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    x0, u_prev, vel_ref, curv, u_old = t(w["x0"]), t(w["u_prev"]), t(w["vel_ref"]), t(w["curv_s"]), t(w["u_old"])
+    x0, u_prev, curv, u_old = t(w["x0"]), t(w["u_prev"]), t(w["curv_s"]), t(w["u_old"])
+    vel_ref = None if planner else t(w["vel_ref"])
+    max_ey = t(w["max_ey"]) if planner else None
     # one engine (workspace + output buffers) per stream: steps issued on different streams are independent
     S = max(1, args.streams)
     engines = [eng] + [workloads.make_solver(w, device=local_rank) for _ in range(S - 1)]
@@ -83,7 +93,7 @@ def main():
     outs = []
     for e in engines:
         e.reserve(B)
-        outs.append(dict(xPred=torch.empty((B, N + 1, 6), dtype=torch.float64, device=dev),
+        outs.append(dict(xPred=torch.empty((B, N + 1, nx), dtype=torch.float64, device=dev),
                          uPred=torch.empty((B, N, 2), dtype=torch.float64, device=dev),
                          status=torch.empty(B, dtype=torch.int32, device=dev),
                          iters=torch.empty(B, dtype=torch.int32, device=dev),
@@ -96,7 +106,7 @@ def main():
         i = counter[0] % S
         counter[0] += 1
         o = outs[i]
-        engines[i].solve_dev(B, x0, u_prev, vel_ref, curv, u_old, None, o["xPred"], o["uPred"], o["status"], o["iters"],
+        engines[i].solve_dev(B, x0, u_prev, vel_ref, curv, u_old, max_ey, o["xPred"], o["uPred"], o["status"], o["iters"],
                              o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"], stream=streams[i].cuda_stream)
 
     def fence():
@@ -146,18 +156,18 @@ def main():
 
     if rank == 0:
         total = B * world * args.steps
-        bytes_launch, bytes_iter = algorithmic_bytes(it_host)
+        bytes_launch, bytes_iter = algorithmic_bytes(it_host, N=N, nx=nx, m_rows=((N + 1) * nx + (N + 1) * nx + N * 2) if planner else None)
         k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
         achieved = bytes_launch / k_avg_s / 1e9 if k_n else float("nan")
         traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside bench.py)
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pm.get("batch") == B:
+            if pm.get("batch") == B and not planner:
                 traffic = pm["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
         out = {
-            "metric": "MPC solves/sec (N=20, nx=6, nu=2)",
+            "metric": "MPC solves/sec (N=20, nx=6, nu=2)" if not planner else "LPV-MPP planner solves/sec (N=30, nx=5, nu=2)",
             "value": total / elapsed,
             "unit": "solves/s",
             "n_gpus": world,
@@ -169,9 +179,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: batch=%d LPV-MPC controller solves per GPU, N=20, random x0 along "
-                                   "oval, racing tuning, OSQP defaults + polish, cold start" % B,
-                       "batch_per_gpu": B, "horizon": N, "nx": 6, "nu": 2,
+            "config": {"workload": ("configs[1]: batch=%d LPV-MPC controller solves per GPU, N=20, random x0 along "
+                                    "oval, racing tuning, OSQP defaults + polish, cold start" % B) if not planner else
+                                   ("configs[2]: batch=%d LPV-MPP planner solves per GPU (velocity-max cost), N=30, "
+                                    "L-shape track, OSQP defaults + polish, cold start" % B),
+                       "batch_per_gpu": B, "horizon": N, "nx": nx, "nu": 2,
                        "mean_admm_iters": agg[0] / (B * world),
                        "max_admm_iters_rank0": int(it_host.max()),
                        "solved_fraction": agg[1] / (B * world),
@@ -179,7 +191,7 @@ def main():
                        "single_stream_solves_per_s_per_gpu": serial_rate},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "admm_solve_kernel<6>", "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
+                         "kernel": "admm_solve_kernel<%d, %d, 2>" % (nx, N), "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
                          "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_admm_iteration": bytes_iter,
                          "aggregate_algorithmic_GBps": bytes_launch * args.steps * world / elapsed / 1e9,
                          "note": "algorithmic bytes per SURVEY 8(d) (factor + vectors streamed once per ADMM "
@@ -188,7 +200,7 @@ def main():
                                  "spent sharing the GPU with the neighbouring batches"},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w)
+            out["cpu_baseline"] = cpu_baseline(w, planner=planner)
         print(json.dumps(out), flush=True)
 
     for e in engines:
@@ -197,22 +209,35 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(w, target_s=15.0):
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(w, target_s=15.0, planner=False):
     """The CPU oracle port (same tick: LPV roll-out + sparse assembly + OSQP restatement, float64) on a
     bounded sample of the same workload, on all host cores (OpenMP over instances)."""
     import numpy as np
     from oracle import osqp_ref
-    cores = os.cpu_count() or 1
+    tick = osqp_ref.plan_tick_batch if planner else osqp_ref.ctrl_tick_batch
+    cores = usable_cores()
     sub = lambda n: {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == w["x0"].shape[0] and k != "track" else v)
                      for k, v in w.items()}
-    osqp_ref.ctrl_tick_batch(sub(8), nthreads=cores)                    # warm the thread pool / page in
-    t0 = time.perf_counter(); osqp_ref.ctrl_tick_batch(sub(64), nthreads=cores); t64 = time.perf_counter() - t0
+    tick(sub(8), nthreads=cores)                    # warm the thread pool / page in
+    t0 = time.perf_counter(); tick(sub(64), nthreads=cores); t64 = time.perf_counter() - t0
     n = int(min(w["x0"].shape[0], max(64, 64 * target_s / max(t64, 1e-6))))
     reps, done, t_all = 0, 0, 0.0
     while t_all < target_s and reps < 50:
-        t0 = time.perf_counter(); osqp_ref.ctrl_tick_batch(sub(n), nthreads=cores); t_all += time.perf_counter() - t0
+        t0 = time.perf_counter(); tick(sub(n), nthreads=cores); t_all += time.perf_counter() - t0
         done += n; reps += 1
-    t1 = time.perf_counter(); osqp_ref.ctrl_tick_batch(sub(64), nthreads=1); t_single = time.perf_counter() - t1
+    t1 = time.perf_counter(); tick(sub(64), nthreads=1); t_single = time.perf_counter() - t1
     return {"value": done / t_all, "unit": "solves/s", "cores": cores, "kind": "port",
             "sample": "%d x the first %d instances of the same batch (oracle/lpv_ref.c + oracle/osqp_ref.c, OpenMP over "
                       "instances, %.1f s)" % (reps, n, t_all),
