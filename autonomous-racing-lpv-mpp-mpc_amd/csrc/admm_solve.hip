@@ -792,6 +792,30 @@ struct Solver {
         sync();
     }
 
+    // ---- opt-in warm start (the reference always cold-starts, quirk Q8) ---------------
+    // As osqp_warm_start: x <- D^-1 x_prev, y <- c E^-1 y_prev, z <- A x; with shift, stage k takes the
+    // previous solution's stage k+1 (the last stage that exists for that row / variable is kept).
+    __device__ __forceinline__ void warm_start(const double *st, bool shift) {
+        const double *sx = st, *syd = st + NS * 8, *syb = st + 2 * NS * 8;
+        for (int e = tid; e < NS * 8; e += kStride) {
+            const int k = e >> 3, r = e & 7;
+            const int kx = shift ? (r < NX ? (k < N ? k + 1 : N) : (k < N - 1 ? k + 1 : (k < N ? N - 1 : k))) : k;
+            const int kd = shift ? (k < N ? k + 1 : N) : k;
+            const bool brow_to_N = !kCtrl && r < NX;                       // planner state-box rows exist up to stage N
+            const int kb = shift ? (brow_to_N ? (k < N ? k + 1 : N) : (k < N - 1 ? k + 1 : (k < N ? N - 1 : k))) : k;
+            X[e] = (r < nvar(k)) ? sx[kx * 8 + r] / D[e] : 0.0;
+            Yd[e] = (r < NX) ? c * syd[kd * 8 + r] / Ed[e] : 0.0;
+            Yb[e] = (r < nbox(k)) ? c * syb[kb * 8 + r] / Eb[e] : 0.0;
+        }
+        sync();
+        A_mul(X, Zd, Zb);
+        sync();
+    }
+    __device__ __forceinline__ void save_duals(double *st) const {
+        double *syd = st + NS * 8, *syb = st + 2 * NS * 8;
+        for (int e = tid; e < NS * 8; e += kStride) { syd[e] = cinv * Ed[e] * Yd[e]; syb[e] = cinv * Eb[e] * Yb[e]; }
+    }
+
     // ---- the whole solve --------------------------------------------------------------------------
     __device__ __forceinline__ void run(const SolveArgs &a, int inst) {
         // ---------- load + build the unscaled problem ----------
@@ -847,6 +871,7 @@ struct Solver {
         cache_row_coefficients();
         set_rho(fmin(fmax(cfg.rho, kRhoMin), kRhoMax));
         factor(cfg.sigma);
+        if (a.warm && a.state) warm_start(a.state + (size_t)inst * 3 * NS * 8, a.warm == 2);
         recompute_w();                      // cold start: x = z = y = 0
 
         // ---------- ADMM ----------
@@ -891,8 +916,13 @@ struct Solver {
         if (status == LPVMPC_DUAL_INFEASIBLE_ || status == LPVMPC_DUAL_INFEASIBLE_INACC_) obj = -kInfty;
 
         const double rho_admm = rho;
+        double *const st_out = a.state ? a.state + (size_t)inst * 3 * NS * 8 : nullptr;
+        if (st_out) save_duals(st_out);        // ADMM duals (the polish below reuses the y arrays)
         // ---------- polish ----------
-        if (cfg.polish && status == LPVMPC_SOLVED_) status_polish = polish(pri_res, dua_res, obj);
+        if (cfg.polish && status == LPVMPC_SOLVED_) {
+            status_polish = polish(pri_res, dua_res, obj);
+            if (st_out && status_polish == 1) save_duals(st_out);
+        }
 
         // ---------- write back (store_solution) ----------
         // store_solution: decided on the FINAL status (the approximate check above may have turned an
@@ -906,6 +936,10 @@ struct Solver {
             const double v = sol ? D[e] * X[e] : nan;
             if (r < NX) a.xPred[((size_t)inst * NS + k) * NX + r] = v;
             else if (r < NB && k < N) a.uPred[((size_t)inst * N + k) * 2 + (r - NX)] = v;
+            if (st_out) st_out[e] = sol ? v : 0.0;
+        }
+        if (st_out && !sol) {      // no solution: do not seed the next solve with garbage
+            for (int e = tid; e < NS * 8; e += kStride) { st_out[NS * 8 + e] = 0.0; st_out[2 * NS * 8 + e] = 0.0; }
         }
 #ifdef LPVMPC_STAMPS
         if (tid == 0 && a.resid) {     // diagnostic build: resid carries per-iteration cycle counts instead

@@ -28,6 +28,8 @@ struct lpvmpc_handle {
     // device workspace
     double *d_x0, *d_uprev, *d_vel, *d_curv, *d_uold, *d_maxey, *d_AB, *d_states, *d_xPred, *d_uPred, *d_resid;
     double *d_xlast, *d_delta;
+    double *d_state;         // warm-start state [cap][3][8(N+1)] (opt-in)
+    int warm_mode, state_valid_B;   // 0 off (default); instances whose state is valid from the previous solve
     int32_t *d_status, *d_iters, *d_polish;
     hipStream_t stream;
     std::vector<hipEvent_t> ev0, ev1;   // ring of event pairs around the solve-kernel launches
@@ -87,11 +89,11 @@ extern "C" void lpvmpc_default_config(int32_t kind, lpvmpc_config *c) {
 
 static void free_ws(lpvmpc_handle *h) {
     void *ptrs[] = {h->d_x0, h->d_uprev, h->d_vel, h->d_curv, h->d_uold, h->d_maxey, h->d_AB, h->d_states,
-                    h->d_xPred, h->d_uPred, h->d_resid, h->d_xlast, h->d_delta, h->d_status, h->d_iters, h->d_polish};
+                    h->d_xPred, h->d_uPred, h->d_resid, h->d_xlast, h->d_delta, h->d_status, h->d_iters, h->d_polish, h->d_state};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     h->d_x0 = h->d_uprev = h->d_vel = h->d_curv = h->d_uold = h->d_maxey = h->d_AB = h->d_states = nullptr;
     h->d_xPred = h->d_uPred = h->d_resid = h->d_xlast = h->d_delta = nullptr;
-    h->d_status = h->d_iters = h->d_polish = nullptr;
+    h->d_status = h->d_iters = h->d_polish = nullptr; h->d_state = nullptr; h->state_valid_B = 0;
     h->cap = 0;
 }
 
@@ -106,6 +108,7 @@ static int ensure_ws(lpvmpc_handle *h, int B) {
     ALLOC(h->d_AB, b * N * nx * nb * 8); ALLOC(h->d_states, b * N * nx * 8);
     ALLOC(h->d_xPred, b * (N + 1) * nx * 8); ALLOC(h->d_uPred, b * N * 2 * 8); ALLOC(h->d_resid, b * 4 * 8);
     ALLOC(h->d_xlast, b * N * 6 * 8); ALLOC(h->d_delta, b * N * 8);
+    ALLOC(h->d_state, b * 3 * (N + 1) * 8 * 8);
     ALLOC(h->d_status, b * 4); ALLOC(h->d_iters, b * 4); ALLOC(h->d_polish, b * 4);
 #undef ALLOC
     h->cap = B;
@@ -129,7 +132,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->d_cfg = nullptr; h->cap = 0; h->force_generic = 0; h->timing = false; h->last_ms = -1.0; h->stream = nullptr; h->ev_count = 0;
     h->d_x0 = h->d_uprev = h->d_vel = h->d_curv = h->d_uold = h->d_maxey = h->d_AB = h->d_states = nullptr;
     h->d_xPred = h->d_uPred = h->d_resid = h->d_xlast = h->d_delta = nullptr;
-    h->d_status = h->d_iters = h->d_polish = nullptr;
+    h->d_status = h->d_iters = h->d_polish = nullptr; h->d_state = nullptr; h->warm_mode = 0; h->state_valid_B = 0;
     DevCfg &d = h->dev;
     std::memset(&d, 0, sizeof(d));
     d.kind = cfg->kind; d.N = cfg->N; d.track_rows = cfg->track_rows; d.max_iter = cfg->max_iter;
@@ -177,6 +180,10 @@ extern "C" const char *lpvmpc_last_error(const lpvmpc_handle *h) { return h ? h-
 extern "C" int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value) {
     if (!h || !name) return fail(h, LPVMPC_E_ARG, "lpvmpc_set_option: bad arguments");
     if (std::strcmp(name, "force_generic_kernel") == 0) { h->force_generic = value != 0 ? 1 : 0; return LPVMPC_OK; }
+    if (std::strcmp(name, "warm_start") == 0) {
+        if (value < 0 || value > 2) return fail(h, LPVMPC_E_ARG, "warm_start must be 0 (off), 1 (previous solution) or 2 (shifted by one stage)");
+        h->warm_mode = value; h->state_valid_B = 0; return LPVMPC_OK;
+    }
     if (std::strcmp(name, "kernel_variant") == 0) { if (value < 0 || value > 2) return fail(h, LPVMPC_E_ARG, "kernel_variant must be 0, 1 or 2"); h->force_generic = value; return LPVMPC_OK; }
     return fail(h, LPVMPC_E_ARG, "lpvmpc_set_option: unknown option '%s'", name);
 }
@@ -337,8 +344,10 @@ extern "C" int lpvmpc_solve_batch_AB(lpvmpc_handle *h, int32_t B, const double *
     if (u_old) H2D(h->d_uold, u_old, b * 2 * 8);
     if (!ctrl) H2D(h->d_maxey, max_ey, b * 8);
     SolveArgs a{B, h->d_x0, h->d_AB, ctrl ? h->d_vel : nullptr, u_old ? h->d_uold : nullptr, ctrl ? nullptr : h->d_maxey,
-                h->d_xPred, h->d_uPred, h->d_status, h->d_iters, h->d_polish, h->d_resid};
+                h->d_xPred, h->d_uPred, h->d_status, h->d_iters, h->d_polish, h->d_resid,
+                h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0};
     rc = launch_solve_timed(h, a, st); if (rc) return rc;
+    if (h->warm_mode) h->state_valid_B = B;
     return copy_out(h, B, xPred, uPred, status, iters, resid, polish, st);
 }
 
@@ -355,8 +364,11 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
     if ((ctrl && lap == 0) || !ctrl) { rc = need_track(h, "lpvmpc_solve_batch_dev"); if (rc) return rc; }
     hipStream_t st = (hipStream_t)stream;
     rc = launch_lpv(h, B, x0, u_prev, vel_ref, curv_s, cf_new, lap, nullptr, h->d_AB, st); if (rc) return rc;
-    SolveArgs a{B, x0, h->d_AB, ctrl ? vel_ref : nullptr, u_old, ctrl ? nullptr : max_ey, xPred, uPred, status, iters, polish, resid};
-    return launch_solve_timed(h, a, st);
+    SolveArgs a{B, x0, h->d_AB, ctrl ? vel_ref : nullptr, u_old, ctrl ? nullptr : max_ey, xPred, uPred, status, iters, polish, resid,
+                h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0};
+    rc = launch_solve_timed(h, a, st); if (rc) return rc;
+    if (h->warm_mode) h->state_valid_B = B;
+    return LPVMPC_OK;
 }
 
 extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0, const double *u_prev,

@@ -50,6 +50,8 @@ struct SolveArgs {
     double *uPred;          // [B][N][2]
     int32_t *status, *iters, *polish;
     double *resid;          // [B][4]
+    double *state;          // [B][3][8(N+1)] unscaled x, y(dynamics rows), y(box rows) of the previous solve, or null
+    int warm;               // 0 cold start (reference behaviour), 1 warm start from state, 2 same shifted by one stage
 };
 
 // host-side launchers (defined next to their kernels)

@@ -108,7 +108,10 @@ const char *lpvmpc_last_error(const lpvmpc_handle *h);
 /* Runtime options.  "kernel_variant": 0 = fastest instantiation for (kind, N) (default), 1 = run-time-horizon
  * kernel (factor tiles in LDS, any N), 2 = compile-time horizon with ONE wavefront per instance (where it
  * exists; the default for N = 20 / 30 / 40 uses two wavefronts and a two-sided elimination).
- * "force_generic_kernel" (0/1) is shorthand for variants 0 / 1.  Used by the tests to cross-check the kernels. */
+ * "force_generic_kernel" (0/1) is shorthand for variants 0 / 1.  Used by the tests to cross-check the kernels.
+ * "warm_start": 0 = every solve starts from x = z = y = 0 like the reference (fresh OSQP object per call,
+ * CTRL:302,316 / PLAN:204-208; default); 1 = start from the previous solve's (x, y) of the same handle and
+ * batch size; 2 = the same shifted by one stage (receding horizon).  Opt-in, changes iteration counts, not optima. */
 int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value);
 
 /* Pre-size the device workspace for batches up to B (otherwise grown on demand). */

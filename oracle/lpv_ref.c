@@ -29,9 +29,10 @@ typedef struct {
     double obj_val, pri_res, dua_res, rho_estimate, rho_final;
 } osqp_ref_info;
 void osqp_ref_default_settings(osqp_ref_settings *s);
-int osqp_ref_solve(int n, int m, const int *Pp, const int *Pi, const double *Px, const double *q, const int *Ap,
-                   const int *Ai, const double *Ax, const double *l, const double *u, const int *perm,
-                   const osqp_ref_settings *settings, double *x_out, double *y_out, osqp_ref_info *info_out);
+int osqp_ref_solve_ws(int n, int m, const int *Pp, const int *Pi, const double *Px, const double *q, const int *Ap,
+                      const int *Ai, const double *Ax, const double *l, const double *u, const int *perm,
+                      const osqp_ref_settings *settings, const double *x_ws, const double *y_ws, double *x_out,
+                      double *y_out, osqp_ref_info *info_out);
 
 static double curvature(const double *tab, int rows, double s) {   /* UTIL:31-50 */
     const double L = tab[(rows - 1) * 6 + 3] + tab[(rows - 1) * 6 + 4];
@@ -73,7 +74,10 @@ int oracle_ctrl_tick_batch(int B, int N, double dt, const double *params, const 
                            const double *dR, const double *track, int track_rows, const double *x0,
                            const double *u_prev, const double *vel_ref, const double *curv_ref, const double *u_old,
                            double cf_new, int lap, double *xPred, double *uPred, int *status, int *iters,
-                           int nthreads) {
+                           int nthreads, const double *z_ws, const double *y_ws, int shift, double *z_sol, double *y_sol) {
+    /* z_ws [B][nz] / y_ws [B][m] (optional): previous solution in the reference's variable / row order, used as a
+     * warm start, shifted by one stage when shift != 0 (stage k takes stage k+1, the last stage is kept).
+     * z_sol / y_sol (optional) receive this tick's primal / dual solution in the same orders. */
     const int nx = 6, nu = 2, nz = (N + 1) * nx + N * nu, mi = 6 * N, me = (N + 1) * nx, m = mi + me;
     const double max_vel = params[7];
 #ifdef _OPENMP
@@ -102,6 +106,7 @@ int oracle_ctrl_tick_batch(int B, int N, double dt, const double *params, const 
         double *Ax = (double *)malloc(sizeof(double) * (nz * 10));
         double *l = (double *)malloc(sizeof(double) * m), *u = (double *)malloc(sizeof(double) * m);
         double *xo = (double *)malloc(sizeof(double) * nz), *yo = (double *)malloc(sizeof(double) * m);
+        double *xw = (double *)malloc(sizeof(double) * nz), *yw = (double *)malloc(sizeof(double) * m);
 #pragma omp for schedule(dynamic, 4)
         for (int b = 0; b < B; b++) {
             /* ---- LPV roll-out ---- */
@@ -158,13 +163,27 @@ int oracle_ctrl_tick_batch(int B, int N, double dt, const double *params, const 
             }
             for (int r = 0; r < me; r++) l[mi + r] = u[mi + r] = (r < nx) ? x0[(size_t)b * 6 + r] : 0.0;
             osqp_ref_info info;
-            osqp_ref_solve(nz, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, perm, &st, xo, yo, &info);
+            const double *xws = 0, *yws = 0;
+            if (z_ws && y_ws) {
+                const double *zp = z_ws + (size_t)b * nz, *yp = y_ws + (size_t)b * m;
+                for (int k = 0; k <= N; k++) { const int ks = shift ? (k < N ? k + 1 : N) : k;
+                    for (int a = 0; a < nx; a++) { xw[k * nx + a] = zp[ks * nx + a]; yw[mi + k * nx + a] = yp[mi + ks * nx + a]; } }
+                for (int k = 0; k < N; k++) { const int ks = shift ? (k < N - 1 ? k + 1 : N - 1) : k;
+                    for (int j = 0; j < nu; j++) xw[(N + 1) * nx + k * nu + j] = zp[(N + 1) * nx + ks * nu + j];
+                    yw[2 * k] = yp[2 * ks]; yw[2 * k + 1] = yp[2 * ks + 1];
+                    for (int t2 = 0; t2 < 4; t2++) yw[2 * N + 4 * k + t2] = yp[2 * N + 4 * ks + t2]; }
+                xws = xw; yws = yw;
+            }
+            osqp_ref_solve_ws(nz, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, perm, &st, xws, yws, xo, yo, &info);
             memcpy(xPred + (size_t)b * (N + 1) * nx, xo, sizeof(double) * (N + 1) * nx);
             memcpy(uPred + (size_t)b * N * nu, xo + (N + 1) * nx, sizeof(double) * N * nu);
+            if (z_sol) memcpy(z_sol + (size_t)b * nz, xo, sizeof(double) * nz);
+            if (y_sol) memcpy(y_sol + (size_t)b * m, yo, sizeof(double) * m);
             if (status) status[b] = info.status_val;
             if (iters) iters[b] = info.iter;
         }
         free(AB); free(Pp); free(Pi); free(Px); free(q); free(Ap); free(Ai); free(Ax); free(l); free(u); free(xo); free(yo);
+        free(xw); free(yw);
     }
     free(perm);
     return 0;
@@ -273,7 +292,7 @@ int oracle_plan_tick_batch(int B, int N, double dt, const double *params, const 
             for (int k = 0; k <= N; k++) for (int a = 0; a < nx; a++) { l[me + k * nx + a] = xmin[a]; u[me + k * nx + a] = xmax[a]; }
             for (int k = 0; k < N; k++) for (int j = 0; j < nu; j++) { l[me + (N + 1) * nx + k * nu + j] = umin[j]; u[me + (N + 1) * nx + k * nu + j] = umax[j]; }
             osqp_ref_info info;
-            osqp_ref_solve(nz, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, perm, &st, xo, yo, &info);
+            osqp_ref_solve_ws(nz, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, perm, &st, 0, 0, xo, yo, &info);
             memcpy(xPred + (size_t)b * (N + 1) * nx, xo, sizeof(double) * (N + 1) * nx);
             memcpy(uPred + (size_t)b * N * nu, xo + (N + 1) * nx, sizeof(double) * N * nu);
             if (status) status[b] = info.status_val;

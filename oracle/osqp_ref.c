@@ -525,10 +525,25 @@ static void polish(work_t *w) {
  * Optional: iter_trace (length max_iter*2) receives (pri_res, dua_res) at every check.
  * Returns 0, or a negative number on a setup failure.
  */
+int osqp_ref_solve_ws(int n, int m, const int *Pp, const int *Pi, const double *Px, const double *q,
+                      const int *Ap, const int *Ai, const double *Ax, const double *l, const double *u,
+                      const int *perm, const osqp_ref_settings *settings, const double *x_ws, const double *y_ws,
+                      double *x_out, double *y_out, osqp_ref_info *info_out);
+
 int osqp_ref_solve(int n, int m, const int *Pp, const int *Pi, const double *Px, const double *q,
                    const int *Ap, const int *Ai, const double *Ax, const double *l, const double *u,
                    const int *perm, const osqp_ref_settings *settings, double *x_out, double *y_out,
                    osqp_ref_info *info_out) {
+    return osqp_ref_solve_ws(n, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, perm, settings, 0, 0, x_out, y_out, info_out);
+}
+
+/* Same with an optional warm start (x_ws[n], y_ws[m], unscaled; NULL = cold start): as osqp_warm_start,
+ * x <- D^-1 x_ws, y <- c E^-1 y_ws, z <- A x.  The reference never warm starts; this is the
+ * opt-in "next row" f3. */
+int osqp_ref_solve_ws(int n, int m, const int *Pp, const int *Pi, const double *Px, const double *q,
+                      const int *Ap, const int *Ai, const double *Ax, const double *l, const double *u,
+                      const int *perm, const osqp_ref_settings *settings, const double *x_ws, const double *y_ws,
+                      double *x_out, double *y_out, osqp_ref_info *info_out) {
     work_t W; memset(&W, 0, sizeof(W)); work_t *w = &W;
     w->n = n; w->m = m; w->s = *settings; w->perm = perm;
     w->P = csc_copy(n, n, Pp, Pi, Px); w->A = csc_copy(m, n, Ap, Ai, Ax);
@@ -553,6 +568,8 @@ int osqp_ref_solve(int n, int m, const int *Pp, const int *Pi, const double *Px,
     if (refactor_admm(w) != 0) { rc = -1; goto done; }
 
     w->info.status_val = ST_UNSOLVED; w->info.status_polish = 0; w->info.rho_updates = 0; w->info.obj_val = NAN;
+    if (x_ws) { for (int j = 0; j < n; j++) w->x[j] = w->Dinv[j] * x_ws[j]; mat_vec(w->A, w->x, w->z, 0); }
+    if (y_ws) for (int i = 0; i < m; i++) w->y[i] = w->c * w->Einv[i] * y_ws[i];
     int iter, can_check = 0;
     const double alpha = w->s.alpha, sigma = w->s.sigma;
     for (iter = 1; iter <= w->s.max_iter; iter++) {

@@ -126,10 +126,11 @@ def solve_qp(P, q, A, l, u, perm="rcm", **settings):
                              rho_final=info.rho_final))
 
 
-def ctrl_tick_batch(w, nthreads=1, params=None):
+def ctrl_tick_batch(w, nthreads=1, params=None, warm=None, shift=True):
     """Whole controller tick (LPV roll-out + QP assembly + OSQP restatement) for a batch, in C
     (oracle/lpv_ref.c).  ``w`` is a workload dict (keys N, dt, Q, R, dR, track, x0, u_prev, vel_ref,
-    curv_s, u_old, cf_new, lap).  Returns dict(xPred, uPred, status, iters)."""
+    curv_s, u_old, cf_new, lap).  Returns dict(xPred, uPred, status, iters, z, y); ``warm`` = a previous result
+    dict whose (z, y) warm-start this tick (shifted by one stage when ``shift``)."""
     from .lpv_ref import DEFAULT_PARAMS
     p = dict(DEFAULT_PARAMS)
     if params:
@@ -144,14 +145,21 @@ def ctrl_tick_batch(w, nthreads=1, params=None):
                 u_old=np.ascontiguousarray(w["u_old"], np.float64))
     xPred = np.empty((B, N + 1, 6)); uPred = np.empty((B, N, 2))
     status = np.empty(B, np.int32); iters = np.empty(B, np.int32)
+    nz = (N + 1) * 6 + N * 2; m = 6 * N + (N + 1) * 6
+    z = np.empty((B, nz)); y = np.empty((B, m))
+    zw = yw = None
+    if warm is not None:
+        zw = np.ascontiguousarray(warm["z"], np.float64); yw = np.ascontiguousarray(warm["y"], np.float64)
     d = C.c_double
     f = lib().oracle_ctrl_tick_batch
     f.restype = C.c_int
     f(C.c_int(B), C.c_int(N), d(float(w["dt"])), _ptr(pv, d), _ptr(arrs["Q"], d), _ptr(arrs["R"], d), _ptr(arrs["dR"], d),
       _ptr(arrs["track"], d), C.c_int(arrs["track"].shape[0]), _ptr(x0, d), _ptr(arrs["u_prev"], d), _ptr(arrs["vel_ref"], d),
       _ptr(arrs["curv"], d), _ptr(arrs["u_old"], d), d(float(w["cf_new"])), C.c_int(int(w["lap"])),
-      _ptr(xPred, d), _ptr(uPred, d), _ptr(status, C.c_int), _ptr(iters, C.c_int), C.c_int(int(nthreads)))
-    return dict(xPred=xPred, uPred=uPred, status=status, iters=iters)
+      _ptr(xPred, d), _ptr(uPred, d), _ptr(status, C.c_int), _ptr(iters, C.c_int), C.c_int(int(nthreads)),
+      _ptr(zw, d) if zw is not None else None, _ptr(yw, d) if yw is not None else None, C.c_int(1 if shift else 0),
+      _ptr(z, d), _ptr(y, d))
+    return dict(xPred=xPred, uPred=uPred, status=status, iters=iters, z=z, y=y)
 
 
 def plan_tick_batch(w, nthreads=1, params=None):

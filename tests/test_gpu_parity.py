@@ -249,3 +249,37 @@ def test_bad_arguments_fail_cleanly(lpvmpc):
     out = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, 60.0, 1)              # lap >= 1 works without a map
     assert np.all(out["status"] == 1)
     eng.close()
+
+
+def test_opt_in_warm_start_matches_oracle(lpvmpc):
+    """Row f3 of SURVEY 8f: warm start from the previous tick's (x, y), shifted by one stage.  Off by default
+    (the reference cold-starts every call); when enabled the GPU and the oracle's warm-started OSQP restatement
+    take the same iterations and agree on the solution, and fewer iterations are needed than from cold."""
+    from lpvmpc import workloads
+    B = 128
+    w = workloads.controller_batch(B, N=20, seed=21)
+    eng = workloads.make_solver(w)
+    eng.set_option("warm_start", 2)
+    o0 = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"])     # first call: cold
+    r0 = O.ctrl_tick_batch(w, nthreads=8)
+    assert np.array_equal(o0["iters"], r0["iters"])
+    w2 = dict(w)
+    w2["x0"] = r0["xPred"][:, 1, :].copy(); w2["u_old"] = r0["uPred"][:, 0, :].copy()
+    w2["u_prev"] = np.concatenate([r0["uPred"][:, 1:, :], r0["uPred"][:, -1:, :]], axis=1)
+    o1 = eng.solve(w2["x0"], w2["u_prev"], w2["vel_ref"], w2["curv_s"], w2["u_old"], None, w2["cf_new"], w2["lap"])   # warm
+    eng.close()
+    r1w = O.ctrl_tick_batch(w2, nthreads=8, warm=r0, shift=True)
+    r1c = O.ctrl_tick_batch(w2, nthreads=8)
+    assert np.array_equal(o1["status"], r1w["status"])
+    same = o1["iters"] == r1w["iters"]
+    assert same.mean() >= 0.97, (same.mean(), o1["iters"][~same], r1w["iters"][~same])
+    pol = same & (o1["polish"] == 1)
+    assert np.max(np.abs(o1["xPred"][pol] - r1w["xPred"][pol])) <= 1e-6
+    assert np.max(np.abs(o1["uPred"][same] - r1w["uPred"][same])) <= 2e-4
+    assert o1["iters"].mean() < 0.85 * r1c["iters"].mean(), (o1["iters"].mean(), r1c["iters"].mean())
+    # and the default is still a cold start
+    eng = workloads.make_solver(w)
+    a = eng.solve(w2["x0"], w2["u_prev"], w2["vel_ref"], w2["curv_s"], w2["u_old"], None, w2["cf_new"], w2["lap"])
+    b = eng.solve(w2["x0"], w2["u_prev"], w2["vel_ref"], w2["curv_s"], w2["u_old"], None, w2["cf_new"], w2["lap"])
+    eng.close()
+    assert np.array_equal(a["iters"], r1c["iters"]) and np.array_equal(b["iters"], r1c["iters"])
