@@ -59,7 +59,9 @@ class LpvMpcError(RuntimeError):
 EXPORTS = ("lpvmpc_version", "lpvmpc_default_config", "lpvmpc_create", "lpvmpc_destroy", "lpvmpc_last_error",
            "lpvmpc_reserve", "lpvmpc_lpv_batch", "lpvmpc_estimate_abc_batch", "lpvmpc_solve_batch_AB",
            "lpvmpc_solve_batch", "lpvmpc_solve_batch_dev", "lpvmpc_last_kernel_ms", "lpvmpc_set_timing",
-           "lpvmpc_kernel_time_stats", "lpvmpc_set_option")
+           "lpvmpc_kernel_time_stats", "lpvmpc_set_option",
+           "lpvmpc_local_position_batch", "lpvmpc_global_position_batch", "lpvmpc_plant_step_batch",
+           "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read")
 
 _lib = None
 
@@ -98,6 +100,15 @@ def load():
     lib.lpvmpc_set_option.restype = C.c_int
     lib.lpvmpc_kernel_time_stats.argtypes = [vp, P(_d), P(_i)]
     lib.lpvmpc_kernel_time_stats.restype = C.c_int
+    lib.lpvmpc_local_position_batch.argtypes = [vp, _i, vp, _d, _d, vp]
+    lib.lpvmpc_global_position_batch.argtypes = [vp, _i, vp, vp]
+    lib.lpvmpc_plant_step_batch.argtypes = [vp, _i, vp, vp, _i, _d, _d]
+    lib.lpvmpc_cl_init.argtypes = [vp, _i, vp, _d, _d, _i, _i, _d, _d]
+    lib.lpvmpc_cl_tick.argtypes = [vp, _i]
+    lib.lpvmpc_cl_read.argtypes = [vp, vp, vp, vp, vp, vp]
+    for name in ("lpvmpc_local_position_batch", "lpvmpc_global_position_batch", "lpvmpc_plant_step_batch",
+                 "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read"):
+        getattr(lib, name).restype = C.c_int
     for name in ("lpvmpc_reserve", "lpvmpc_lpv_batch", "lpvmpc_estimate_abc_batch", "lpvmpc_solve_batch_AB",
                  "lpvmpc_solve_batch", "lpvmpc_solve_batch_dev", "lpvmpc_set_timing"):
         getattr(lib, name).restype = C.c_int

@@ -200,6 +200,41 @@ class BatchedSolver:
                                                ptr(o["status"]), ptr(o["iters"]), ptr(o["resid"]), ptr(o["polish"])))
         return o
 
+    # -- caller-side helpers and the closed-loop fleet ------------------------------------
+    def local_position(self, xy_psi, half_width, slack):
+        """Batched Map.getLocalPosition: [B,3] -> [B,4] = (s, ey, epsi, inside)."""
+        a = f64(xy_psi).reshape(-1, 3); out = np.empty((a.shape[0], 4))
+        self._chk(self._lib.lpvmpc_local_position_batch(self._h, a.shape[0], ptr(a), float(half_width), float(slack), ptr(out)))
+        return out
+
+    def global_position(self, s_ey):
+        """Batched Map.getGlobalPosition: [B,2] -> [B,3] = (x, y, theta)."""
+        a = f64(s_ey).reshape(-1, 2); out = np.empty((a.shape[0], 3))
+        self._chk(self._lib.lpvmpc_global_position_batch(self._h, a.shape[0], ptr(a), ptr(out)))
+        return out
+
+    def plant_step(self, state, u, n_sub=1, dt_sim=0.005, mu_sim=0.05):
+        """n_sub steps of Simulator.f on state [B,8] under u [B,2] = (a, delta); returns the new state."""
+        st = f64(state).reshape(-1, 8).copy(); u = f64(u, (st.shape[0], 2), "u")
+        self._chk(self._lib.lpvmpc_plant_step_batch(self._h, st.shape[0], ptr(st), ptr(u), int(n_sub), float(dt_sim), float(mu_sim)))
+        return st
+
+    def cl_init(self, plant0, half_width, slack, q9_swap=True, n_sub=7, dt_sim=0.005, mu_sim=0.05):
+        p0 = f64(plant0).reshape(-1, 8)
+        self._cl_B = p0.shape[0]
+        self._chk(self._lib.lpvmpc_cl_init(self._h, self._cl_B, ptr(p0), float(half_width), float(slack), 1 if q9_swap else 0,
+                                           int(n_sub), float(dt_sim), float(mu_sim)))
+
+    def cl_tick(self, n_ticks=1):
+        self._chk(self._lib.lpvmpc_cl_tick(self._h, int(n_ticks)))
+
+    def cl_read(self):
+        B = self._cl_B
+        o = dict(plant=np.empty((B, 8)), local=np.empty((B, 6)), cmd=np.empty((B, 2)), iters=np.empty(B, np.int32),
+                 status=np.empty(B, np.int32))
+        self._chk(self._lib.lpvmpc_cl_read(self._h, ptr(o["plant"]), ptr(o["local"]), ptr(o["cmd"]), ptr(o["iters"]), ptr(o["status"])))
+        return o
+
     # -- device-pointer entry point (torch tensors or raw integers) -----------------------------------
     def solve_dev(self, B, x0, u_prev, vel_ref, curv_s, u_old, max_ey, xPred, uPred, status=None, iters=None,
                   resid=None, polish=None, cf_new=60.0, lap=1, stream=0):

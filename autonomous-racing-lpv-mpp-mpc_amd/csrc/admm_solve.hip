@@ -860,7 +860,7 @@ struct Solver {
                 Lo[e] = fmax(lo, -kInfty); Hi[e] = fmin(hi, kInfty);
             }
         }
-        if (tid < 16) beq[tid] = (tid < NX) ? a.x0[(size_t)inst * NX + tid] : 0.0;
+        if (tid < 16) beq[tid] = (tid < NX) ? a.x0[(size_t)inst * a.x0_stride + tid] : 0.0;
         sync();
 
         // ---------- setup: scaling, rho, factorisation ----------

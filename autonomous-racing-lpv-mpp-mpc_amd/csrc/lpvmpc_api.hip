@@ -30,6 +30,11 @@ struct lpvmpc_handle {
     double *d_xlast, *d_delta;
     double *d_state;         // warm-start state [cap][3][8(N+1)] (opt-in)
     int warm_mode, state_valid_B;   // 0 off (default); instances whose state is valid from the previous solve
+    // closed-loop fleet (lpvmpc_cl_*): plant [B][8], local state [B][6], command [B][2] and scratch
+    double *cl_plant, *cl_local, *cl_cmd;
+    int cl_B, cl_first_it, cl_q9, cl_ticks;
+    double cl_hw, cl_slack;
+    lpvmpc::PlantCfg cl_pc;
     int32_t *d_status, *d_iters, *d_polish;
     hipStream_t stream;
     std::vector<hipEvent_t> ev0, ev1;   // ring of event pairs around the solve-kernel launches
@@ -133,6 +138,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->d_x0 = h->d_uprev = h->d_vel = h->d_curv = h->d_uold = h->d_maxey = h->d_AB = h->d_states = nullptr;
     h->d_xPred = h->d_uPred = h->d_resid = h->d_xlast = h->d_delta = nullptr;
     h->d_status = h->d_iters = h->d_polish = nullptr; h->d_state = nullptr; h->warm_mode = 0; h->state_valid_B = 0;
+    h->cl_plant = h->cl_local = h->cl_cmd = nullptr; h->cl_B = 0; h->cl_first_it = 1; h->cl_q9 = 1; h->cl_ticks = 0;
     DevCfg &d = h->dev;
     std::memset(&d, 0, sizeof(d));
     d.kind = cfg->kind; d.N = cfg->N; d.track_rows = cfg->track_rows; d.max_iter = cfg->max_iter;
@@ -169,6 +175,9 @@ extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     free_ws(h);
+    if (h->cl_plant) (void)hipFree(h->cl_plant);
+    if (h->cl_local) (void)hipFree(h->cl_local);
+    if (h->cl_cmd) (void)hipFree(h->cl_cmd);
     if (h->d_cfg) (void)hipFree(h->d_cfg);
     for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
@@ -345,7 +354,7 @@ extern "C" int lpvmpc_solve_batch_AB(lpvmpc_handle *h, int32_t B, const double *
     if (!ctrl) H2D(h->d_maxey, max_ey, b * 8);
     SolveArgs a{B, h->d_x0, h->d_AB, ctrl ? h->d_vel : nullptr, u_old ? h->d_uold : nullptr, ctrl ? nullptr : h->d_maxey,
                 h->d_xPred, h->d_uPred, h->d_status, h->d_iters, h->d_polish, h->d_resid,
-                h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0};
+                h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0, h->nx};
     rc = launch_solve_timed(h, a, st); if (rc) return rc;
     if (h->warm_mode) h->state_valid_B = B;
     return copy_out(h, B, xPred, uPred, status, iters, resid, polish, st);
@@ -365,7 +374,7 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
     hipStream_t st = (hipStream_t)stream;
     rc = launch_lpv(h, B, x0, u_prev, vel_ref, curv_s, cf_new, lap, nullptr, h->d_AB, st); if (rc) return rc;
     SolveArgs a{B, x0, h->d_AB, ctrl ? vel_ref : nullptr, u_old, ctrl ? nullptr : max_ey, xPred, uPred, status, iters, polish, resid,
-                h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0};
+                h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0, h->nx};
     rc = launch_solve_timed(h, a, st); if (rc) return rc;
     if (h->warm_mode) h->state_valid_B = B;
     return LPVMPC_OK;
@@ -393,4 +402,112 @@ extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0,
                                 h->d_uPred, h->d_status, h->d_iters, h->d_resid, h->d_polish, (void *)st);
     if (rc) return rc;
     return copy_out(h, B, xPred, uPred, status, iters, resid, polish, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// caller-side helpers of the reference, batched on the device
+// ------------------------------------------------------------------------------------------------
+extern "C" int lpvmpc_local_position_batch(lpvmpc_handle *h, int32_t B, const double *xy_psi, double half_width, double slack, double *out) {
+    int rc = check_common(h, B, "lpvmpc_local_position_batch"); if (rc) return rc;
+    if (!xy_psi || !out) return fail(h, LPVMPC_E_ARG, "lpvmpc_local_position_batch: NULL argument");
+    rc = need_track(h, "lpvmpc_local_position_batch"); if (rc) return rc;
+    hipStream_t st = h->stream;
+    // workspace reuse: inputs in d_xlast ([cap][N][6] >= [B][3]), outputs in d_states ([cap][N][nx] >= [B][4])
+    H2D(h->d_xlast, xy_psi, (size_t)B * 3 * 8);
+    HIP_TRY(h, lpvmpc::launch_local_position(h->d_cfg, B, h->d_xlast, half_width, slack, h->d_states, st));
+    D2H(out, h->d_states, (size_t)B * 4 * 8);
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return LPVMPC_OK;
+}
+
+extern "C" int lpvmpc_global_position_batch(lpvmpc_handle *h, int32_t B, const double *s_ey, double *out) {
+    int rc = check_common(h, B, "lpvmpc_global_position_batch"); if (rc) return rc;
+    if (!s_ey || !out) return fail(h, LPVMPC_E_ARG, "lpvmpc_global_position_batch: NULL argument");
+    rc = need_track(h, "lpvmpc_global_position_batch"); if (rc) return rc;
+    hipStream_t st = h->stream;
+    H2D(h->d_xlast, s_ey, (size_t)B * 2 * 8);
+    HIP_TRY(h, lpvmpc::launch_global_position(h->d_cfg, B, h->d_xlast, h->d_states, st));
+    D2H(out, h->d_states, (size_t)B * 3 * 8);
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return LPVMPC_OK;
+}
+
+static lpvmpc::PlantCfg plant_cfg(const lpvmpc_handle *h, int n_sub, double dt_sim, double mu_sim) {
+    lpvmpc::PlantCfg pc; pc.lf = h->cfg.lf; pc.lr = h->cfg.lr; pc.m = h->cfg.m; pc.Iz = h->cfg.Iz; pc.mu = mu_sim; pc.dt = dt_sim; pc.n_sub = n_sub;
+    return pc;
+}
+
+extern "C" int lpvmpc_plant_step_batch(lpvmpc_handle *h, int32_t B, double *state, const double *u, int32_t n_sub, double dt_sim, double mu_sim) {
+    int rc = check_common(h, B, "lpvmpc_plant_step_batch"); if (rc) return rc;
+    if (!state || !u || n_sub < 1 || !(dt_sim > 0)) return fail(h, LPVMPC_E_ARG, "lpvmpc_plant_step_batch: bad argument");
+    hipStream_t st = h->stream;
+    H2D(h->d_xlast, state, (size_t)B * 8 * 8); H2D(h->d_states, u, (size_t)B * 2 * 8);
+    HIP_TRY(h, lpvmpc::launch_plant(B, h->d_xlast, h->d_states, plant_cfg(h, n_sub, dt_sim, mu_sim), st));
+    D2H(state, h->d_xlast, (size_t)B * 8 * 8);
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return LPVMPC_OK;
+}
+
+// ---- closed-loop fleet: controller in the lap-0 path-tracking branch of controllerMain.py ----------------
+extern "C" int lpvmpc_cl_init(lpvmpc_handle *h, int32_t B, const double *plant0, double half_width, double slack, int32_t q9_swap,
+                              int32_t n_sub, double dt_sim, double mu_sim) {
+    int rc = check_common(h, B, "lpvmpc_cl_init"); if (rc) return rc;
+    if (h->cfg.kind != LPVMPC_KIND_CONTROLLER) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_init: controller handles only");
+    if (h->cfg.N > 20) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_init: the reference's seed trajectories have 20 rows (N <= 20)");
+    if (!plant0 || n_sub < 1 || !(dt_sim > 0)) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_init: bad argument");
+    rc = need_track(h, "lpvmpc_cl_init"); if (rc) return rc;
+    if (h->cl_plant) { (void)hipFree(h->cl_plant); (void)hipFree(h->cl_local); (void)hipFree(h->cl_cmd); h->cl_plant = h->cl_local = h->cl_cmd = nullptr; }
+    HIP_TRY(h, hipMalloc((void **)&h->cl_plant, (size_t)B * 8 * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->cl_local, (size_t)B * 6 * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->cl_cmd, (size_t)B * 2 * 8));
+    hipStream_t st = h->stream;
+    H2D(h->cl_plant, plant0, (size_t)B * 8 * 8);
+    HIP_TRY(h, hipMemsetAsync(h->cl_cmd, 0, (size_t)B * 2 * 8, st));
+    std::vector<double> ones((size_t)B * (h->cfg.N + 1), 1.0);                  // vel_ref = 1 m/s on lap 0 (CMAIN:311,326)
+    H2D(h->d_vel, ones.data(), ones.size() * 8);
+    HIP_TRY(h, hipStreamSynchronize(st));
+    h->cl_B = B; h->cl_first_it = 1; h->cl_q9 = q9_swap != 0; h->cl_ticks = 0; h->cl_hw = half_width; h->cl_slack = slack;
+    h->cl_pc = plant_cfg(h, n_sub, dt_sim, mu_sim);
+    h->state_valid_B = 0;
+    return LPVMPC_OK;
+}
+
+extern "C" int lpvmpc_cl_tick(lpvmpc_handle *h, int32_t n_ticks) {
+    if (!h || !h->cl_plant || n_ticks < 1) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_tick: call lpvmpc_cl_init first");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const int B = h->cl_B, N = h->cfg.N;
+    hipStream_t st = h->stream;
+    for (int t = 0; t < n_ticks; ++t) {
+        HIP_TRY(h, lpvmpc::launch_cl_measure(h->d_cfg, B, h->cl_plant, h->cl_cmd, h->cl_hw, h->cl_slack, h->cl_q9, h->cl_local, h->d_uold, st));
+        const double *x0 = h->cl_local; int x0_stride = 6;
+        if (h->cl_first_it < 10) {                                           // CMAIN:310-315: seed mode
+            HIP_TRY(h, lpvmpc::launch_cl_seed(B, N, h->cl_local, h->d_xlast, h->d_delta, st));
+            HIP_TRY(h, lpvmpc::launch_abc(h->dev, h->d_cfg, B, h->d_xlast, h->d_delta, h->d_AB, st));
+            h->cl_first_it++;
+        } else {                                                             // CMAIN:325-331: LPV prediction, x0 = first rolled-out state
+            HIP_TRY(h, lpvmpc::launch_lpv(h->dev, h->d_cfg, B, h->cl_local, h->d_uPred, h->d_vel, nullptr, 60.0, 0, h->d_states, h->d_AB, st));
+            x0 = h->d_states; x0_stride = N * 6;
+        }
+        SolveArgs a{B, x0, h->d_AB, h->d_vel, h->d_uold, nullptr, h->d_xPred, h->d_uPred, h->d_status, h->d_iters, h->d_polish, h->d_resid,
+                    h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0, x0_stride};
+        int rc = launch_solve_timed(h, a, st); if (rc) return rc;
+        if (h->warm_mode) h->state_valid_B = B;
+        HIP_TRY(h, lpvmpc::launch_cl_command_plant(B, N, h->d_uPred, h->cl_cmd, h->cl_plant, h->cl_pc, st));
+        h->cl_ticks++;
+    }
+    return LPVMPC_OK;
+}
+
+extern "C" int lpvmpc_cl_read(lpvmpc_handle *h, double *plant, double *local_state, double *cmd, int32_t *iters, int32_t *status) {
+    if (!h || !h->cl_plant) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_read: call lpvmpc_cl_init first");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t B = h->cl_B;
+    hipStream_t st = h->stream;
+    if (plant) D2H(plant, h->cl_plant, B * 8 * 8);
+    if (local_state) D2H(local_state, h->cl_local, B * 6 * 8);
+    if (cmd) D2H(cmd, h->cl_cmd, B * 2 * 8);
+    if (iters) D2H(iters, h->d_iters, B * 4);
+    if (status) D2H(status, h->d_status, B * 4);
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return LPVMPC_OK;
 }

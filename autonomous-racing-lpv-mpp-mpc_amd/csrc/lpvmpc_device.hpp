@@ -41,7 +41,7 @@ __device__ inline double track_curvature(const DevCfg &c, double s) {
 // arguments of the solve kernel (device pointers)
 struct SolveArgs {
     int B;
-    const double *x0;       // [B][NX]
+    const double *x0;       // [B][x0_stride], first NX used
     const double *AB;       // [B][N][NX][NX+2]
     const double *vel_ref;  // [B][N+1]   controller
     const double *u_old;    // [B][2] or null
@@ -52,6 +52,7 @@ struct SolveArgs {
     double *resid;          // [B][4]
     double *state;          // [B][3][8(N+1)] unscaled x, y(dynamics rows), y(box rows) of the previous solve, or null
     int warm;               // 0 cold start (reference behaviour), 1 warm start from state, 2 same shifted by one stage
+    int x0_stride;          // doubles between consecutive instances' x0 (NX, or N*NX when x0 = first rolled-out state)
 };
 
 // host-side launchers (defined next to their kernels)
@@ -61,5 +62,15 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
 hipError_t launch_lpv(const DevCfg &cfg, const DevCfg *dcfg, int B, const double *x0, const double *u_prev, const double *vel_ref,
                       const double *curv_s, double cf_new, int lap, double *states, double *AB, hipStream_t stream);
 hipError_t launch_abc(const DevCfg &cfg, const DevCfg *dcfg, int B, const double *xlast, const double *delta, double *AB, hipStream_t stream);
+
+// closed-loop helpers (closed_loop.hip)
+struct PlantCfg { double lf, lr, m, Iz, mu, dt; int n_sub; };
+hipError_t launch_local_position(const DevCfg *dcfg, int B, const double *xypsi, double half_width, double slack, double *out, hipStream_t s);
+hipError_t launch_global_position(const DevCfg *dcfg, int B, const double *sey, double *out, hipStream_t s);
+hipError_t launch_plant(int B, double *plant, const double *u_a_delta, PlantCfg pc, hipStream_t s);
+hipError_t launch_cl_measure(const DevCfg *dcfg, int B, const double *plant, const double *cmd, double half_width, double slack,
+                             int q9_swap, double *local_state, double *u_old, hipStream_t s);
+hipError_t launch_cl_seed(int B, int N, const double *local_state, double *xlast, double *delta, hipStream_t s);
+hipError_t launch_cl_command_plant(int B, int N, const double *uPred, double *cmd, double *plant, PlantCfg pc, hipStream_t s);
 
 }  // namespace lpvmpc

@@ -189,6 +189,35 @@ int lpvmpc_kernel_time_stats(lpvmpc_handle *h, double *total_ms, int32_t *count)
 /* Duration (ms) of the most recent timed solve-kernel launch, negative if none. */
 double lpvmpc_last_kernel_ms(lpvmpc_handle *h);
 
+/* ---------------------------------------------------------------------------------------------------
+ * "Next row" f1 of the hot-path scope table: the caller-side pieces a closed-loop run needs, batched.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Map.getLocalPosition (TRACK:283-383): xy_psi [B][3] -> out [B][4] = {s, ey, epsi, inside}; off the track the
+ * reference's sentinels {10000, 10000, 10000, 0}.  half_width / slack = Map.halfWidth / Map.slack. */
+int lpvmpc_local_position_batch(lpvmpc_handle *h, int32_t B, const double *xy_psi, double half_width, double slack,
+                                double *out);
+
+/* Map.getGlobalPosition (TRACK:205-262): s_ey [B][2] -> out [B][3] = {x, y, theta}. */
+int lpvmpc_global_position_batch(lpvmpc_handle *h, int32_t B, const double *s_ey, double *out);
+
+/* n_sub steps of Simulator.f (vehicleSimulator.py:164-199; linear tyres Fy = 60 alpha) on
+ * state [B][8] = {x, y, vx, vy, ax, ay, yaw, psiDot} (in/out) under the constant input u [B][2] = {a, delta}.
+ * lf, lr, m, Iz come from the handle's configuration; mu_sim = simulator/mu, dt_sim = simulator/dt. */
+int lpvmpc_plant_step_batch(lpvmpc_handle *h, int32_t B, double *state, const double *u, int32_t n_sub, double dt_sim,
+                            double mu_sim);
+
+/* Closed-loop fleet of B vehicles under the LPV-MPC controller in the lap-0 path-tracking branch of
+ * controllerMain.py (:179-190 measurement incl. quirk Q9 when q9_swap != 0, :289-298 last command as uOld,
+ * :310-315 nine seed ticks, :325-331 LPV prediction with x0 = first rolled-out state, :381-386 command), with the
+ * plant advanced n_sub simulator steps per control tick.  Everything stays on the device; lpvmpc_cl_tick enqueues
+ * n_ticks control ticks without synchronising, lpvmpc_cl_read synchronises and copies the current fleet state
+ * (any pointer may be NULL): plant [B][8], local_state [B][6], cmd [B][2] = {servo, motor}, iters / status [B]. */
+int lpvmpc_cl_init(lpvmpc_handle *h, int32_t B, const double *plant0, double half_width, double slack, int32_t q9_swap,
+                   int32_t n_sub, double dt_sim, double mu_sim);
+int lpvmpc_cl_tick(lpvmpc_handle *h, int32_t n_ticks);
+int lpvmpc_cl_read(lpvmpc_handle *h, double *plant, double *local_state, double *cmd, int32_t *iters, int32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,14 +82,35 @@ def install_stubs():
     osqp.OSQP = OSQP
     sys.modules["osqp"] = osqp
 
+    # ROS message / tf packages imported by vehicleSimulator.py: attribute access yields a dummy class
+    class _Any(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return type(name, (object,), {"__init__": lambda self, *a, **k: None})
+    for name in ("geometry_msgs", "geometry_msgs.msg", "barc", "barc.msg", "sensor_msgs", "sensor_msgs.msg",
+                 "marvelmind_nav", "marvelmind_nav.msg", "tf"):
+        sys.modules[name] = _Any(name)
+    rospy.Rate = lambda *a, **k: None
+    rospy.Publisher = lambda *a, **k: None
+    rospy.Subscriber = lambda *a, **k: None
+    PARAMS.update({"simulator/c_f": 0.8, "simulator/B": 6.0, "simulator/C": 1.6, "simulator/mu": 0.05,
+                   "simulator/init_vx": 0.2, "simulator/dt": 0.005})
+
 
 def import_reference():
     tmp = tempfile.mkdtemp(prefix="refimport_")
     for rel in ("ControllerObject/PathFollowingLPVMPC.py", "PlannerObject/LPV_MPC_Planner.py",
-                "Utilities/utilities.py", "Utilities/trackInitialization.py"):
+                "Utilities/utilities.py", "Utilities/trackInitialization.py", "vehicleSimulator.py"):
         shutil.copy(os.path.join(REF, rel), tmp)
     subprocess.run([sys.executable, "-m", "lib2to3", "-w", "-n", tmp], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # vehicleSimulator.py mixes tabs and spaces (legal in Python 2, tab stops every 8 columns)
+    vs = os.path.join(tmp, "vehicleSimulator.py")
+    with open(vs) as fh:
+        lines = [ln.expandtabs(8) for ln in fh]
+    with open(vs, "w") as fh:
+        fh.writelines(lines)
     sys.path.insert(0, tmp)
     install_stubs()
     import PathFollowingLPVMPC as CTRL
@@ -315,6 +336,65 @@ def main():
         cl.update(plan_xPred=np.array(tx), plan_uPred=np.array(tu), plan_SS=np.array(tss))
         np.savez_compressed(os.path.join(HERE, "closed_loop.npz"), **cl)
         print("wrote closed_loop.npz")
+
+        # ---------------- plant model + coordinate transforms ----------------
+        import vehicleSimulator as SIM
+        pt = {}
+        rng = np.random.default_rng(5)
+        for shape in ("oval", "L_shape"):
+            mp = make_map(TRACK, shape)
+            ss = rng.uniform(0.001, mp.TrackLength * 0.999, 200); eys = rng.uniform(-0.28, 0.28, 200)
+            glob = np.array([[float(v) for v in mp.getGlobalPosition(s_, e_)] for s_, e_ in zip(ss, eys)])
+            psis = glob[:, 2] + rng.normal(0, 0.3, 200)
+            pts = np.column_stack([glob[:, 0], glob[:, 1], psis])
+            pts = np.vstack([pts, np.column_stack([rng.uniform(-4, 4, 40), rng.uniform(-2, 5, 40), rng.uniform(-3, 3, 40)])])
+            loc = np.array([[float(v) for v in mp.getLocalPosition(*p_)] for p_ in pts])
+            pt.update({shape + "_s": ss, shape + "_ey": eys, shape + "_glob": glob, shape + "_pts": pts, shape + "_loc": loc,
+                       shape + "_hw": np.array(mp.halfWidth), shape + "_slack": np.array(mp.slack)})
+        sim = SIM.Simulator()
+        useq = np.column_stack([rng.uniform(-1.0, 2.0, 300), rng.uniform(-0.25, 0.25, 300)])     # [a, delta]
+        sts = []
+        for u_ in useq:
+            sim.f([float(u_[0]), float(u_[1])])
+            sts.append([sim.x, sim.y, sim.vx, sim.vy, sim.ax, sim.ay, sim.yaw, sim.psiDot])
+        pt.update(sim_u=useq, sim_states=np.array(sts), sim_init=np.array([0.01, 0.0, 0.2, 0.0, 0.0, 0.0, 0.0, 0.0]))
+
+        # ---------------- closed loop: reference controller + reference plant + reference map ----------------
+        # synchronous schedule (documented in DESIGN.md): per 30 Hz control tick the plant takes 7 steps of 5 ms;
+        # measurement = ground truth; lap-0 path-tracking branch of controllerMain.py:179-190,289-331,381-386.
+        PARAMS["trackShape"] = "oval"
+        oval2 = make_map(TRACK, "oval")
+        N = 20
+        Q, R, dR = TUNINGS["path"]
+        c = CTRL.PathFollowingLPV_MPC(Q, R, dR, N, 1, dt, oval2, "OSQP", 0, 0)
+        sim = SIM.Simulator()
+        sim.vx = 1.0
+        first_it = 1
+        cmd = [0.0, 0.0]                                    # [servo, motor]
+        tr_plant, tr_local, tr_cmd, tr_iter = [], [], [], []
+        for tick in range(40):
+            G_ = np.array([sim.vx, sim.vy, sim.psiDot, sim.x, sim.y, sim.yaw])
+            Lc = G_.copy()
+            if Lc[0] < 0.01:
+                Lc[0] = 0.01
+            Lc[4], Lc[3], Lc[5], inside = oval2.getLocalPosition(G_[3], G_[4], G_[5])     # quirk Q9 (CMAIN:188)
+            c.OldSteering.append(cmd[0]); c.OldAccelera.append(cmd[1])
+            c.OldSteering.pop(0); c.OldAccelera.pop(0)
+            if first_it < 10:
+                xx, uu = lpv_ref.ctrl_seed_vectors(Lc)
+                c.solve(Lc[0:6], xx, uu, False, np.ones(N), 0, 0, 0, first_it)
+                first_it += 1
+            else:
+                S, A_L, B_L, C_L = c.LPVPrediction(Lc[0:6], c.uPred, np.ones(N + 1), np.zeros(N), 60.0, 0)
+                c.solve(S[0, :], S, c.uPred, False, np.ones(N + 1), A_L, B_L, C_L, first_it)
+            cmd = [float(c.uPred[0, 0]), float(c.uPred[0, 1])]
+            tr_plant.append([sim.x, sim.y, sim.vx, sim.vy, sim.ax, sim.ay, sim.yaw, sim.psiDot])
+            tr_local.append(Lc.copy()); tr_cmd.append(list(cmd)); tr_iter.append(CAPTURE[-1]["iter"])
+            for _ in range(7):
+                sim.f([cmd[1], cmd[0]])                     # u = [motor, servo]  (vehicleSimulator.py:330)
+        pt.update(cl_plant=np.array(tr_plant), cl_local=np.array(tr_local), cl_cmd=np.array(tr_cmd), cl_iter=np.array(tr_iter))
+        np.savez_compressed(os.path.join(HERE, "plant_and_transforms.npz"), **pt)
+        print("wrote plant_and_transforms.npz")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
