@@ -1076,8 +1076,13 @@ struct Solver {
     }
 };
 
+// waves per SIMD the kernel must allow: workgroups per CU are LDS-limited (4 at N = 20, 2 at N = 30 / 40), so only
+// the N <= 20 two-wavefront kernels need two waves per SIMD (<= 256 registers); the others may use up to 512
+template <int NT, int NW>
+constexpr int min_waves_per_simd() { return (NW == 2 && NT <= 20) ? 2 : 1; }
+
 template <int NX, int NT, int NW>
-__global__ void __launch_bounds__(64 * NW, NW) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
+__global__ void __launch_bounds__(64 * NW, (min_waves_per_simd<NT, NW>())) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
     extern __shared__ __align__(16) double smem[];
     const int inst = blockIdx.x;
     if (inst >= a.B) return;

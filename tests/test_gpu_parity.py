@@ -147,9 +147,10 @@ def test_kernel_variants_agree(lpvmpc):
     """Three kernels run the same algorithm: variant 0 (default: compile-time horizon, two wavefronts per
     instance, two-sided elimination), variant 2 (compile-time horizon, one wavefront) and variant 1 (run-time
     horizon, factor tiles in LDS): identical statuses / polish flags, iteration counts equal (the factorisations
-    differ in elimination order, i.e. in round-off only), solutions equal to 1e-8."""
+    differ in elimination order, i.e. in round-off only), solutions equal to 1e-6 (1e-8 when polished)."""
     from lpvmpc import workloads
-    for w in (workloads.controller_batch(128, N=20, seed=5), workloads.planner_batch(64, N=30, seed=6)):
+    for w in (workloads.controller_batch(128, N=20, seed=5), workloads.planner_batch(64, N=30, seed=6),
+              workloads.planner_batch(48, N=40, seed=7), workloads.controller_batch(64, N=10, seed=8)):
         outs = []
         for variant in (0, 1, 2):
             eng = workloads.make_solver(w)
@@ -162,8 +163,13 @@ def test_kernel_variants_agree(lpvmpc):
             assert np.array_equal(a["iters"], b["iters"]), (np.nonzero(a["iters"] != b["iters"]), a["iters"][a["iters"] != b["iters"]], b["iters"][a["iters"] != b["iters"]])
             assert np.array_equal(a["polish"], b["polish"])
             ok = np.isin(a["status"], (1, 2, -2))
-            assert np.max(np.abs(a["xPred"][ok] - b["xPred"][ok])) < 1e-8
-            assert np.max(np.abs(a["uPred"][ok] - b["uPred"][ok])) < 1e-8
+            # polished instances sit on the same optimum; un-polished planner iterates after thousands of iterations carry
+            # the (different) round-off of the two elimination orders
+            assert np.max(np.abs(a["xPred"][ok] - b["xPred"][ok])) < 1e-6
+            assert np.max(np.abs(a["uPred"][ok] - b["uPred"][ok])) < 1e-6
+            pol = ok & (a["polish"] == 1)
+            if pol.any():
+                assert np.max(np.abs(a["uPred"][pol] - b["uPred"][pol])) < 1e-8
 
 
 def _agree(out, ref, b, nx, tol_x):
@@ -283,3 +289,52 @@ def test_opt_in_warm_start_matches_oracle(lpvmpc):
     b = eng.solve(w2["x0"], w2["u_prev"], w2["vel_ref"], w2["curv_s"], w2["u_old"], None, w2["cf_new"], w2["lap"])
     eng.close()
     assert np.array_equal(a["iters"], r1c["iters"]) and np.array_equal(b["iters"], r1c["iters"])
+
+
+def test_full_size_cfg4_properties(lpvmpc):
+    """BASELINE configs[3] at full size on one GPU (32768 controller + 32768 planner-style instances, N = 20):
+    size-independent properties -- every controller instance solved; every returned trajectory satisfies the
+    initial-state equality, the dynamics x_{k+1} = A_k x_k + B_k u_k and the input boxes to OSQP's tolerance; a
+    second solve warm-started at its own solution stops at the first termination check with the same answer."""
+    from lpvmpc import workloads
+    B = 32768
+    wc = workloads.controller_batch(B, N=20, seed=2)
+    ec = workloads.make_solver(wc)
+    S, A, Bm = ec.lpv(wc["x0"], wc["u_prev"], wc["vel_ref"], wc["curv_s"], cf_new=60.0, lap=1)
+    oc = ec.solve(wc["x0"], wc["u_prev"], wc["vel_ref"], wc["curv_s"], wc["u_old"], None, 60.0, 1)
+    # a handful of extreme random states (low speed in a curve) run into max_iter / "solved inaccurate", as in OSQP
+    assert set(np.unique(oc["status"])) <= {1, 2, -2} and np.mean(oc["status"] == 1) > 0.999
+    s1 = oc["status"] == 1
+    x, u = oc["xPred"][s1], oc["uPred"][s1]
+    # every constraint violation of the returned point is bounded by the primal residual the solver reports
+    # (||Ax - z||_inf with z inside the bounds), which OSQP's stopping rule keeps below eps_abs + eps_rel max(|Ax|, |z|)
+    pri = oc["resid"][s1, 0]
+    scale = np.maximum(np.max(np.abs(x), axis=(1, 2)), 1.0)
+    assert np.all(pri <= 1e-3 + 1e-3 * 1.5 * scale)
+    tol = 1.01 * pri + 1e-9
+    dyn = x[:, 1:, :] - np.einsum("bkij,bkj->bki", A[s1], x[:, :-1, :]) - np.einsum("bkij,bkj->bki", Bm[s1], u)
+    assert np.all(np.max(np.abs(x[:, 0, :] - wc["x0"][s1]), axis=1) <= tol)
+    assert np.all(np.max(np.abs(dyn), axis=(1, 2)) <= tol)
+    assert np.all(np.max(np.abs(u[:, :, 0]), axis=1) <= 0.249 + tol)
+    assert np.all(np.max(u[:, :, 1], axis=1) <= 4.0 + tol) and np.all(np.min(u[:, :, 1], axis=1) >= -1.0 - tol)
+    assert np.all(np.min(x[:, :-1, 0], axis=1) >= 0.01 - tol)
+    # idempotence under a warm start at the solution
+    ec.set_option("warm_start", 1)
+    ec.solve(wc["x0"], wc["u_prev"], wc["vel_ref"], wc["curv_s"], wc["u_old"], None, 60.0, 1)           # stores the state
+    o2 = ec.solve(wc["x0"], wc["u_prev"], wc["vel_ref"], wc["curv_s"], wc["u_old"], None, 60.0, 1)      # warm at its own solution
+    ec.close()
+    assert np.mean(o2["status"] == 1) > 0.999 and np.mean(o2["iters"][s1] == 25) > 0.99
+    pol = (oc["polish"] == 1) & (o2["polish"] == 1)
+    # an accepted polish with a mis-guessed active set is still an accepted polish (OSQP semantics), so "same optimum"
+    # holds for almost all, not all, instances
+    d = np.max(np.abs(o2["uPred"][pol] - oc["uPred"][pol]), axis=(1, 2))
+    assert np.mean(d <= 1e-6) > 0.99 and np.max(d) <= 5e-2
+    wp = workloads.planner_batch(B, N=20, seed=2)
+    ep = workloads.make_solver(wp)
+    op = ep.solve(wp["x0"], wp["u_prev"], None, wp["curv_s"], wp["u_old"], wp["max_ey"])
+    ep.close()
+    assert set(np.unique(op["status"])) <= {1, 2, 3, -2, -3}
+    sol = np.isin(op["status"], (1, 2, -2))
+    assert sol.mean() > 0.7
+    assert np.all(np.isnan(op["xPred"][~sol])) and np.all(np.isfinite(op["xPred"][sol]))
+    assert np.max(np.abs(op["xPred"][sol][:, 0, :] - wp["x0"][sol])) <= 5e-3
