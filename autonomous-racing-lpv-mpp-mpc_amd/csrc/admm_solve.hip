@@ -351,7 +351,8 @@ struct Solver {
     // row of each factor with 16-byte loads.  T0 = K_{k,pred}, T1 = C_pred^-1, T2 = G, T3 = C_pred^-T (row-major).
     // One elimination step: given the coupling block ko to the previously eliminated stage (whose C^-1 sits in
     // T1/T3), returns s = kd - G G' and l = G C_pred^-1.
-    __device__ __forceinline__ void schur_step(double *T, double ko, double kd, double &s, double &l) const {
+    struct SL { double s, l; };
+    __device__ __forceinline__ SL schur_step(double *T, double ko, double kd) const {
         double *const T0 = T, *const T2 = T + 128;
         const double2 *const rowi0 = reinterpret_cast<const double2 *>(T0 + ti * 8);
         const double2 *const rowj1 = reinterpret_cast<const double2 *>(T + 64 + tj * 8);
@@ -365,13 +366,14 @@ struct Solver {
         for (int t = 0; t < 4; ++t) { const double2 a = rowi0[t], b = rowj1[t]; g += a.x * b.x; g += a.y * b.y; }
         T2[lane] = g;
         wsync();
-        s = kd; l = 0.0;
+        double s = kd, l = 0.0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {                       // S = Kd - G G' ;  L = G C^-1 = sum_t G[i][t] Cinv^T[j][t]
             const double2 a = rowi2[t], b = rowj2[t], cT = rowj3[t];
             s -= a.x * b.x; s -= a.y * b.y;
             l += a.x * cT.x; l += a.y * cT.y;
         }
+        return SL{s, l};
     }
     // publish W = C^-1 (row-major in T1, transposed in T3) and return S^-1 = C^-T C^-1
     __device__ __forceinline__ double publish_and_invert(double *T, double w) const {
@@ -395,7 +397,7 @@ struct Solver {
                 const int k = wv ? N - p : p;
                 const double kd = kd_block(k, sig);
                 double s = kd, l = 0.0;
-                if (p >= 1) schur_step(T, wv ? ko_up(k) : ko_down(k), kd, s, l);
+                if (p >= 1) { const SL r = schur_step(T, wv ? ko_up(k) : ko_down(k), kd); s = r.s; l = r.l; }
                 const double w = chol_inverse(s);
                 const double sinv = publish_and_invert(T, w);
                 const double lt = (p & 1) ? __shfl(l, tj * 8 + ti) : l;      // odd chain positions keep L transposed
@@ -406,8 +408,8 @@ struct Solver {
             // ---- middle stage: S_m = K_mm - G_t G_t' - G_b G_b' with both neighbours' C^-1 (wave 0) ----
             if (wv == 0) {
                 const double kd = kd_block(kMid, sig);
-                double s = kd, lt = 0.0, lb = 0.0, s2;
-                if (kP0 >= 1) { schur_step(T, ko_down(kMid), kd, s, lt); }
+                double s = kd, lt = 0.0, lb = 0.0;
+                if (kP0 >= 1) { const SL r = schur_step(T, ko_down(kMid), kd); s = r.s; lt = r.l; }
                 if (kP1 >= 1) {
                     // second neighbour: reuse the step with wave 1's published C^-1 (its T1/T3), on wave 0's T0/T2
                     double *const Tb = XT + 256;
@@ -415,8 +417,8 @@ struct Solver {
                     // copy wave 1's C^-1 tiles next to our T0/T2 so that schur_step finds them at T+64 / T+192
                     T[64 + lane] = Tb[64 + lane]; T[192 + lane] = Tb[192 + lane];
                     wsync();
-                    schur_step(T, ko_up(kMid), s, s2, lb);
-                    s = s2;
+                    const SL r = schur_step(T, ko_up(kMid), s);
+                    s = r.s; lb = r.l;
                 }
                 const double w = chol_inverse(s);
                 rSm = publish_and_invert(T, w);
@@ -435,7 +437,7 @@ struct Solver {
         for (int k = 0; k <= N; ++k) {
             const double kd = kd_block(k, sig);
             double s = kd, l = 0.0;
-            if (k >= 1) schur_step(T, ko_down(k), kd, s, l);
+            if (k >= 1) { const SL r = schur_step(T, ko_down(k), kd); s = r.s; l = r.l; }
             const double w = chol_inverse(s);
             const double sinv = publish_and_invert(T, w);
             if constexpr (kReg) {
@@ -894,7 +896,7 @@ struct Solver {
             if (checked || adapt) {
                 R = residuals(X, Zd, Zb, Yd, Yb);
                 pri_res = R.pri; dua_res = R.dua;
-                if (checked && check_termination(R, false, status)) break;
+                if (checked) { status = check_termination(R, false); if (status != LPVMPC_UNSOLVED_) break; }
                 if (adapt) {
                     const double rn = rho_estimate(R, rho);
                     if (rn > rho * cfg.rho_tol || rn < rho / cfg.rho_tol) { set_rho(rn); factor(sigma); }
@@ -905,13 +907,13 @@ struct Solver {
         if (iter > cfg.max_iter) iter = cfg.max_iter;
         if (!checked) {
             R = residuals(X, Zd, Zb, Yd, Yb); pri_res = R.pri; dua_res = R.dua;
-            check_termination(R, false, status);
+            status = check_termination(R, false);
         }
         const bool has_sol = !(status == LPVMPC_PRIMAL_INFEASIBLE_ || status == LPVMPC_PRIMAL_INFEASIBLE_INACC_ ||
                                status == LPVMPC_DUAL_INFEASIBLE_ || status == LPVMPC_DUAL_INFEASIBLE_INACC_ ||
                                status == LPVMPC_NON_CVX_);
         if (has_sol) obj = objective(X);
-        if (status == LPVMPC_UNSOLVED_) { if (!check_termination(R, true, status)) status = LPVMPC_MAX_ITER_; }
+        if (status == LPVMPC_UNSOLVED_) { status = check_termination(R, true); if (status == LPVMPC_UNSOLVED_) status = LPVMPC_MAX_ITER_; }
         if (status == LPVMPC_PRIMAL_INFEASIBLE_ || status == LPVMPC_PRIMAL_INFEASIBLE_INACC_) obj = kInfty;
         if (status == LPVMPC_DUAL_INFEASIBLE_ || status == LPVMPC_DUAL_INFEASIBLE_INACC_) obj = -kInfty;
 
@@ -920,7 +922,8 @@ struct Solver {
         if (st_out) save_duals(st_out);        // ADMM duals (the polish below reuses the y arrays)
         // ---------- polish ----------
         if (cfg.polish && status == LPVMPC_SOLVED_) {
-            status_polish = polish(pri_res, dua_res, obj);
+            const PolishOut po = polish(pri_res, dua_res, obj);
+            status_polish = po.flag; pri_res = po.pri; dua_res = po.dua; obj = po.obj;
             if (st_out && status_polish == 1) save_duals(st_out);
         }
 
@@ -963,20 +966,20 @@ struct Solver {
                          LPVMPC_DUAL_INFEASIBLE_INACC_ = 4, LPVMPC_MAX_ITER_ = -2, LPVMPC_PRIMAL_INFEASIBLE_ = -3,
                          LPVMPC_DUAL_INFEASIBLE_ = -4, LPVMPC_NON_CVX_ = -7, LPVMPC_UNSOLVED_ = -10;
 
-    // OSQP check_termination
-    __device__ __forceinline__ bool check_termination(const Res &R, bool approx, int &status) {
+    // OSQP check_termination: returns the status reached, or LPVMPC_UNSOLVED_ when the iteration must go on
+    __device__ __forceinline__ int check_termination(const Res R, bool approx) {
         double ea = cfg.eps_abs, er = cfg.eps_rel, epi = cfg.eps_prim_inf, edi = cfg.eps_dual_inf;
-        if (R.pri > kInfty || R.dua > kInfty) { status = LPVMPC_NON_CVX_; return true; }
+        if (R.pri > kInfty || R.dua > kInfty) return LPVMPC_NON_CVX_;
         if (approx) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
         bool prc = false, drc = false, pic = false, dic = false;
         const double ep = ea + er * fmax(R.nz, R.nAx);
         if (R.pri < ep) prc = true; else pic = primal_infeasible(epi);
         const double ed = ea + er * fmax(R.nq, fmax(R.nAty, R.nPx));
         if (R.dua < ed) drc = true; else dic = dual_infeasible(edi);
-        if (prc && drc) { status = approx ? LPVMPC_SOLVED_INACC_ : LPVMPC_SOLVED_; return true; }
-        if (pic) { status = approx ? LPVMPC_PRIMAL_INFEASIBLE_INACC_ : LPVMPC_PRIMAL_INFEASIBLE_; return true; }
-        if (dic) { status = approx ? LPVMPC_DUAL_INFEASIBLE_INACC_ : LPVMPC_DUAL_INFEASIBLE_; return true; }
-        return false;
+        if (prc && drc) return approx ? LPVMPC_SOLVED_INACC_ : LPVMPC_SOLVED_;
+        if (pic) return approx ? LPVMPC_PRIMAL_INFEASIBLE_INACC_ : LPVMPC_PRIMAL_INFEASIBLE_;
+        if (dic) return approx ? LPVMPC_DUAL_INFEASIBLE_INACC_ : LPVMPC_DUAL_INFEASIBLE_;
+        return LPVMPC_UNSOLVED_;
     }
     // OSQP compute_rho_estimate (scaled-space norms)
     __device__ __forceinline__ double rho_estimate(const Res &R, double rho) const {
@@ -989,7 +992,8 @@ struct Solver {
     // ---- polish (OSQP polish.c) on the reduced form ----------------------------------------------
     // active rows carry weight 1/delta in K_pol = P + delta I + A_act' A_act / delta; W > 0 marks
     // upper-active, W < 0 lower-active rows (|W| = 1/delta), W = 0 inactive.
-    __device__ __forceinline__ int polish(double &pri_res, double &dua_res, double &obj) {
+    struct PolishOut { int flag; double pri, dua, obj; };
+    __device__ __forceinline__ PolishOut polish(double pri_res, double dua_res, double obj) {
         const double delta = cfg.delta, dinv = 1.0 / cfg.delta;
         for (int e = tid; e < NS * 8; e += kStride) {
             const int k = e >> 3, r = e & 7;
@@ -1068,18 +1072,21 @@ struct Solver {
                           (R.dua < dua_res && pri_res < 1e-10);
         if (good) {
             for (int e = tid; e < NS * 8; e += kStride) X[e] = DX[e];
-            pri_res = R.pri; dua_res = R.dua; obj = pobj;
             sync();
-            return 1;
+            return PolishOut{1, R.pri, R.dua, pobj};
         }
-        return -1;
+        return PolishOut{-1, pri_res, dua_res, obj};
     }
 };
 
 // waves per SIMD the kernel must allow: workgroups per CU are LDS-limited (4 at N = 20, 2 at N = 30 / 40), so only
 // the N <= 20 two-wavefront kernels need two waves per SIMD (<= 256 registers); the others may use up to 512
 template <int NT, int NW>
+#ifdef LPVMPC_FORCE_TWO_WAVES_PER_SIMD
+constexpr int min_waves_per_simd() { return NW; }      // diagnostic: provoke register spilling in the big-N kernels
+#else
 constexpr int min_waves_per_simd() { return (NW == 2 && NT <= 20) ? 2 : 1; }
+#endif
 
 template <int NX, int NT, int NW>
 __global__ void __launch_bounds__(64 * NW, (min_waves_per_simd<NT, NW>())) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
