@@ -56,12 +56,22 @@ class LpvMpcError(RuntimeError):
         self.code = code
 
 
+MAX_FILTER_ORDER = 8
+
+
+class HandoffConfig(C.Structure):
+    """Mirror of ``struct lpvmpc_handoff_config`` (include/lpvmpc.h)."""
+    _fields_ = [("interp_dt", _d), ("padlen", _i), ("order", _i), ("b", _d * (MAX_FILTER_ORDER + 1)), ("a", _d * (MAX_FILTER_ORDER + 1))]
+
+
 EXPORTS = ("lpvmpc_version", "lpvmpc_default_config", "lpvmpc_create", "lpvmpc_destroy", "lpvmpc_last_error",
            "lpvmpc_reserve", "lpvmpc_lpv_batch", "lpvmpc_estimate_abc_batch", "lpvmpc_solve_batch_AB",
            "lpvmpc_solve_batch", "lpvmpc_solve_batch_dev", "lpvmpc_last_kernel_ms", "lpvmpc_set_timing",
            "lpvmpc_kernel_time_stats", "lpvmpc_set_option",
            "lpvmpc_local_position_batch", "lpvmpc_global_position_batch", "lpvmpc_plant_step_batch",
-           "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read")
+           "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read",
+           "lpvmpc_handoff_default_config", "lpvmpc_handoff_length", "lpvmpc_handoff_operators", "lpvmpc_handoff_setup",
+           "lpvmpc_handoff_batch", "lpvmpc_cascade_init", "lpvmpc_cascade_tick", "lpvmpc_cascade_read")
 
 _lib = None
 
@@ -106,8 +116,22 @@ def load():
     lib.lpvmpc_cl_init.argtypes = [vp, _i, vp, _d, _d, _i, _i, _d, _d]
     lib.lpvmpc_cl_tick.argtypes = [vp, _i]
     lib.lpvmpc_cl_read.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.lpvmpc_handoff_default_config.argtypes = [P(HandoffConfig)]
+    lib.lpvmpc_handoff_default_config.restype = None
+    lib.lpvmpc_handoff_length.argtypes = [_i, _d, P(HandoffConfig)]
+    lib.lpvmpc_handoff_operators.argtypes = [_i, _d, P(HandoffConfig), vp, vp]
+    lib.lpvmpc_handoff_setup.argtypes = [vp, P(HandoffConfig)]
+    lib.lpvmpc_handoff_batch.argtypes = [vp, _i, vp, vp, vp, vp, vp]
+    lib.lpvmpc_cascade_init.argtypes = [vp, vp, _i, vp, vp, vp, _i, _d, _d, _d, _i, vp, _d, _d]
+    lib.lpvmpc_cascade_tick.argtypes = [vp, _i]
+    lib.lpvmpc_cascade_read.argtypes = [vp] + [vp] * 12
+    for name in ("lpvmpc_handoff_length", "lpvmpc_handoff_operators", "lpvmpc_handoff_setup", "lpvmpc_handoff_batch",
+                 "lpvmpc_cascade_init", "lpvmpc_cascade_tick", "lpvmpc_cascade_read"):
+        getattr(lib, name).restype = C.c_int
     for name in ("lpvmpc_local_position_batch", "lpvmpc_global_position_batch", "lpvmpc_plant_step_batch",
-                 "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read"):
+                 "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read",
+           "lpvmpc_handoff_default_config", "lpvmpc_handoff_length", "lpvmpc_handoff_operators", "lpvmpc_handoff_setup",
+           "lpvmpc_handoff_batch", "lpvmpc_cascade_init", "lpvmpc_cascade_tick", "lpvmpc_cascade_read"):
         getattr(lib, name).restype = C.c_int
     for name in ("lpvmpc_reserve", "lpvmpc_lpv_batch", "lpvmpc_estimate_abc_batch", "lpvmpc_solve_batch_AB",
                  "lpvmpc_solve_batch", "lpvmpc_solve_batch_dev", "lpvmpc_set_timing"):
@@ -119,6 +143,12 @@ def load():
 def default_config(kind):
     cfg = Config()
     load().lpvmpc_default_config(kind, C.byref(cfg))
+    return cfg
+
+
+def default_handoff_config():
+    cfg = HandoffConfig()
+    load().lpvmpc_handoff_default_config(C.byref(cfg))
     return cfg
 
 

@@ -235,6 +235,57 @@ class BatchedSolver:
         self._chk(self._lib.lpvmpc_cl_read(self._h, ptr(o["plant"]), ptr(o["local"]), ptr(o["cmd"]), ptr(o["iters"]), ptr(o["status"])))
         return o
 
+    # -- planner -> controller hand-off ------------------------------------------------
+    def handoff_setup(self, cfg=None):
+        """Build the resampling / filtering operators for this PLANNER handle; returns M (samples per My_Planning array)."""
+        cfg = cfg if cfg is not None else _ffi.default_handoff_config()
+        M = self._lib.lpvmpc_handoff_setup(self._h, C.byref(cfg))
+        self._chk(min(M, 0))
+        self._ho_M = M
+        return M
+
+    def handoff(self, xPred, SS, pose, want_sig=False):
+        """PMAIN:201-224,257-308 for a batch.  Returns dict(SS, pose, refs[, sig]); SS / pose are the carried state."""
+        N = self.N
+        x = f64(xPred).reshape(-1, N + 1, 5)
+        B = x.shape[0]
+        SS = f64(SS, (B, N + 1), "SS").copy(); pose = f64(pose, (B, 3), "pose").copy()
+        refs = np.empty((B, 5, self._ho_M)); sig = np.empty((B, 5, N)) if want_sig else None
+        self._chk(self._lib.lpvmpc_handoff_batch(self._h, B, ptr(x), ptr(SS), ptr(pose), ptr(sig), ptr(refs)))
+        out = dict(SS=SS, pose=pose, refs=refs)
+        if want_sig:
+            out["sig"] = sig
+        return out
+
+    # -- planner + controller + plant cascade (configs[4]) ------------------------------------------------
+    def cascade_init(self, planner, plant0, cmd0, uPred0, lap0=1, half_width=0.3, slack=0.15, plan_max_ey=0.2, q9_swap=True,
+                     n_sub=(7, 7, 6), dt_sim=0.005, mu_sim=0.05):
+        p0 = f64(plant0).reshape(-1, 8)
+        B = p0.shape[0]
+        c0 = f64(cmd0, (B, 2), "cmd0"); u0 = f64(uPred0, (B, self.N, 2), "uPred0")
+        ns = np.ascontiguousarray(n_sub, np.int32)
+        if ns.shape != (3,):
+            raise ValueError("n_sub must have 3 entries")
+        self._chk(self._lib.lpvmpc_cascade_init(self._h, planner._h, B, ptr(p0), ptr(c0), ptr(u0), int(lap0), float(half_width),
+                                                float(slack), float(plan_max_ey), 1 if q9_swap else 0, ptr(ns), float(dt_sim), float(mu_sim)))
+        self._cas = (B, planner.N, planner._ho_M)
+        self._cas_planner = planner                      # keep the planner handle alive as long as the cascade
+
+    def cascade_tick(self, n_ticks=1):
+        self._chk(self._lib.lpvmpc_cascade_tick(self._h, int(n_ticks)))
+
+    def cascade_read(self, full=True):
+        B, Np, M = self._cas
+        o = dict(plant=np.empty((B, 8)), local=np.empty((B, 6)), cmd=np.empty((B, 2)), iters=np.empty(B, np.int32),
+                 status=np.empty(B, np.int32), lap=np.empty(B, np.int32), lap_tick=np.empty(B, np.int32),
+                 plan_iters=np.empty(B, np.int32), plan_status=np.empty(B, np.int32), ticks=np.empty(2, np.int32))
+        if full:
+            o.update(refs=np.empty((B, 5, M)), plan_xPred=np.empty((B, Np + 1, 5)))
+        self._chk(self._lib.lpvmpc_cascade_read(self._h, ptr(o["plant"]), ptr(o["local"]), ptr(o["cmd"]), ptr(o["iters"]), ptr(o["status"]),
+                                                ptr(o["lap"]), ptr(o["lap_tick"]), ptr(o.get("refs")), ptr(o.get("plan_xPred")),
+                                                ptr(o["plan_iters"]), ptr(o["plan_status"]), ptr(o["ticks"])))
+        return o
+
     # -- device-pointer entry point (torch tensors or raw integers) -----------------------------------
     def solve_dev(self, B, x0, u_prev, vel_ref, curv_s, u_old, max_ey, xPred, uPred, status=None, iters=None,
                   resid=None, polish=None, cf_new=60.0, lap=1, stream=0):
@@ -247,6 +298,18 @@ class BatchedSolver:
                                                    dp(u_old), dp(max_ey), float(cf_new), int(lap), dp(xPred),
                                                    dp(uPred), dp(status), dp(iters), dp(resid), dp(polish),
                                                    C.c_void_p(int(stream))))
+
+
+def handoff_operators(N, dt, cfg=None):
+    """Host-only: the hand-off operators for an N-sample planner horizon at period dt (no device needed).
+    Returns (W, FW), each (M, N): refs = W @ signal for x, y, yaw, vx and FW @ curvature (PMAIN:257-280)."""
+    lib = _ffi.load()
+    cfg = cfg if cfg is not None else _ffi.default_handoff_config()
+    M = lib.lpvmpc_handoff_length(int(N), float(dt), C.byref(cfg))
+    _ffi.check(None, min(M, 0))
+    W = np.empty((M, int(N))); FW = np.empty((M, int(N)))
+    _ffi.check(None, min(lib.lpvmpc_handoff_operators(int(N), float(dt), C.byref(cfg), ptr(W), ptr(FW)), 0))
+    return W, FW
 
 
 # =====================================================================================================

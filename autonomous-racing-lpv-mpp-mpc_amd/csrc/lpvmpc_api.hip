@@ -11,41 +11,11 @@
 #include <string>
 #include <vector>
 
-#include "lpvmpc.h"
-#include "lpvmpc_device.hpp"
-
-using lpvmpc::DevCfg;
-using lpvmpc::SolveArgs;
+#include "lpvmpc_handle.hpp"
 
 static thread_local std::string g_last_error;
 
-struct lpvmpc_handle {
-    lpvmpc_config cfg;
-    DevCfg dev;
-    DevCfg *d_cfg;           // device copy of dev (kernels read the configuration through this pointer)
-    int nx, nb;
-    int cap;                 // workspace capacity (instances)
-    // device workspace
-    double *d_x0, *d_uprev, *d_vel, *d_curv, *d_uold, *d_maxey, *d_AB, *d_states, *d_xPred, *d_uPred, *d_resid;
-    double *d_xlast, *d_delta;
-    double *d_state;         // warm-start state [cap][3][8(N+1)] (opt-in)
-    int warm_mode, state_valid_B;   // 0 off (default); instances whose state is valid from the previous solve
-    // closed-loop fleet (lpvmpc_cl_*): plant [B][8], local state [B][6], command [B][2] and scratch
-    double *cl_plant, *cl_local, *cl_cmd;
-    int cl_B, cl_first_it, cl_q9, cl_ticks;
-    double cl_hw, cl_slack;
-    lpvmpc::PlantCfg cl_pc;
-    int32_t *d_status, *d_iters, *d_polish;
-    hipStream_t stream;
-    std::vector<hipEvent_t> ev0, ev1;   // ring of event pairs around the solve-kernel launches
-    int ev_count;                       // pairs recorded since timing was (re)enabled
-    bool timing;
-    int force_generic;                  // 1: always use the run-time-horizon kernel (validation)
-    double last_ms;
-    std::string err;
-};
-
-static int fail(lpvmpc_handle *h, int code, const char *fmt, ...) {
+int lpvmpc_fail(lpvmpc_handle *h, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -55,11 +25,6 @@ static int fail(lpvmpc_handle *h, int code, const char *fmt, ...) {
     g_last_error = buf;
     return code;
 }
-#define HIP_TRY(h, expr)                                                                            \
-    do {                                                                                            \
-        hipError_t e_ = (expr);                                                                     \
-        if (e_ != hipSuccess) return fail(h, LPVMPC_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
 
 extern "C" int lpvmpc_version(void) { return LPVMPC_VERSION; }
 
@@ -139,6 +104,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->d_xPred = h->d_uPred = h->d_resid = h->d_xlast = h->d_delta = nullptr;
     h->d_status = h->d_iters = h->d_polish = nullptr; h->d_state = nullptr; h->warm_mode = 0; h->state_valid_B = 0;
     h->cl_plant = h->cl_local = h->cl_cmd = nullptr; h->cl_B = 0; h->cl_first_it = 1; h->cl_q9 = 1; h->cl_ticks = 0;
+    h->d_Wop = h->d_FWop = nullptr; h->ho_M = 0; h->cascade = nullptr; h->cascade_prefetch = 1;
     DevCfg &d = h->dev;
     std::memset(&d, 0, sizeof(d));
     d.kind = cfg->kind; d.N = cfg->N; d.track_rows = cfg->track_rows; d.max_iter = cfg->max_iter;
@@ -178,6 +144,9 @@ extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
     if (h->cl_plant) (void)hipFree(h->cl_plant);
     if (h->cl_local) (void)hipFree(h->cl_local);
     if (h->cl_cmd) (void)hipFree(h->cl_cmd);
+    if (h->cascade) lpvmpc_cascade_free(h);
+    if (h->d_Wop) (void)hipFree(h->d_Wop);
+    if (h->d_FWop) (void)hipFree(h->d_FWop);
     if (h->d_cfg) (void)hipFree(h->d_cfg);
     for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
@@ -194,6 +163,7 @@ extern "C" int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t val
         h->warm_mode = value; h->state_valid_B = 0; return LPVMPC_OK;
     }
     if (std::strcmp(name, "kernel_variant") == 0) { if (value < 0 || value > 2) return fail(h, LPVMPC_E_ARG, "kernel_variant must be 0, 1 or 2"); h->force_generic = value; return LPVMPC_OK; }
+    if (std::strcmp(name, "cascade_prefetch") == 0) { h->cascade_prefetch = value != 0 ? 1 : 0; return LPVMPC_OK; }   // read by lpvmpc_cascade_init
     return fail(h, LPVMPC_E_ARG, "lpvmpc_set_option: unknown option '%s'", name);
 }
 
@@ -237,7 +207,7 @@ extern "C" double lpvmpc_last_kernel_ms(lpvmpc_handle *h) {
 }
 
 // ------------------------------------------------------------------------------------------------
-static int need_track(lpvmpc_handle *h, const char *who) {
+int lpvmpc_need_track(lpvmpc_handle *h, const char *who) {
     if (h->cfg.track_rows < 1) return fail(h, LPVMPC_E_ARG, "%s: the handle was created without a track table", who);
     return LPVMPC_OK;
 }
@@ -248,7 +218,7 @@ static int launch_lpv(lpvmpc_handle *h, int B, const double *x0, const double *u
     return LPVMPC_OK;
 }
 
-static int launch_solve_timed(lpvmpc_handle *h, const SolveArgs &a, hipStream_t st) {
+int lpvmpc_launch_solve_timed(lpvmpc_handle *h, const SolveArgs &a, hipStream_t st) {
     const int slot = h->ev_count % kEventRing;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0[slot], st));
     HIP_TRY(h, lpvmpc::launch_solve(h->dev, h->d_cfg, a, st, h->force_generic));
@@ -256,26 +226,24 @@ static int launch_solve_timed(lpvmpc_handle *h, const SolveArgs &a, hipStream_t 
     return LPVMPC_OK;
 }
 
-static int check_common(lpvmpc_handle *h, int B, const char *who) {
+int lpvmpc_check_common(lpvmpc_handle *h, int B, const char *who) {
     if (!h) return fail(nullptr, LPVMPC_E_ARG, "%s: handle is NULL", who);
     if (B <= 0) return fail(h, LPVMPC_E_ARG, "%s: B=%d", who, B);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     return ensure_ws(h, B);
 }
 
-#define H2D(dst, src, n) HIP_TRY(h, hipMemcpyAsync(dst, src, (n), hipMemcpyHostToDevice, st))
-#define D2H(dst, src, n) HIP_TRY(h, hipMemcpyAsync(dst, src, (n), hipMemcpyDeviceToHost, st))
 
 extern "C" int lpvmpc_lpv_batch(lpvmpc_handle *h, int32_t B, const double *x0, const double *u_prev,
                                 const double *vel_ref, const double *curv_s, double cf_new, int32_t lap,
                                 double *states, double *A, double *Bm) {
-    int rc = check_common(h, B, "lpvmpc_lpv_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_common(h, B, "lpvmpc_lpv_batch"); if (rc) return rc;
     const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
     if (!x0 || !u_prev) return fail(h, LPVMPC_E_ARG, "lpvmpc_lpv_batch: x0 / u_prev is NULL");
     if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_lpv_batch: controller needs vel_ref");
     if (ctrl && lap != 0 && !curv_s) return fail(h, LPVMPC_E_ARG, "lpvmpc_lpv_batch: controller with lap != 0 needs curv_ref");
     if (!ctrl && !curv_s) return fail(h, LPVMPC_E_ARG, "lpvmpc_lpv_batch: planner needs SS");
-    if ((ctrl && lap == 0) || !ctrl) { rc = need_track(h, "lpvmpc_lpv_batch"); if (rc) return rc; }
+    if ((ctrl && lap == 0) || !ctrl) { rc = lpvmpc_need_track(h, "lpvmpc_lpv_batch"); if (rc) return rc; }
     const size_t N = h->cfg.N, nx = h->nx, nb = h->nb, b = B;
     hipStream_t st = h->stream;
     H2D(h->d_x0, x0, b * nx * 8); H2D(h->d_uprev, u_prev, b * N * 2 * 8);
@@ -298,9 +266,9 @@ extern "C" int lpvmpc_lpv_batch(lpvmpc_handle *h, int32_t B, const double *x0, c
 
 extern "C" int lpvmpc_estimate_abc_batch(lpvmpc_handle *h, int32_t B, const double *xlast, const double *delta,
                                          double *A, double *Bm) {
-    int rc = check_common(h, B, "lpvmpc_estimate_abc_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_common(h, B, "lpvmpc_estimate_abc_batch"); if (rc) return rc;
     if (!xlast || !delta) return fail(h, LPVMPC_E_ARG, "lpvmpc_estimate_abc_batch: NULL input");
-    rc = need_track(h, "lpvmpc_estimate_abc_batch"); if (rc) return rc;
+    rc = lpvmpc_need_track(h, "lpvmpc_estimate_abc_batch"); if (rc) return rc;
     const size_t N = h->cfg.N, nx = h->nx, nb = h->nb, b = B;
     hipStream_t st = h->stream;
     H2D(h->d_xlast, xlast, b * N * 6 * 8); H2D(h->d_delta, delta, b * N * 8);
@@ -334,7 +302,7 @@ extern "C" int lpvmpc_solve_batch_AB(lpvmpc_handle *h, int32_t B, const double *
                                      const double *vel_ref, const double *u_old, const double *max_ey,
                                      double *xPred, double *uPred, int32_t *status, int32_t *iters, double *resid,
                                      int32_t *polish) {
-    int rc = check_common(h, B, "lpvmpc_solve_batch_AB"); if (rc) return rc;
+    int rc = lpvmpc_check_common(h, B, "lpvmpc_solve_batch_AB"); if (rc) return rc;
     const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
     if (!x0 || !A || !Bm) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_AB: x0 / A / B is NULL");
     if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_AB: controller needs vel_ref");
@@ -355,7 +323,7 @@ extern "C" int lpvmpc_solve_batch_AB(lpvmpc_handle *h, int32_t B, const double *
     SolveArgs a{B, h->d_x0, h->d_AB, ctrl ? h->d_vel : nullptr, u_old ? h->d_uold : nullptr, ctrl ? nullptr : h->d_maxey,
                 h->d_xPred, h->d_uPred, h->d_status, h->d_iters, h->d_polish, h->d_resid,
                 h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0, h->nx};
-    rc = launch_solve_timed(h, a, st); if (rc) return rc;
+    rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
     if (h->warm_mode) h->state_valid_B = B;
     return copy_out(h, B, xPred, uPred, status, iters, resid, polish, st);
 }
@@ -364,18 +332,18 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
                                       const double *vel_ref, const double *curv_s, const double *u_old,
                                       const double *max_ey, double cf_new, int32_t lap, double *xPred, double *uPred,
                                       int32_t *status, int32_t *iters, double *resid, int32_t *polish, void *stream) {
-    int rc = check_common(h, B, "lpvmpc_solve_batch_dev"); if (rc) return rc;
+    int rc = lpvmpc_check_common(h, B, "lpvmpc_solve_batch_dev"); if (rc) return rc;
     const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
     if (!x0 || !u_prev || !xPred || !uPred) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_dev: NULL x0 / u_prev / xPred / uPred");
     if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_dev: controller needs vel_ref");
     if (ctrl && lap != 0 && !curv_s) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_dev: controller with lap != 0 needs curv_ref");
     if (!ctrl && (!curv_s || !max_ey)) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_dev: planner needs SS and max_ey");
-    if ((ctrl && lap == 0) || !ctrl) { rc = need_track(h, "lpvmpc_solve_batch_dev"); if (rc) return rc; }
+    if ((ctrl && lap == 0) || !ctrl) { rc = lpvmpc_need_track(h, "lpvmpc_solve_batch_dev"); if (rc) return rc; }
     hipStream_t st = (hipStream_t)stream;
     rc = launch_lpv(h, B, x0, u_prev, vel_ref, curv_s, cf_new, lap, nullptr, h->d_AB, st); if (rc) return rc;
     SolveArgs a{B, x0, h->d_AB, ctrl ? vel_ref : nullptr, u_old, ctrl ? nullptr : max_ey, xPred, uPred, status, iters, polish, resid,
                 h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0, h->nx};
-    rc = launch_solve_timed(h, a, st); if (rc) return rc;
+    rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
     if (h->warm_mode) h->state_valid_B = B;
     return LPVMPC_OK;
 }
@@ -384,7 +352,7 @@ extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0,
                                   const double *vel_ref, const double *curv_s, const double *u_old,
                                   const double *max_ey, double cf_new, int32_t lap, double *xPred, double *uPred,
                                   int32_t *status, int32_t *iters, double *resid, int32_t *polish) {
-    int rc = check_common(h, B, "lpvmpc_solve_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_common(h, B, "lpvmpc_solve_batch"); if (rc) return rc;
     const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
     if (!x0 || !u_prev) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch: x0 / u_prev is NULL");
     if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch: controller needs vel_ref");
@@ -408,9 +376,9 @@ extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0,
 // caller-side helpers of the reference, batched on the device
 // ------------------------------------------------------------------------------------------------
 extern "C" int lpvmpc_local_position_batch(lpvmpc_handle *h, int32_t B, const double *xy_psi, double half_width, double slack, double *out) {
-    int rc = check_common(h, B, "lpvmpc_local_position_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_common(h, B, "lpvmpc_local_position_batch"); if (rc) return rc;
     if (!xy_psi || !out) return fail(h, LPVMPC_E_ARG, "lpvmpc_local_position_batch: NULL argument");
-    rc = need_track(h, "lpvmpc_local_position_batch"); if (rc) return rc;
+    rc = lpvmpc_need_track(h, "lpvmpc_local_position_batch"); if (rc) return rc;
     hipStream_t st = h->stream;
     // workspace reuse: inputs in d_xlast ([cap][N][6] >= [B][3]), outputs in d_states ([cap][N][nx] >= [B][4])
     H2D(h->d_xlast, xy_psi, (size_t)B * 3 * 8);
@@ -421,9 +389,9 @@ extern "C" int lpvmpc_local_position_batch(lpvmpc_handle *h, int32_t B, const do
 }
 
 extern "C" int lpvmpc_global_position_batch(lpvmpc_handle *h, int32_t B, const double *s_ey, double *out) {
-    int rc = check_common(h, B, "lpvmpc_global_position_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_common(h, B, "lpvmpc_global_position_batch"); if (rc) return rc;
     if (!s_ey || !out) return fail(h, LPVMPC_E_ARG, "lpvmpc_global_position_batch: NULL argument");
-    rc = need_track(h, "lpvmpc_global_position_batch"); if (rc) return rc;
+    rc = lpvmpc_need_track(h, "lpvmpc_global_position_batch"); if (rc) return rc;
     hipStream_t st = h->stream;
     H2D(h->d_xlast, s_ey, (size_t)B * 2 * 8);
     HIP_TRY(h, lpvmpc::launch_global_position(h->d_cfg, B, h->d_xlast, h->d_states, st));
@@ -432,17 +400,17 @@ extern "C" int lpvmpc_global_position_batch(lpvmpc_handle *h, int32_t B, const d
     return LPVMPC_OK;
 }
 
-static lpvmpc::PlantCfg plant_cfg(const lpvmpc_handle *h, int n_sub, double dt_sim, double mu_sim) {
+lpvmpc::PlantCfg lpvmpc_plant_cfg(const lpvmpc_handle *h, int n_sub, double dt_sim, double mu_sim) {
     lpvmpc::PlantCfg pc; pc.lf = h->cfg.lf; pc.lr = h->cfg.lr; pc.m = h->cfg.m; pc.Iz = h->cfg.Iz; pc.mu = mu_sim; pc.dt = dt_sim; pc.n_sub = n_sub;
     return pc;
 }
 
 extern "C" int lpvmpc_plant_step_batch(lpvmpc_handle *h, int32_t B, double *state, const double *u, int32_t n_sub, double dt_sim, double mu_sim) {
-    int rc = check_common(h, B, "lpvmpc_plant_step_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_common(h, B, "lpvmpc_plant_step_batch"); if (rc) return rc;
     if (!state || !u || n_sub < 1 || !(dt_sim > 0)) return fail(h, LPVMPC_E_ARG, "lpvmpc_plant_step_batch: bad argument");
     hipStream_t st = h->stream;
     H2D(h->d_xlast, state, (size_t)B * 8 * 8); H2D(h->d_states, u, (size_t)B * 2 * 8);
-    HIP_TRY(h, lpvmpc::launch_plant(B, h->d_xlast, h->d_states, plant_cfg(h, n_sub, dt_sim, mu_sim), st));
+    HIP_TRY(h, lpvmpc::launch_plant(B, h->d_xlast, h->d_states, lpvmpc_plant_cfg(h, n_sub, dt_sim, mu_sim), st));
     D2H(state, h->d_xlast, (size_t)B * 8 * 8);
     HIP_TRY(h, hipStreamSynchronize(st));
     return LPVMPC_OK;
@@ -451,11 +419,11 @@ extern "C" int lpvmpc_plant_step_batch(lpvmpc_handle *h, int32_t B, double *stat
 // ---- closed-loop fleet: controller in the lap-0 path-tracking branch of controllerMain.py ----------------
 extern "C" int lpvmpc_cl_init(lpvmpc_handle *h, int32_t B, const double *plant0, double half_width, double slack, int32_t q9_swap,
                               int32_t n_sub, double dt_sim, double mu_sim) {
-    int rc = check_common(h, B, "lpvmpc_cl_init"); if (rc) return rc;
+    int rc = lpvmpc_check_common(h, B, "lpvmpc_cl_init"); if (rc) return rc;
     if (h->cfg.kind != LPVMPC_KIND_CONTROLLER) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_init: controller handles only");
     if (h->cfg.N > 20) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_init: the reference's seed trajectories have 20 rows (N <= 20)");
     if (!plant0 || n_sub < 1 || !(dt_sim > 0)) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_init: bad argument");
-    rc = need_track(h, "lpvmpc_cl_init"); if (rc) return rc;
+    rc = lpvmpc_need_track(h, "lpvmpc_cl_init"); if (rc) return rc;
     if (h->cl_plant) { (void)hipFree(h->cl_plant); (void)hipFree(h->cl_local); (void)hipFree(h->cl_cmd); h->cl_plant = h->cl_local = h->cl_cmd = nullptr; }
     HIP_TRY(h, hipMalloc((void **)&h->cl_plant, (size_t)B * 8 * 8));
     HIP_TRY(h, hipMalloc((void **)&h->cl_local, (size_t)B * 6 * 8));
@@ -467,7 +435,7 @@ extern "C" int lpvmpc_cl_init(lpvmpc_handle *h, int32_t B, const double *plant0,
     H2D(h->d_vel, ones.data(), ones.size() * 8);
     HIP_TRY(h, hipStreamSynchronize(st));
     h->cl_B = B; h->cl_first_it = 1; h->cl_q9 = q9_swap != 0; h->cl_ticks = 0; h->cl_hw = half_width; h->cl_slack = slack;
-    h->cl_pc = plant_cfg(h, n_sub, dt_sim, mu_sim);
+    h->cl_pc = lpvmpc_plant_cfg(h, n_sub, dt_sim, mu_sim);
     h->state_valid_B = 0;
     return LPVMPC_OK;
 }
@@ -490,7 +458,7 @@ extern "C" int lpvmpc_cl_tick(lpvmpc_handle *h, int32_t n_ticks) {
         }
         SolveArgs a{B, x0, h->d_AB, h->d_vel, h->d_uold, nullptr, h->d_xPred, h->d_uPred, h->d_status, h->d_iters, h->d_polish, h->d_resid,
                     h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0, x0_stride};
-        int rc = launch_solve_timed(h, a, st); if (rc) return rc;
+        int rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
         if (h->warm_mode) h->state_valid_B = B;
         HIP_TRY(h, lpvmpc::launch_cl_command_plant(B, N, h->d_uPred, h->cl_cmd, h->cl_plant, h->cl_pc, st));
         h->cl_ticks++;

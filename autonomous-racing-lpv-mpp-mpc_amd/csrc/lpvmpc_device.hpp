@@ -73,4 +73,16 @@ hipError_t launch_cl_measure(const DevCfg *dcfg, int B, const double *plant, con
 hipError_t launch_cl_seed(int B, int N, const double *local_state, double *xlast, double *delta, hipStream_t s);
 hipError_t launch_cl_command_plant(int B, int N, const double *uPred, double *cmd, double *plant, PlantCfg pc, hipStream_t s);
 
+
+// planner -> controller hand-off and trajectory-tracking measurement (handoff.hip)
+#define LPVMPC_HANDOFF_MAX_N 64
+int handoff_length(int N, double dt, double interp_dt);
+hipError_t launch_plan_pose(const DevCfg *dcfg, int B, const double *xPred, double *SS, double *pose, double *sig, hipStream_t s);
+hipError_t launch_resample(int B, int N, int M, const double *WT, const double *FWT, const double *sig, double *refs, hipStream_t s);
+hipError_t launch_plan_first(const DevCfg *dcfg, int B, const double *plant, double hw, double slack, int q9_swap, double accel_rate,
+                             double *x0, double *xlast, double *delta, hipStream_t s);
+hipError_t launch_tt_measure(const DevCfg *dcfg, int B, int M, int tick, const double *plant, const double *cmd, const double *refs, int latch,
+                             double *vel, double *curv, double *ref0, int32_t *lap, int32_t *lap_tick, double *SS, double *local_state,
+                             double *u_old, hipStream_t s);
+
 }  // namespace lpvmpc

@@ -218,6 +218,71 @@ int lpvmpc_cl_init(lpvmpc_handle *h, int32_t B, const double *plant0, double hal
 int lpvmpc_cl_tick(lpvmpc_handle *h, int32_t n_ticks);
 int lpvmpc_cl_read(lpvmpc_handle *h, double *plant, double *local_state, double *cmd, int32_t *iters, int32_t *status);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Planner -> controller reference hand-off.  Replaces the post-processing in the planner node
+ *   plannerMain.py:201-224   s integration along the planned states, centre-line pose (Map.getGlobalPosition),
+ *                            xp / yp / yaw reconstruction, vel = vx, curv = wz / vx
+ *   plannerMain.py:257-280   scipy interp1d(kind='cubic') from N samples at dt to round(N dt / interp_dt) samples,
+ *                            scipy.signal.filtfilt(b, a, curvature, padlen)
+ *   plannerMain.py:303-308   the five My_Planning arrays x_d, y_d, psi_d, vx_d, curv_d (barc/msg/My_Planning.msg:1-6)
+ * Resampling and filtering are linear in the N samples, so they are applied as two dense operators built on the host:
+ * W (cubic not-a-knot spline evaluation) and FW = filtfilt o W. */
+#define LPVMPC_MAX_FILTER_ORDER 8
+typedef struct lpvmpc_handoff_config {
+    double  interp_dt;                          /* 0.033                                   PMAIN:257 */
+    int32_t padlen;                             /* 50                                      PMAIN:280 */
+    int32_t order;                              /* 4: signal.ellip(4, 0.01, 120, 0.125)    PMAIN:112 */
+    double  b[LPVMPC_MAX_FILTER_ORDER + 1];     /* numerator, order + 1 entries used */
+    double  a[LPVMPC_MAX_FILTER_ORDER + 1];     /* denominator */
+} lpvmpc_handoff_config;
+
+/* the reference's values, including the coefficients of its elliptic filter */
+void lpvmpc_handoff_default_config(lpvmpc_handoff_config *cfg);
+
+/* Number of resampled points M = round(N dt / interp_dt) (PMAIN:259), or LPVMPC_E_ARG when the configuration cannot
+ * work: like scipy's filtfilt (and so the reference's node) this refuses M <= padlen, i.e. N < 34 at the reference's rates. */
+int lpvmpc_handoff_length(int32_t N, double dt, const lpvmpc_handoff_config *cfg);
+
+/* Host-only (no device needed): the operators W and FW, each [M][N] row-major; returns M. */
+int lpvmpc_handoff_operators(int32_t N, double dt, const lpvmpc_handoff_config *cfg, double *W, double *FW);
+
+/* Build the operators for a PLANNER handle's (N, dt) and keep them on its device; returns M. */
+int lpvmpc_handoff_setup(lpvmpc_handle *planner, const lpvmpc_handoff_config *cfg);
+
+/* One hand-off for B planner solutions: xPred [B][N+1][5]; SS [B][N+1] and pose [B][3] = {Xlast, Ylast, Thetalast}
+ * are the node's carried state (in/out: SS is re-integrated and SS[0] = SS[1], pose = centre-line pose of stage 1);
+ * sig [B][5][N] (may be NULL) = xp, yp, yaw, vel, curv at the planner's rate; refs [B][5][M] = the My_Planning arrays. */
+int lpvmpc_handoff_batch(lpvmpc_handle *planner, int32_t B, const double *xPred, double *SS, double *pose, double *sig,
+                         double *refs);
+
+/* Planner + controller + plant cascade for a fleet of B vehicles in the racing phase (LapNumber >= 1), resident on the
+ * device.  `ctrl` is a controller handle with the trajectory-tracking tuning (Controller_TT, CMAIN:142-150), `planner` a
+ * planner handle on which lpvmpc_handoff_setup has been called.  Per controller tick (30 Hz):
+ *   - planner ticks 0 .. floor(2k/3) have run before controller tick k (20 Hz node; PMAIN:126-224,257-308: first tick
+ *     from the measured state with the seed trajectory of PMAIN:465-505, later ticks open loop from xPred[1]);
+ *   - measurement of the LapNumber >= 1 branch (CMAIN:176-182,198-248): yaw - 2 pi LapNumber wrapped, reference windows
+ *     [0:N] re-read from the latest message on every second tick only (`index` toggle), Body_Frame_Errors (CMAIN:495-506)
+ *     with dead-reckoned s, racing lap counter (CMAIN:268-272); uOld = last command (CMAIN:289-298);
+ *   - Controller_TT.LPVPrediction + solve from the measured state (CMAIN:361-363); command = uPred[0] (CMAIN:381-386);
+ *   - the plant advances n_sub[k % 3] steps of Simulator.f (7, 7, 6 steps of 5 ms = 100 ms per 3 ticks).
+ * plant0 [B][8], cmd0 [B][2] = {servo, motor} and uPred0 [B][N][2] (Controller_TT.uPred = Controller.uPred, CMAIN:336)
+ * describe the fleet at the lap event; lap0 >= 1.  half_width / slack: the map's, used by Map.getLocalPosition;
+ * plan_max_ey: the max_ey argument of the planner's solve (the ROS parameter /TrajectoryPlanner/halfWidth).  q9_swap: the planner's first x0 takes the map's (ey, epsi) in the
+ * (epsi, ey) slots as PMAIN:141 assigns them.  The two nodes run on their own HIP streams; with option
+ * "cascade_prefetch" = 1 (default; set on `ctrl` before init) a planner tick is enqueued as soon as its message buffer is
+ * free, so that it overlaps the controller ticks that still use the previous message -- results do not change.
+ * lpvmpc_cascade_tick enqueues n_ticks controller ticks without synchronising; lpvmpc_cascade_read synchronises and copies
+ * (any pointer may be NULL): plant [B][8], local_state [B][6], cmd [B][2], ctrl_iters / ctrl_status [B], lap / lap_tick [B]
+ * (lap counter and the controller tick of the last lap event), refs [B][5][M] and plan_xPred [B][Np+1][5] / plan_iters /
+ * plan_status [B] of the most recent planner tick, ticks [2] = {controller ticks, planner ticks} enqueued so far. */
+int lpvmpc_cascade_init(lpvmpc_handle *ctrl, lpvmpc_handle *planner, int32_t B, const double *plant0, const double *cmd0,
+                        const double *uPred0, int32_t lap0, double half_width, double slack, double plan_max_ey,
+                        int32_t q9_swap, const int32_t *n_sub, double dt_sim, double mu_sim);
+int lpvmpc_cascade_tick(lpvmpc_handle *ctrl, int32_t n_ticks);
+int lpvmpc_cascade_read(lpvmpc_handle *ctrl, double *plant, double *local_state, double *cmd, int32_t *ctrl_iters,
+                        int32_t *ctrl_status, int32_t *lap, int32_t *lap_tick, double *refs, double *plan_xPred,
+                        int32_t *plan_iters, int32_t *plan_status, int32_t *ticks);
+
 #ifdef __cplusplus
 }
 #endif

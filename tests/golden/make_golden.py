@@ -193,10 +193,183 @@ def save_cases(name, cases):
     print("wrote %s.npz (%d cases)" % (name, len(cases)))
 
 
+def gen_handoff(CTRL, PLAN, TRACK, UTIL):
+    """planner -> controller hand-off (PMAIN:201-224,257-280) and the planner + controller
+    cascade (CMAIN:198-283,337-363,381-386).  The glue of the two main() loops is restated here (it cannot be
+    imported); every function it calls is the reference's own (Map, Curvature, the two MPC classes, Simulator) or
+    scipy's, which is what the reference itself calls."""
+    import vehicleSimulator as SIM
+    from scipy import signal
+    from scipy.interpolate import interp1d
+    lsh = make_map(TRACK, "L_shape")
+    table = np.array(lsh.PointAndTangent)
+    Np, dtp, HW = 40, 0.05, 0.2                           # MAIN_LAUNCH.launch:38-47 (N = 40, 20 Hz, halfWidth 0.2)
+    b_f, a_f = signal.ellip(4, 0.01, 120, 0.125)          # PMAIN:112
+    n33 = int(np.around(Np * dtp / 0.033))
+
+    class PlannerNode(object):                            # state of plannerMain.main()
+        def __init__(self):
+            self.P = PLAN.LPV_MPC_Planner(PLAN_Q, PLAN_R, PLAN_dR, PLAN_L, Np, dtp, lsh, "OSQP")
+            self.first = 1
+            self.SS = np.zeros(Np + 1)
+            self.last = [0.0, 0.0, 0.0]
+            self.log = []
+
+        def tick(self, local_state):
+            P = self.P
+            if self.first == 1:
+                x0 = np.array(local_state, float)
+                xx, uu = lpv_ref.plan_seed_vectors(Np, x0, 0.2, dtp)
+                P.solve(x0, xx, uu, 0, 0, 0, self.first, HW)
+                self.first += 1
+            else:
+                S, A_L, B_L, C_L = P.LPVPrediction(P.xPred[1, :], self.SS, P.uPred)
+                P.solve(P.xPred[1, :], 0, 0, A_L, B_L, C_L, self.first, HW)
+            P.OldSteering.append(P.uPred[0, 0]); P.OldAccelera.append(P.uPred[0, 1])
+            rec = dict(xPred=np.array(P.xPred), uPred=np.array(P.uPred), SS_in=self.SS.copy(), pose_in=np.array(self.last),
+                       iters=CAPTURE[-1]["iter"], status=CAPTURE[-1]["status_val"])
+            SS = self.SS
+            Xref = np.zeros(Np + 1); Yref = np.zeros(Np + 1); Th = np.zeros(Np + 1)
+            Xref[0], Yref[0], Th[0] = self.last
+            for j in range(Np):
+                cv = UTIL.Curvature(SS[j], lsh.PointAndTangent)
+                SS[j + 1] = (SS[j] + ((P.xPred[j, 0] * np.cos(P.xPred[j, 4]) - P.xPred[j, 1] * np.sin(P.xPred[j, 4]))
+                                      / (1 - P.xPred[j, 3] * cv)) * dtp)
+                Xref[j + 1], Yref[j + 1], Th[j + 1] = lsh.getGlobalPosition(SS[j + 1], 0.0)
+            SS[0] = SS[1]
+            self.last = [Xref[1], Yref[1], Th[1]]
+            yaw = np.zeros(Np); xp = np.zeros(Np); yp = np.zeros(Np)
+            for i in range(Np):
+                yaw[i] = Th[i] + P.xPred[i, 4]
+                xp[i] = Xref[i] - P.xPred[i, 3] * np.sin(yaw[i])
+                yp[i] = Yref[i] + P.xPred[i, 3] * np.cos(yaw[i])
+            vel = np.array(P.xPred[0:Np, 0]); curv = np.array(P.xPred[0:Np, 2] / P.xPred[0:Np, 0])
+            t50 = np.linspace(0, Np * dtp, num=Np, endpoint=True)
+            t33 = np.linspace(0, Np * dtp, num=n33, endpoint=True)
+            refs = [interp1d(t50, v, kind="cubic")(t33) for v in (xp, yp, yaw, vel, curv)]
+            refs[4] = signal.filtfilt(b_f, a_f, refs[4], padlen=50)
+            rec.update(SS_out=SS.copy(), pose_out=np.array(self.last), sig=np.array([xp, yp, yaw, vel, curv]), refs=np.array(refs))
+            self.log.append(rec)
+            return np.array(refs)
+
+    # ---- (1) planner alone, open loop for 60 ticks (3 s: into and through the first corner) ----
+    node = PlannerNode()
+    for tick in range(60):
+        node.tick([1.0, 0.0, 0.0, 0.03, -0.02])
+    keys = ("xPred", "uPred", "SS_in", "pose_in", "SS_out", "pose_out", "sig", "refs", "iters", "status")
+    ho = {"plan_" + k: np.array([r[k] for r in node.log]) for k in keys}
+    ho.update(ellip_b=np.array(b_f), ellip_a=np.array(a_f), table=table, N=np.array(Np), dt=np.array(dtp))
+    # Body_Frame_Errors samples are cheap to pin exactly as well (CMAIN:495-506, with TRACK.wrap)
+    rng = np.random.default_rng(11)
+    bfe_in = np.column_stack([rng.uniform(-3, 3, 64), rng.uniform(-3, 3, 64), rng.uniform(-4, 4, 64), rng.uniform(-3, 3, 64),
+                              rng.uniform(-3, 3, 64), rng.uniform(-4, 4, 64), rng.uniform(0, 19, 64), rng.uniform(0.5, 4, 64),
+                              rng.normal(0, 0.2, 64), rng.uniform(-2, 2, 64)])
+    bfe_out = []
+    for r in bfe_in:
+        x, y, psi, xd, yd, psid, s0, vx, vy, cv = [float(v) for v in r]
+        ex = (x - xd) * np.cos(psid) + (y - yd) * np.sin(psid)
+        ey = -(x - xd) * np.sin(psid) + (y - yd) * np.cos(psid)
+        epsi = TRACK.wrap(psi - psid)
+        s = s0 + ((vx * np.cos(epsi) - vy * np.sin(epsi)) / (1 - ey * cv)) * (1.0 / 30)
+        bfe_out.append([s, ex, ey, epsi])
+    ho.update(bfe_in=bfe_in, bfe_out=np.array(bfe_out))
+    np.savez_compressed(os.path.join(HERE, "handoff.npz"), **ho)
+    print("wrote handoff.npz")
+
+    # ---- (2) cascade: lap-0 approach to the start line, lap event, then planner + Controller_TT + plant ----
+    # schedule (DESIGN.md section 7): controller tick k is preceded by planner ticks 0 .. floor(2k/3) (20 Hz against
+    # 30 Hz), the plant takes 7, 7, 6 steps of 5 ms after controller ticks 3j, 3j+1, 3j+2 (100 ms per 3 ticks);
+    # measurement = ground truth; the command is applied right after the solve, as in the f1 fixture.
+    N, dt = 20, 1.0 / 30
+    Qp, Rp, dRp = TUNINGS["path"]; Qr, Rr, dRr = TUNINGS["race"]
+    C0 = CTRL.PathFollowingLPV_MPC(Qp, Rp, dRp, N, 1, dt, lsh, "OSQP", 0, 0)
+    CT = CTRL.PathFollowingLPV_MPC(Qr, Rr, dRr, N, 1, dt, lsh, "OSQP", 0, 0)
+    sim = SIM.Simulator()
+    sim.x, sim.y, sim.yaw, sim.vx = -0.55, 0.02, 0.01, 1.0
+    cmd = [0.0, 0.0]; first_it = 1; LapNumber = 0; HalfTrack = 1; SS = 0.0; index = 0
+    L = lsh.TrackLength
+    pre = []
+    for tick in range(60):                                  # lap 0 until the reference's lap event fires
+        G_ = np.array([sim.vx, sim.vy, sim.psiDot, sim.x, sim.y, sim.yaw]); Lc = G_.copy()
+        if Lc[0] < 0.01:
+            Lc[0] = 0.01
+        Lc[4], Lc[3], Lc[5], inside = lsh.getLocalPosition(G_[3], G_[4], G_[5])
+        if HalfTrack == 1 and Lc[4] <= L / 4:              # CMAIN:254-259
+            HalfTrack = 0; LapNumber += 1; SS = 0
+            break
+        C0.OldSteering.append(cmd[0]); C0.OldAccelera.append(cmd[1]); C0.OldSteering.pop(0); C0.OldAccelera.pop(0)
+        if first_it < 10:
+            xx, uu = lpv_ref.ctrl_seed_vectors(Lc)
+            C0.solve(Lc[0:6], xx, uu, False, np.ones(N), 0, 0, 0, first_it); first_it += 1
+        else:
+            S, A_L, B_L, C_L = C0.LPVPrediction(Lc[0:6], C0.uPred, np.ones(N + 1), np.zeros(N), 60.0, 0)
+            C0.solve(S[0, :], S, C0.uPred, False, np.ones(N + 1), A_L, B_L, C_L, first_it)
+        CT.uPred = C0.uPred                                  # CMAIN:336
+        cmd = [float(C0.uPred[0, 0]), float(C0.uPred[0, 1])]
+        pre.append(tick)
+        for _ in range(7):
+            sim.f([cmd[1], cmd[0]])
+    assert LapNumber == 1 and len(pre) > 10, (LapNumber, len(pre))
+    # the tick on which the lap event fired continues in the LapNumber >= 1 branch (CMAIN:198 onwards is evaluated
+    # before the event, with LapNumber still 0, on that very tick; the fixture starts with the next measurement)
+    cas = dict(plant0=np.array([sim.x, sim.y, sim.vx, sim.vy, sim.ax, sim.ay, sim.yaw, sim.psiDot]), cmd0=np.array(cmd),
+               uPred0=np.array(CT.uPred), lap0=np.array(LapNumber), pre_ticks=np.array(len(pre)))
+    node = PlannerNode()
+    refs = None; plan_done = 0
+    K = 60
+    tr = {k: [] for k in ("plant", "local", "vel_ref", "curv_ref", "cmd", "iters", "status", "lap", "SS", "plan_ticks", "uPred", "xPred")}
+    nsub = (7, 7, 6)
+    for k in range(K):
+        G_ = np.array([sim.vx, sim.vy, sim.psiDot, sim.x, sim.y, sim.yaw]); Lc = G_.copy()
+        while plan_done < (2 * k) // 3 + 1:                 # planner node, own thread of time (PMAIN:137-141, Testing == 0)
+            pl = np.array([G_[0], G_[1], G_[2], 0.0, 0.0])
+            _s, pl[4], pl[3], _in = lsh.getLocalPosition(G_[3], G_[4], G_[5])
+            refs = node.tick(pl); plan_done += 1
+        if Lc[0] < 0.01:
+            Lc[0] = 0.01
+        G_[5] = G_[5] - 2 * np.pi * LapNumber               # CMAIN:200-202
+        G_[5] = TRACK.wrap(G_[5])
+        if index <= 0:                                      # CMAIN:219-235, max_window = 0
+            if index == 0:
+                Xv = refs[0][0:N]; Yv = refs[1][0:N]; Pv = refs[2][0:N]; Vv = refs[3][0:N]; Cv = refs[4][0:N]
+            x_ref = Xv[index:index + N]; y_ref = Yv[index:index + N]; yaw_ref = Pv[index:index + N]
+            vel_ref = Vv[index:index + N]; curv_ref = Cv[index:index + N]
+            index += 1
+        else:
+            index = 0
+        psid = yaw_ref[0]
+        ex = (G_[3] - x_ref[0]) * np.cos(psid) + (G_[4] - y_ref[0]) * np.sin(psid)     # Body_Frame_Errors, CMAIN:495-506
+        ey = -(G_[3] - x_ref[0]) * np.sin(psid) + (G_[4] - y_ref[0]) * np.cos(psid)
+        epsi = TRACK.wrap(G_[5] - psid)
+        s = SS + ((Lc[0] * np.cos(epsi) - Lc[1] * np.sin(epsi)) / (1 - ey * curv_ref[0])) * dt
+        Lc[4], Lc[5], Lc[3] = s, ey, epsi
+        SS = Lc[4]
+        if LapNumber >= 1 and abs(G_[3]) < 0.1 and Lc[4] >= (L - L / 10):             # CMAIN:268-272
+            LapNumber += 1; SS = 0
+        CT.OldSteering.append(cmd[0]); CT.OldAccelera.append(cmd[1]); CT.OldSteering.pop(0); CT.OldAccelera.pop(0)
+        S, A_L, B_L, C_L = CT.LPVPrediction(Lc[0:6], CT.uPred, vel_ref, curv_ref, 60, LapNumber)
+        CT.solve(Lc[0:6], 0.0, CT.uPred, False, vel_ref, A_L, B_L, C_L, first_it)
+        cmd = [float(CT.uPred[0, 0]), float(CT.uPred[0, 1])]
+        tr["plant"].append([sim.x, sim.y, sim.vx, sim.vy, sim.ax, sim.ay, sim.yaw, sim.psiDot]); tr["local"].append(Lc.copy())
+        tr["vel_ref"].append(np.array(vel_ref)); tr["curv_ref"].append(np.array(curv_ref)); tr["cmd"].append(list(cmd))
+        tr["iters"].append(CAPTURE[-1]["iter"]); tr["status"].append(CAPTURE[-1]["status_val"]); tr["lap"].append(LapNumber)
+        tr["SS"].append(SS); tr["plan_ticks"].append(plan_done); tr["uPred"].append(np.array(CT.uPred)); tr["xPred"].append(np.array(CT.xPred))
+        for _ in range(nsub[k % 3]):
+            sim.f([cmd[1], cmd[0]])
+    cas.update({"ctrl_" + k: np.array(v) for k, v in tr.items()})
+    cas.update({"plan_" + k: np.array([r[k] for r in node.log]) for k in ("xPred", "uPred", "refs", "iters", "status", "SS_out")})
+    cas.update(table=table)
+    np.savez_compressed(os.path.join(HERE, "cascade.npz"), **cas)
+    print("wrote cascade.npz")
+
+
 def main():
     warnings.simplefilter("ignore")
     CTRL, PLAN, TRACK, UTIL, tmp = import_reference()
     try:
+        if "handoff" in sys.argv[1:]:                       # regenerate only handoff.npz / cascade.npz
+            gen_handoff(CTRL, PLAN, TRACK, UTIL)
+            return
         # ---------------- track tables + curvature samples ----------------
         tracks = {}
         for shape in ("oval", "L_shape", "3110", "Euge_Track"):
@@ -395,6 +568,7 @@ def main():
         pt.update(cl_plant=np.array(tr_plant), cl_local=np.array(tr_local), cl_cmd=np.array(tr_cmd), cl_iter=np.array(tr_iter))
         np.savez_compressed(os.path.join(HERE, "plant_and_transforms.npz"), **pt)
         print("wrote plant_and_transforms.npz")
+        gen_handoff(CTRL, PLAN, TRACK, UTIL)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

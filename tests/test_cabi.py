@@ -45,6 +45,13 @@ def test_version_and_struct_layout(ffi, tmp_path):
     size, oq, orho, otrack = map(int, subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
     assert C.sizeof(ffi.Config) == size
     assert (ffi.Config.Q.offset, ffi.Config.rho.offset, ffi.Config.track.offset) == (oq, orho, otrack)
+    src.write_text('#include "lpvmpc.h"\n#include <stdio.h>\n#include <stddef.h>\n'
+                   'int main(){printf("%zu %zu %zu %zu\\n", sizeof(lpvmpc_handoff_config), offsetof(lpvmpc_handoff_config, order),'
+                   ' offsetof(lpvmpc_handoff_config, b), offsetof(lpvmpc_handoff_config, a)); return 0;}\n')
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    size, oo, ob, oa = map(int, subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
+    H = ffi.HandoffConfig
+    assert (C.sizeof(H), H.order.offset, H.b.offset, H.a.offset) == (size, oo, ob, oa)
 
 
 def test_default_config_matches_reference_constants(ffi):

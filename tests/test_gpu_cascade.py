@@ -1,0 +1,159 @@
+"""GPU: row f2 of SURVEY 8f -- planner -> controller hand-off and the planner + controller + plant cascade on the device,
+through the C ABI, against vectors made with the reference's own classes (tests/golden/handoff.npz, cascade.npz) and
+against the oracle cascade on a small fleet of different vehicles."""
+import numpy as np
+import pytest
+
+from tests._golden import load
+
+pytestmark = pytest.mark.gpu
+
+
+def planner(N=40):
+    import lpvmpc
+    from lpvmpc import workloads as W
+    mp = lpvmpc.Map("L_shape", 0.2)
+    eng = lpvmpc.BatchedSolver("planner", N, 0.05, W.PLAN_Q, W.PLAN_R, W.PLAN_dR, L_cf=W.PLAN_L, track=mp.PointAndTangent)
+    return eng, mp
+
+
+def controller_tt(mp):
+    import lpvmpc
+    from lpvmpc import workloads as W
+    Q, R, dR = W.CTRL_TUNINGS["race"]
+    return lpvmpc.BatchedSolver("controller", 20, 1 / 30.0, Q, R, dR, track=mp.PointAndTangent)
+
+
+def test_handoff_matches_reference_vectors():
+    """All 60 planner ticks of the fixture as one batch: carried state, planner-rate signals and the five My_Planning arrays."""
+    g = load("handoff")
+    eng, _ = planner()
+    assert eng.handoff_setup() == 61
+    o = eng.handoff(g["plan_xPred"], g["plan_SS_in"], g["plan_pose_in"], want_sig=True)
+    assert np.max(np.abs(o["SS"] - g["plan_SS_out"])) <= 1e-12
+    assert np.max(np.abs(o["pose"] - g["plan_pose_out"])) <= 1e-12
+    assert np.max(np.abs(o["sig"] - g["plan_sig"])) <= 1e-12
+    assert np.max(np.abs(o["refs"] - g["plan_refs"])) <= 1e-11
+    eng.close()
+
+
+def test_handoff_other_horizon_vs_oracle_and_bad_use():
+    import lpvmpc
+    from oracle import handoff_ref as H
+    eng, mp = planner(43)                                  # the commented-out launch block uses N = 43 (MAIN_LAUNCH.launch:24)
+    with pytest.raises(lpvmpc.LpvMpcError):
+        eng.handoff(np.zeros((1, 44, 5)), np.zeros((1, 44)), np.zeros((1, 3)))            # setup not called
+    M = eng.handoff_setup()
+    assert M == H.n_resampled(43, 0.05)
+    rng = np.random.default_rng(3)
+    B = 16
+    x = np.stack([rng.uniform(1, 3, (B, 44)), rng.normal(0, 0.05, (B, 44)), rng.normal(0, 0.5, (B, 44)),
+                  rng.normal(0, 0.08, (B, 44)), rng.normal(0, 0.1, (B, 44))], axis=2)
+    s0 = rng.uniform(0, 2.5 * mp.TrackLength, B)
+    SS = s0[:, None] + np.arange(44)[None, :] * 0.07
+    pose = np.array([H.get_global_position(mp.PointAndTangent, s, 0.0) for s in SS[:, 0]], float)
+    o = eng.handoff(x, SS, pose, want_sig=True)
+    for b in range(B):
+        SSr, last, xp, yp, yaw, vel, curv = H.planner_pose_refs(mp.PointAndTangent, x[b], SS[b], tuple(pose[b]), 0.05)
+        assert np.max(np.abs(o["SS"][b] - SSr)) <= 1e-11 and np.max(np.abs(o["pose"][b] - np.array(last))) <= 1e-11
+        assert np.max(np.abs(o["sig"][b] - np.array([xp, yp, yaw, vel, curv]))) <= 1e-11
+        assert np.max(np.abs(o["refs"][b] - H.resample_refs(xp, yp, yaw, vel, curv, 0.05))) <= 1e-10
+    eng.close()
+    short, _ = planner(30)
+    with pytest.raises(lpvmpc.LpvMpcError) as e:            # 45 resampled points <= padlen: scipy (and the reference's node) refuse
+        short.handoff_setup()
+    assert "padlen" in str(e.value)
+    short.close()
+
+
+def run_trace(prefetch, K):
+    c = load("cascade")
+    plan, mp = planner()
+    plan.handoff_setup()
+    ctrl = controller_tt(mp)
+    ctrl.set_option("cascade_prefetch", prefetch)
+    ctrl.cascade_init(plan, c["plant0"][None], c["cmd0"][None], c["uPred0"][None], lap0=int(c["lap0"]), half_width=mp.halfWidth,
+                      slack=mp.slack, plan_max_ey=0.2, q9_swap=True)
+    out = []
+    for k in range(K):
+        before = ctrl.cascade_read()
+        ctrl.cascade_tick(1)
+        after = ctrl.cascade_read()
+        out.append((before, after))
+    ctrl.close(); plan.close()
+    return c, out
+
+
+def test_cascade_matches_reference_trace():
+    """60 controller ticks / 40 planner ticks of one vehicle against the reference's classes in the same schedule.
+    The planner recursion is open loop and its QPs are solved to OSQP's eps = 1e-3 (polished when polish succeeds), so
+    round-off differences grow slowly along the trace: tolerances are stated per quantity."""
+    c, out = run_trace(0, 60)
+    worst = dict(plant=0.0, local=0.0, cmd=0.0, refs=0.0)
+    for k, (before, after) in enumerate(out):
+        worst["plant"] = max(worst["plant"], float(np.max(np.abs(before["plant"][0] - c["ctrl_plant"][k]))))
+        worst["local"] = max(worst["local"], float(np.max(np.abs(after["local"][0] - c["ctrl_local"][k]))))
+        worst["cmd"] = max(worst["cmd"], float(np.max(np.abs(after["cmd"][0] - c["ctrl_cmd"][k]))))
+        j = int(c["ctrl_plan_ticks"][k]) - 1
+        assert after["ticks"][0] == k + 1 and after["ticks"][1] == j + 1
+        worst["refs"] = max(worst["refs"], float(np.max(np.abs(after["refs"][0] - c["plan_refs"][j]))))
+        assert after["iters"][0] == c["ctrl_iters"][k] and after["status"][0] == c["ctrl_status"][k], k
+        assert after["plan_iters"][0] == c["plan_iters"][j] and after["plan_status"][0] == c["plan_status"][j], (k, j)
+        assert after["lap"][0] == c["ctrl_lap"][k]
+    print("cascade trace worst abs differences:", worst)
+    assert worst["plant"] <= 1e-5 and worst["local"] <= 1e-5 and worst["cmd"] <= 1e-4 and worst["refs"] <= 1e-4
+
+
+def test_cascade_prefetch_does_not_change_results():
+    _, a = run_trace(0, 24)
+    _, b = run_trace(1, 24)
+    for (_, x), (_, y) in zip(a, b):
+        for key in ("plant", "local", "cmd", "iters", "status", "lap"):
+            assert np.array_equal(x[key], y[key]), key
+
+
+def test_cascade_fleet_vs_oracle():
+    """8 different vehicles for 18 controller ticks (12 planner ticks) against the oracle cascade."""
+    from oracle import cascade_ref as CR
+    from lpvmpc import workloads as W
+    c = load("cascade")
+    rng = np.random.default_rng(9)
+    B = 8
+    plant0 = np.tile(c["plant0"], (B, 1))
+    plant0[:, 1] += rng.normal(0, 0.03, B); plant0[:, 2] += rng.uniform(-0.1, 0.3, B); plant0[:, 6] += rng.normal(0, 0.03, B)
+    cmd0 = np.tile(c["cmd0"], (B, 1)); uPred0 = np.tile(c["uPred0"], (B, 1, 1))
+    plan, mp = planner()
+    plan.handoff_setup()
+    ctrl = controller_tt(mp)
+    ctrl.cascade_init(plan, plant0, cmd0, uPred0, lap0=1, half_width=mp.halfWidth, slack=mp.slack, plan_max_ey=0.2, q9_swap=True)
+    ref = CR.CascadeRef(mp.PointAndTangent, W.CTRL_TUNINGS["race"], (W.PLAN_Q, W.PLAN_R, W.PLAN_dR, W.PLAN_L), plant0, cmd0, uPred0,
+                        half_width=mp.halfWidth, slack=mp.slack, plan_max_ey=0.2, nthreads=4)
+    same_iters = 0
+    for k in range(18):
+        ctrl.cascade_tick(1); ref.tick()
+        o = ctrl.cascade_read(full=False)
+        assert np.max(np.abs(o["plant"] - ref.plant)) <= 1e-5, k
+        assert np.max(np.abs(o["local"] - ref.local)) <= 1e-5, k
+        assert np.max(np.abs(o["cmd"] - ref.cmd)) <= 1e-4, k
+        assert np.array_equal(o["status"], ref.ctrl["status"])
+        same_iters += int(np.sum(o["iters"] == ref.ctrl["iters"]))
+    assert same_iters >= 0.95 * 18 * B
+    ctrl.close(); plan.close()
+
+
+def test_cascade_bad_arguments():
+    import lpvmpc
+    c = load("cascade")
+    plan, mp = planner()
+    ctrl = controller_tt(mp)
+    args = (c["plant0"][None], c["cmd0"][None], c["uPred0"][None])
+    with pytest.raises(lpvmpc.LpvMpcError):                 # hand-off operators missing
+        ctrl.cascade_init(plan, *args)
+    plan.handoff_setup()
+    with pytest.raises(lpvmpc.LpvMpcError):                 # lap 0 is the path-tracking phase (lpvmpc_cl_*)
+        ctrl.cascade_init(plan, *args, lap0=0)
+    with pytest.raises(lpvmpc.LpvMpcError):                 # roles swapped
+        plan.cascade_init(ctrl, *args)
+    with pytest.raises(lpvmpc.LpvMpcError):
+        ctrl.cascade_tick(1)                                # not initialised
+    ctrl.close(); plan.close()

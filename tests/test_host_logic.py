@@ -44,3 +44,45 @@ def test_shard_range_partitions_the_batch():
         assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 3, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# planner -> controller hand-off operators: host-side C++ of the product (no device needed) against scipy,
+# which is what the reference calls (PMAIN:112,257-280)
+# ---------------------------------------------------------------------------------------------------------
+def test_handoff_default_filter_is_the_references_elliptic_design():
+    from scipy import signal
+    from lpvmpc import _ffi
+    c = _ffi.default_handoff_config()
+    b, a = signal.ellip(4, 0.01, 120, 0.125)
+    assert (c.interp_dt, c.padlen, c.order) == (0.033, 50, 4)
+    assert np.max(np.abs(np.array(c.b[:5]) - b)) <= 1e-16 and np.max(np.abs(np.array(c.a[:5]) - a)) <= 1e-15
+
+
+@pytest.mark.parametrize("N,dt", [(40, 0.05), (43, 0.05), (64, 0.033), (36, 0.05)])
+def test_handoff_operators_match_scipy(N, dt):
+    from scipy import signal
+    from scipy.interpolate import interp1d
+    from lpvmpc import api
+    from oracle import handoff_ref as H
+    W, FW = api.handoff_operators(N, dt)
+    M = H.n_resampled(N, dt)
+    assert W.shape == FW.shape == (M, N)
+    b, a = H.ellip_coefficients()
+    t50 = np.linspace(0, N * dt, N); t33 = np.linspace(0, N * dt, M)
+    rng = np.random.default_rng(N)
+    for _ in range(8):
+        x = np.cumsum(rng.normal(0, 1, N))
+        r = interp1d(t50, x, kind="cubic")(t33)
+        assert np.max(np.abs(W @ x - r)) <= 1e-12 * max(1.0, np.max(np.abs(x)))
+        assert np.max(np.abs(FW @ x - signal.filtfilt(b, a, r, padlen=50))) <= 1e-11 * max(1.0, np.max(np.abs(x)))
+    dc = (np.sum(b) / np.sum(a)) ** 2                      # even-order elliptic design: -0.01 dB at DC, applied twice
+    assert np.max(np.abs(W.sum(axis=1) - 1)) <= 1e-13 and np.max(np.abs(FW.sum(axis=1) - dc)) <= 1e-11
+
+
+def test_handoff_refuses_what_scipy_refuses():
+    import lpvmpc
+    from lpvmpc import api
+    with pytest.raises(lpvmpc.LpvMpcError) as e:            # N = 30 at 20 Hz -> 45 samples <= padlen 50 (filtfilt raises ValueError)
+        api.handoff_operators(30, 0.05)
+    assert "padlen" in str(e.value)
