@@ -99,6 +99,8 @@ class BatchedSolver:
         if not self._h:
             msg = lib.lpvmpc_last_error(None)
             raise LpvMpcError(_ffi.E_NODEVICE, msg.decode() if msg else "lpvmpc_create failed")
+        self._ho_M = 0                       # samples per My_Planning array once handoff_setup() has run
+        self._cas = self._cas_planner = None
 
     # -- lifetime --------------------------------------------------------------------------------
     def close(self):
@@ -275,6 +277,8 @@ class BatchedSolver:
         self._chk(self._lib.lpvmpc_cascade_tick(self._h, int(n_ticks)))
 
     def cascade_read(self, full=True):
+        if self._cas is None:
+            raise LpvMpcError(_ffi.E_ARG, "cascade_read: call cascade_init first")
         B, Np, M = self._cas
         o = dict(plant=np.empty((B, 8)), local=np.empty((B, 6)), cmd=np.empty((B, 2)), iters=np.empty(B, np.int32),
                  status=np.empty(B, np.int32), lap=np.empty(B, np.int32), lap_tick=np.empty(B, np.int32),

@@ -820,6 +820,7 @@ struct Solver {
 
     // ---- the whole solve --------------------------------------------------------------------------
     __device__ __forceinline__ void run(const SolveArgs &a, int inst) {
+        bool bad = false;              // this thread saw a non-finite input word
         // ---------- load + build the unscaled problem ----------
         {   // weights -> LDS (the configuration block itself stays in global memory)
             double v = 0.0;
@@ -841,11 +842,14 @@ struct Solver {
             const double *src = a.AB + (size_t)inst * N * NX * NB;
             for (int e = tid; e < N * NX * NB; e += kStride) {
                 const int k = e / (NX * NB), rem = e - k * (NX * NB), r = rem / NB, col = rem - r * NB;
-                tA[k * kTS + r * 8 + col] = src[e];
+                const double v = src[e];
+                bad |= !__builtin_isfinite(v);
+                tA[k * kTS + r * 8 + col] = v;
             }
         }
         const double uo0 = a.u_old ? a.u_old[(size_t)inst * 2 + 0] : 0.0, uo1 = a.u_old ? a.u_old[(size_t)inst * 2 + 1] : 0.0;
         const double mey = (!kCtrl && a.max_ey) ? a.max_ey[inst] : 0.0;
+        bad |= !__builtin_isfinite(uo0) || !__builtin_isfinite(uo1) || !__builtin_isfinite(mey);
         for (int e = tid; e < NS * 8; e += kStride) {
             const int k = e >> 3, r = e & 7;
             // linear cost: controller q = -2 xtrack' M0 (CTRL:434-447); planner q = L_cf (PLAN:163)
@@ -854,6 +858,7 @@ struct Solver {
                 if (kCtrl) q = -cfg.Q[0 * NX + r] * 2.0 * a.vel_ref[(size_t)inst * (N + 1) + k];
                 else q = cfg.Lcf[r];
             } else if (r < NB && k == 0) q = -2.0 * (r == NX ? uo0 : uo1) * cfg.dR[r - NX];   // CTRL:462 / PLAN:167
+            bad |= !__builtin_isfinite(q);
             Qv[e] = q;
             // box rows (CTRL:334-348 / PLAN:173-181); infinities clipped to +-1e30 like OSQP's front end
             if (r < nbox(k)) {
@@ -862,8 +867,29 @@ struct Solver {
                 Lo[e] = fmax(lo, -kInfty); Hi[e] = fmin(hi, kInfty);
             }
         }
-        if (tid < 16) beq[tid] = (tid < NX) ? a.x0[(size_t)inst * a.x0_stride + tid] : 0.0;
+        if (tid < 16) { const double v = (tid < NX) ? a.x0[(size_t)inst * a.x0_stride + tid] : 0.0; bad |= !__builtin_isfinite(v); beq[tid] = v; }
         sync();
+        // Non-finite input data (a NaN measurement, or the NaN "solution" of an infeasible previous tick fed back by the
+        // caller): no iteration is run, the outputs are NaN and the status is UNSOLVED.  (OSQP's NaN-blind max-norms
+        // would declare such a problem solved at its first check and return NaN as well.)
+        if (bad) beq[15] = 1.0;
+        sync();
+        if (beq[15] != 0.0) {
+            const double nanv = __builtin_nan("");
+            for (int e = tid; e < NS * 8; e += kStride) {
+                const int k = e >> 3, r = e & 7;
+                if (r < NX) a.xPred[((size_t)inst * NS + k) * NX + r] = nanv;
+                else if (r < NB && k < N) a.uPred[((size_t)inst * N + k) * 2 + (r - NX)] = nanv;
+            }
+            if (a.state) { double *so = a.state + (size_t)inst * 3 * NS * 8; for (int e = tid; e < 3 * NS * 8; e += kStride) so[e] = 0.0; }
+            if (tid == 0) {
+                if (a.status) a.status[inst] = LPVMPC_UNSOLVED_;
+                if (a.iters) a.iters[inst] = 0;
+                if (a.polish) a.polish[inst] = 0;
+                if (a.resid) { double *o = a.resid + (size_t)inst * 4; o[0] = o[1] = o[2] = o[3] = nanv; }
+            }
+            return;
+        }
 
         // ---------- setup: scaling, rho, factorisation ----------
         if (cfg.scaling > 0) scale_data();

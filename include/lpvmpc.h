@@ -54,7 +54,8 @@ extern "C" {
 #define LPVMPC_PRIMAL_INFEASIBLE            -3
 #define LPVMPC_DUAL_INFEASIBLE              -4
 #define LPVMPC_NON_CVX                      -7
-#define LPVMPC_UNSOLVED                    -10
+#define LPVMPC_UNSOLVED                    -10      /* also: non-finite input data (NaN / Inf in x0, A, B, vel_ref, uOld,
+                                                      max_ey) -- no iteration is run, xPred / uPred are NaN, iters = 0 */
 
 typedef struct lpvmpc_config {
     int32_t kind;            /* LPVMPC_KIND_* */

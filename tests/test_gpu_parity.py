@@ -257,6 +257,30 @@ def test_bad_arguments_fail_cleanly(lpvmpc):
     eng.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_non_finite_inputs_yield_nan_and_unsolved(lpvmpc, variant):
+    """A NaN in one instance's data (a failed measurement, or the NaN solution of an infeasible tick fed back by the
+    caller): that instance returns NaN with status UNSOLVED and zero iterations, its neighbours are unaffected.
+    (The oracle -- like OSQP, whose max-norms skip NaN -- returns NaN as well, but calls it solved.)"""
+    from lpvmpc import workloads
+    w = workloads.controller_batch(6, N=20, seed=4)
+    eng = workloads.make_solver(w)
+    eng.set_option("kernel_variant", variant)
+    clean = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"])
+    x0 = w["x0"].copy(); vel = w["vel_ref"].copy(); uold = w["u_old"].copy()
+    x0[1, 3] = np.nan; vel[3, 7] = np.inf; uold[4, 1] = np.nan
+    out = eng.solve(x0, w["u_prev"], vel, w["curv_s"], uold, None, w["cf_new"], w["lap"])
+    eng.close()
+    for b in (1, 3, 4):
+        assert out["status"][b] == -10 and out["iters"][b] == 0
+        assert np.all(np.isnan(out["xPred"][b])) and np.all(np.isnan(out["uPred"][b]))
+    for b in (0, 2, 5):
+        assert out["status"][b] == clean["status"][b] and out["iters"][b] == clean["iters"][b]
+        assert np.array_equal(out["xPred"][b], clean["xPred"][b]) and np.array_equal(out["uPred"][b], clean["uPred"][b])
+    ref = O.ctrl_tick_batch(dict(w, x0=x0))
+    assert np.all(np.isnan(ref["uPred"][1]))
+
+
 def test_opt_in_warm_start_matches_oracle(lpvmpc):
     """Row f3 of SURVEY 8f: warm start from the previous tick's (x, y), shifted by one stage.  Off by default
     (the reference cold-starts every call); when enabled the GPU and the oracle's warm-started OSQP restatement
