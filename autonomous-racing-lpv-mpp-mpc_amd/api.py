@@ -475,3 +475,43 @@ class LPV_MPC_Planner(_DropInBase):
                                  np.asarray(SS, float).reshape(-1)[:N + 1][None])
         return (S[0], [A[0, i] for i in range(N)], [Bm[0, i] for i in range(N)],
                 [np.zeros((5, 1)) for _ in range(N)])
+
+
+# =====================================================================================================
+# caller-side helpers of the two nodes, single vehicle
+# =====================================================================================================
+class PlannerHandoff(object):
+    """The post-processing block of plannerMain.py for one vehicle: ``refs = PlannerHandoff(Planner).update()`` replaces
+    PMAIN:112 (filter design), :189-224 (s integration, pose reconstruction) and :257-280 (resampling, filtering).
+
+    State carried between ticks, as in the node: ``SS`` (N+1,), ``Xlast / Ylast / Thetalast``.  After ``update()``:
+    ``xp, yp, yaw, vel, curv`` (N,) at the planner's rate and ``x_d, y_d, psi_d, vx_d, curv_d`` (M,) -- the five arrays
+    of the My_Planning message (PMAIN:303-307).  Computed on the device through lpvmpc_handoff_batch."""
+
+    def __init__(self, planner, handoff_config=None):
+        self._eng = planner._eng
+        self.N = planner.N
+        self.M = self._eng.handoff_setup(handoff_config)
+        self.SS = np.zeros(self.N + 1)
+        self.Xlast = self.Ylast = self.Thetalast = 0.0
+        self._planner = planner
+
+    def update(self, xPred=None):
+        xPred = self._planner.xPred if xPred is None else xPred
+        o = self._eng.handoff(np.asarray(xPred, float)[None], self.SS[None], np.array([[self.Xlast, self.Ylast, self.Thetalast]]),
+                              want_sig=True)
+        self.SS = o["SS"][0]
+        self.Xlast, self.Ylast, self.Thetalast = (float(v) for v in o["pose"][0])
+        self.xp, self.yp, self.yaw, self.vel, self.curv = (o["sig"][0, i] for i in range(5))
+        self.x_d, self.y_d, self.psi_d, self.vx_d, self.curv_d = (o["refs"][0, i] for i in range(5))
+        return o["refs"][0]
+
+
+def body_frame_errors(x, y, psi, xd, yd, psid, s0, vx, vy, curv, dt):
+    """Body_Frame_Errors of controllerMain.py:495-506 -> (s, ex, ey, epsi); host arithmetic, a dozen flops."""
+    ex = (x - xd) * np.cos(psid) + (y - yd) * np.sin(psid)
+    ey = -(x - xd) * np.sin(psid) + (y - yd) * np.cos(psid)
+    d = psi - psid
+    epsi = 2 * np.pi + d if d < -np.pi else (d - 2 * np.pi if d > np.pi else d)            # TRACK:413-421 wrap()
+    s = s0 + ((vx * np.cos(epsi) - vy * np.sin(epsi)) / (1 - ey * curv)) * dt
+    return s, ex, ey, epsi

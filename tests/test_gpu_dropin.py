@@ -68,3 +68,37 @@ def test_planner_open_loop_trace():
         assert np.max(np.abs(p.xPred - g["plan_xPred"][tick])) <= 1e-5, tick
         assert np.max(np.abs(p.uPred - g["plan_uPred"][tick])) <= 1e-5, tick
         assert np.max(np.abs(SS - g["plan_SS"][tick])) <= 1e-5, tick
+
+
+def test_planner_node_with_handoff_trace():
+    """The planner node's tick as a maintainer would write it with the drop-ins: LPV_MPC_Planner + PlannerHandoff
+    (replacing PMAIN:189-224,257-280), N = 40 as in the launch file, against the first 16 planner ticks of
+    tests/golden/handoff.npz (reference planner class + reference Map + scipy)."""
+    import lpvmpc
+    from lpvmpc import workloads
+    g = load("handoff")
+    Np, dtp = int(g["N"]), float(g["dt"])
+    mp = lpvmpc.Map("L_shape", 0.2)
+    p = lpvmpc.LPV_MPC_Planner(workloads.PLAN_Q, workloads.PLAN_R, workloads.PLAN_dR, workloads.PLAN_L, Np, dtp, mp, "OSQP")
+    ho = lpvmpc.PlannerHandoff(p)
+    assert ho.M == 61
+    x0 = np.array([1.0, 0.0, 0.0, 0.03, -0.02])
+    first = 1
+    for tick in range(16):
+        if first == 1:
+            xx, uu = L.plan_seed_vectors(Np, x0, 0.2, dtp)
+            p.solve(x0, xx, uu, 0, 0, 0, first, 0.2)
+            first += 1
+        else:
+            S, A_L, B_L, C_L = p.LPVPrediction(p.xPred[1, :], ho.SS, p.uPred)
+            p.solve(p.xPred[1, :], 0, 0, A_L, B_L, C_L, first, 0.2)
+        p.OldSteering.append(p.uPred[0, 0]); p.OldAccelera.append(p.uPred[0, 1])
+        refs = ho.update()
+        # the planner's polish rarely succeeds, so its iterates are eps-accurate and the open-loop recursion amplifies solver
+        # round-off by about 2x per tick (1e-12 at tick 0, 1e-7 at tick 16, 1e-5 at tick 20): the strict window is 16 ticks
+        assert p.iters == g["plan_iters"][tick], tick
+        assert np.max(np.abs(p.xPred - g["plan_xPred"][tick])) <= 1e-6, tick
+        assert np.max(np.abs(ho.SS - g["plan_SS_out"][tick])) <= 1e-6, tick
+        assert np.max(np.abs(np.array([ho.xp, ho.yp, ho.yaw, ho.vel, ho.curv]) - g["plan_sig"][tick])) <= 1e-6, tick
+        assert refs.shape == (5, 61) and np.max(np.abs(refs - g["plan_refs"][tick])) <= 1e-6, tick
+        assert np.array_equal(ho.curv_d, refs[4]) and np.array_equal(ho.vx_d, refs[3])

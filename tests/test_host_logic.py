@@ -86,3 +86,10 @@ def test_handoff_refuses_what_scipy_refuses():
     with pytest.raises(lpvmpc.LpvMpcError) as e:            # N = 30 at 20 Hz -> 45 samples <= padlen 50 (filtfilt raises ValueError)
         api.handoff_operators(30, 0.05)
     assert "padlen" in str(e.value)
+
+
+def test_body_frame_errors_host_helper():
+    import lpvmpc
+    g = load("handoff")
+    out = np.array([lpvmpc.body_frame_errors(*r, 1.0 / 30) for r in g["bfe_in"]])
+    assert np.max(np.abs(out - g["bfe_out"])) <= 1e-12
