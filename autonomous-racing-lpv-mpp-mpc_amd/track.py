@@ -84,3 +84,21 @@ class Map:
         self.halfWidth = fixed_hw if fixed_hw is not None else halfWidth_param + 0.1
         self.PointAndTangent = build_table(segments)
         self.TrackLength = self.PointAndTangent[-1, 3] + self.PointAndTangent[-1, 4]
+        self._eng = None
+
+    # -- coordinate transforms of the reference's Map, evaluated by the device kernels (one point per call) ----------
+    def _engine(self):
+        if self._eng is None:
+            from .api import BatchedSolver                  # raises LpvMpcError without a HIP device: no CPU fallback
+            self._eng = BatchedSolver("controller", 8, 1.0 / 30.0, np.eye(6), np.eye(2), np.ones(2), track=self.PointAndTangent)
+        return self._eng
+
+    def getGlobalPosition(self, s, ey):
+        """TRACK:205-262: (s, ey) -> (x, y, theta)."""
+        x, y, th = self._engine().global_position(np.array([[float(s), float(ey)]]))[0]
+        return float(x), float(y), float(th)
+
+    def getLocalPosition(self, x, y, psi):
+        """TRACK:283-383: (x, y, psi) -> (s, ey, epsi, insideTrack); 10000 sentinels when the point is off the track."""
+        s, ey, epsi, inside = self._engine().local_position(np.array([[float(x), float(y), float(psi)]]), self.halfWidth, self.slack)[0]
+        return float(s), float(ey), float(epsi), int(inside)

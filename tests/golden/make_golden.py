@@ -288,7 +288,7 @@ def gen_handoff(CTRL, PLAN, TRACK, UTIL):
     sim.x, sim.y, sim.yaw, sim.vx = -0.55, 0.02, 0.01, 1.0
     cmd = [0.0, 0.0]; first_it = 1; LapNumber = 0; HalfTrack = 1; SS = 0.0; index = 0
     L = lsh.TrackLength
-    pre = []
+    pre = dict(plant=[], local=[], cmd=[], lap=[])
     for tick in range(60):                                  # lap 0 until the reference's lap event fires
         G_ = np.array([sim.vx, sim.vy, sim.psiDot, sim.x, sim.y, sim.yaw]); Lc = G_.copy()
         if Lc[0] < 0.01:
@@ -296,24 +296,33 @@ def gen_handoff(CTRL, PLAN, TRACK, UTIL):
         Lc[4], Lc[3], Lc[5], inside = lsh.getLocalPosition(G_[3], G_[4], G_[5])
         if HalfTrack == 1 and Lc[4] <= L / 4:              # CMAIN:254-259
             HalfTrack = 0; LapNumber += 1; SS = 0
-            break
-        C0.OldSteering.append(cmd[0]); C0.OldAccelera.append(cmd[1]); C0.OldSteering.pop(0); C0.OldAccelera.pop(0)
+        Cx = C0 if LapNumber == 0 else CT                   # CMAIN:289-298
+        Cx.OldSteering.append(cmd[0]); Cx.OldAccelera.append(cmd[1]); Cx.OldSteering.pop(0); Cx.OldAccelera.pop(0)
         if first_it < 10:
             xx, uu = lpv_ref.ctrl_seed_vectors(Lc)
             C0.solve(Lc[0:6], xx, uu, False, np.ones(N), 0, 0, 0, first_it); first_it += 1
-        else:
+        elif LapNumber == 0:
             S, A_L, B_L, C_L = C0.LPVPrediction(Lc[0:6], C0.uPred, np.ones(N + 1), np.zeros(N), 60.0, 0)
             C0.solve(S[0, :], S, C0.uPred, False, np.ones(N + 1), A_L, B_L, C_L, first_it)
-        CT.uPred = C0.uPred                                  # CMAIN:336
-        cmd = [float(C0.uPred[0, 0]), float(C0.uPred[0, 1])]
-        pre.append(tick)
+            CT.uPred = C0.uPred                              # CMAIN:336
+        else:
+            # the iteration on which the lap event fires already runs the trajectory-tracking branch, with the lap-0
+            # references still in place: vel_ref = ones(N+1), curv_ref = zeros(N)  (CMAIN:326-327,361-363)
+            S, A_L, B_L, C_L = CT.LPVPrediction(Lc[0:6], CT.uPred, np.ones(N + 1), np.zeros(N), 60, LapNumber)
+            CT.solve(Lc[0:6], 0.0, CT.uPred, False, np.ones(N + 1), A_L, B_L, C_L, first_it)
+        Cx = C0 if LapNumber == 0 else CT
+        cmd = [float(Cx.uPred[0, 0]), float(Cx.uPred[0, 1])]
+        pre["plant"].append([sim.x, sim.y, sim.vx, sim.vy, sim.ax, sim.ay, sim.yaw, sim.psiDot]); pre["local"].append(Lc.copy())
+        pre["cmd"].append(list(cmd)); pre["lap"].append(LapNumber)
         for _ in range(7):
             sim.f([cmd[1], cmd[0]])
-    assert LapNumber == 1 and len(pre) > 10, (LapNumber, len(pre))
-    # the tick on which the lap event fired continues in the LapNumber >= 1 branch (CMAIN:198 onwards is evaluated
-    # before the event, with LapNumber still 0, on that very tick; the fixture starts with the next measurement)
+        if LapNumber == 1:
+            break
+    assert LapNumber == 1 and len(pre["lap"]) > 10, (LapNumber, len(pre["lap"]))
+    # the fleet fixture starts after the event iteration: the planner node sees LapNumber >= 1 from then on (PMAIN:129)
     cas = dict(plant0=np.array([sim.x, sim.y, sim.vx, sim.vy, sim.ax, sim.ay, sim.yaw, sim.psiDot]), cmd0=np.array(cmd),
-               uPred0=np.array(CT.uPred), lap0=np.array(LapNumber), pre_ticks=np.array(len(pre)))
+               uPred0=np.array(CT.uPred), lap0=np.array(LapNumber), pre_ticks=np.array(len(pre["lap"])),
+               pre_plant=np.array(pre["plant"]), pre_local=np.array(pre["local"]), pre_cmd=np.array(pre["cmd"]), pre_lap=np.array(pre["lap"]))
     node = PlannerNode()
     refs = None; plan_done = 0
     K = 60

@@ -137,7 +137,7 @@ def test_cascade_fleet_vs_oracle():
     from lpvmpc import workloads as W
     c = load("cascade")
     B = 8
-    plant0 = fleet_start(c, 10, B)
+    plant0 = fleet_start(c, 11, B)
     cmd0 = np.tile(c["cmd0"], (B, 1)); uPred0 = np.tile(c["uPred0"], (B, 1, 1))
     plan, mp = planner()
     plan.handoff_setup()
@@ -164,7 +164,7 @@ def test_infeasible_planner_instance_stays_contained():
     on; here such a vehicle carries NaN, every other vehicle is untouched and the engine keeps ticking."""
     c = load("cascade")
     B = 8
-    plant0 = fleet_start(c, 9, B)
+    plant0 = fleet_start(c, 16, B)
     cmd0 = np.tile(c["cmd0"], (B, 1)); uPred0 = np.tile(c["uPred0"], (B, 1, 1))
     plan, mp = planner()
     plan.handoff_setup()

