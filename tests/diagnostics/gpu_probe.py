@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
+# (test infrastructure: uses the oracle as a checker; lives under tests/ for that reason)
 """Diagnostic dump for a GPU box: per-case status / iterations / error vs the oracle, and a first timing."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import lpvmpc
