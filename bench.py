@@ -221,7 +221,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(w, target_s=15.0, planner=False):
+def cpu_baseline(w, target_s=12.0, planner=False):
     """The CPU oracle port (same tick: LPV roll-out + sparse assembly + OSQP restatement, float64) on a
     bounded sample of the same workload, on all host cores (OpenMP over instances)."""
     import numpy as np
@@ -234,7 +234,7 @@ def cpu_baseline(w, target_s=15.0, planner=False):
     t0 = time.perf_counter(); tick(sub(64), nthreads=cores); t64 = time.perf_counter() - t0
     n = int(min(w["x0"].shape[0], max(64, 64 * target_s / max(t64, 1e-6))))
     reps, done, t_all = 0, 0, 0.0
-    while t_all < target_s and reps < 50:
+    while t_all < target_s and reps < 5000:
         t0 = time.perf_counter(); tick(sub(n), nthreads=cores); t_all += time.perf_counter() - t0
         done += n; reps += 1
     t1 = time.perf_counter(); tick(sub(64), nthreads=1); t_single = time.perf_counter() - t1
