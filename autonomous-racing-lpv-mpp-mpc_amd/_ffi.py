@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblpvmpc.so")
 
 KIND_CONTROLLER, KIND_PLANNER = 0, 1
-MAX_TRACK_ROWS, MAX_N = 16, 64
+MAX_TRACK_ROWS, MAX_N = 16, 52
 E_ARG, E_NODEVICE, E_HIP, E_NOMEM = -1, -2, -3, -4
 
 STATUS_TEXT = {1: "solved", 2: "solved inaccurate", 3: "primal infeasible inaccurate",
@@ -64,7 +64,7 @@ class HandoffConfig(C.Structure):
     _fields_ = [("interp_dt", _d), ("padlen", _i), ("order", _i), ("b", _d * (MAX_FILTER_ORDER + 1)), ("a", _d * (MAX_FILTER_ORDER + 1))]
 
 
-EXPORTS = ("lpvmpc_version", "lpvmpc_default_config", "lpvmpc_create", "lpvmpc_destroy", "lpvmpc_last_error",
+EXPORTS = ("lpvmpc_version", "lpvmpc_default_config", "lpvmpc_create", "lpvmpc_destroy", "lpvmpc_last_error", "lpvmpc_last_error_code",
            "lpvmpc_reserve", "lpvmpc_lpv_batch", "lpvmpc_estimate_abc_batch", "lpvmpc_solve_batch_AB",
            "lpvmpc_solve_batch", "lpvmpc_solve_batch_dev", "lpvmpc_last_kernel_ms", "lpvmpc_set_timing",
            "lpvmpc_kernel_time_stats", "lpvmpc_set_option",
@@ -97,6 +97,8 @@ def load():
     lib.lpvmpc_destroy.restype = None
     lib.lpvmpc_last_error.argtypes = [vp]
     lib.lpvmpc_last_error.restype = C.c_char_p
+    lib.lpvmpc_last_error_code.argtypes = []
+    lib.lpvmpc_last_error_code.restype = C.c_int
     lib.lpvmpc_reserve.argtypes = [vp, _i]
     lib.lpvmpc_lpv_batch.argtypes = [vp, _i, vp, vp, vp, vp, _d, _i, vp, vp, vp]
     lib.lpvmpc_estimate_abc_batch.argtypes = [vp, _i, vp, vp, vp, vp]

@@ -98,7 +98,7 @@ class BatchedSolver:
         self._h = lib.lpvmpc_create(C.byref(cfg))
         if not self._h:
             msg = lib.lpvmpc_last_error(None)
-            raise LpvMpcError(_ffi.E_NODEVICE, msg.decode() if msg else "lpvmpc_create failed")
+            raise LpvMpcError(lib.lpvmpc_last_error_code() or _ffi.E_ARG, msg.decode() if msg else "lpvmpc_create failed")
         self._ho_M = 0                       # samples per My_Planning array once handoff_setup() has run
         self._cas = self._cas_planner = None
 

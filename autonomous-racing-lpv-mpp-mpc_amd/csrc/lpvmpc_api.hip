@@ -14,6 +14,7 @@
 #include "lpvmpc_handle.hpp"
 
 static thread_local std::string g_last_error;
+static thread_local int g_last_code = 0;
 
 int lpvmpc_fail(lpvmpc_handle *h, int code, const char *fmt, ...) {
     char buf[512];
@@ -23,6 +24,7 @@ int lpvmpc_fail(lpvmpc_handle *h, int code, const char *fmt, ...) {
     va_end(ap);
     if (h) h->err = buf;
     g_last_error = buf;
+    g_last_code = code;
     return code;
 }
 
@@ -133,7 +135,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
         hipMemcpy(h->d_cfg, &h->dev, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) {
         fail(nullptr, LPVMPC_E_HIP, "uploading the configuration failed"); lpvmpc_destroy(h); return nullptr; }
     const size_t lds = lpvmpc::solve_lds_bytes(cfg->kind, cfg->N);
-    if (lds > 160 * 1024) { fail(nullptr, LPVMPC_E_ARG, "N=%d needs %zu B of LDS per instance (> 160 KiB)", cfg->N, lds); lpvmpc_destroy(h); return nullptr; }
+    if (lds > 160 * 1024) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: N=%d needs %zu B of LDS per instance (> 160 KiB)", cfg->N, lds); lpvmpc_destroy(h); return nullptr; }
     return h;
 }
 
@@ -153,6 +155,7 @@ extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
     delete h;
 }
 
+extern "C" int lpvmpc_last_error_code(void) { return g_last_code; }
 extern "C" const char *lpvmpc_last_error(const lpvmpc_handle *h) { return h ? h->err.c_str() : g_last_error.c_str(); }
 
 extern "C" int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value) {

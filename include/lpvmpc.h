@@ -36,7 +36,7 @@ extern "C" {
 #define LPVMPC_KIND_PLANNER    1      /* LPV_MPC_Planner       (PLAN:29-320) */
 
 #define LPVMPC_MAX_TRACK_ROWS 16
-#define LPVMPC_MAX_N          64
+#define LPVMPC_MAX_N          52      /* (N+1) stages x 3008 B of LDS per instance must fit 160 KiB (run-time-horizon kernel) */
 
 /* error codes */
 #define LPVMPC_OK            0
@@ -105,6 +105,8 @@ void lpvmpc_default_config(int32_t kind, lpvmpc_config *cfg);
 lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg);
 void lpvmpc_destroy(lpvmpc_handle *h);
 const char *lpvmpc_last_error(const lpvmpc_handle *h);
+/* LPVMPC_E_* code of the last failure on this thread (0 when none); tells why lpvmpc_create returned NULL. */
+int lpvmpc_last_error_code(void);
 
 /* Runtime options.  "kernel_variant": 0 = fastest instantiation for (kind, N) (default), 1 = run-time-horizon
  * kernel (factor tiles in LDS, any N), 2 = compile-time horizon with ONE wavefront per instance (where it

@@ -240,6 +240,30 @@ def test_runtime_horizon_kernel_other_N(lpvmpc, N):
         _agree(out, ref, b, 6, 1e-6)
 
 
+def test_maximum_horizon(lpvmpc):
+    """LPVMPC_MAX_N = 52 for both problem kinds (largest LDS footprint, run-time-horizon kernel) against the C oracle;
+    one more stage is refused at creation."""
+    from lpvmpc import workloads
+    w = workloads.controller_batch(24, N=52, seed=12)
+    eng = workloads.make_solver(w)
+    out = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"])
+    eng.close()
+    ref = O.ctrl_tick_batch(w, nthreads=8)
+    for b in range(24):
+        _agree(out, ref, b, 6, 1e-6)
+    wp = workloads.planner_batch(24, N=52, seed=13)
+    eng = workloads.make_solver(wp)
+    outp = eng.solve(wp["x0"], wp["u_prev"], None, wp["curv_s"], wp["u_old"], wp["max_ey"])
+    eng.close()
+    refp = O.plan_tick_batch(wp, nthreads=8)
+    assert np.array_equal(outp["status"], refp["status"])
+    for b in range(24):
+        _agree(outp, refp, b, 5, 1e-6)
+    with pytest.raises(lpvmpc.LpvMpcError) as e:
+        lpvmpc.BatchedSolver("controller", 53, w["dt"], w["Q"], w["R"], w["dR"], track=w["track"])
+    assert e.value.code == -1                                # LPVMPC_E_ARG, not "no device"
+
+
 def test_bad_arguments_fail_cleanly(lpvmpc):
     from lpvmpc import workloads
     w = workloads.controller_batch(4, N=20, seed=0)
