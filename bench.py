@@ -42,10 +42,10 @@ def algorithmic_bytes(iters, N=HORIZON, nx=6, nu=2, w=8, m_rows=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU (default: configs[1] = 1024)")
-    ap.add_argument("--streams", type=int, default=16,
+    ap.add_argument("--streams", type=int, default=32,
                     help="HIP streams the K steps are issued on round-robin (independent batches overlap, so the few "
                          "slow instances of one batch do not leave the GPU idle); 1 = strictly back-to-back steps")
     ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
