@@ -63,7 +63,7 @@ struct Solver {
     double *SINK;  // [64 + 8 NS] write-only dump for the lanes that do not own a result (avoids exec masking)
     double *Pm;    // [64] unscaled stage Hessian block 2*[Q 0; 0 R + 2 diag(dR)] (LDS copy of the weights)
     double *dRl;   // [8]  dR[0..1]
-    double *RED;   // [64] per-wave partial results of block-wide reductions / chain hand-over (NW == 2)
+    double *RED;   // [80] per-wave partial results of block-wide reductions / chain hand-over (NW == 2)
     double c, cinv;
     // row weights: ADMM rho classes (OSQP set_rho_vec) or, while polishing, |flag| = 1/delta on active rows
     bool pol;
@@ -84,13 +84,13 @@ struct Solver {
         Zd = p; p += V; Yd = p; p += V; Ed = p; p += V; ZTd = p; p += V; DYd = p; p += V;
         Zb = p; p += V; Yb = p; p += V; Eb = p; p += V; ZTb = p; p += V; DYb = p; p += V;
         Lo = p; p += V; Hi = p; p += V;
-        beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; RED = p; p += 64; SINK = p; p += 64 + 8 * NS;
+        beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; RED = p; p += 80; SINK = p; p += 64 + 8 * NS;
         { int first, cnt; rows_on(tj, first, cnt); r0 = cnt >= 1 ? first : 7; r1 = cnt >= 2 ? first + 1 : 7; }
         bvar = box_var(tj); rmask = tj < NX ? 1.0 : 0.0;
         c = 1.0; cinv = 1.0; pol = false; rho = rho_eq = rinv = rinv_eq = 0.0; rSm = rLt = rLb = 0.0;
     }
     static __host__ __device__ size_t lds_doubles(int N) {
-        return (size_t)(N + 1) * ((kReg ? 1 : 3) * kTS + 19 * 8 + 8) + 16 + 64 + 8 + 64 + 64;
+        return (size_t)(N + 1) * ((kReg ? 1 : 3) * kTS + 19 * 8 + 8) + 16 + 64 + 8 + 80 + 64;
     }
 
     // ---- problem structure ---------------------------------------------------------------------
@@ -128,15 +128,34 @@ struct Solver {
     }
     // all-reduce over the whole instance (one or two wavefronts); both waves combine in the same order, so
     // every lane of the block sees bit-identical results and takes identical branches
+    // RED[64 .. 79] holds four slots of {sum wave 0, sum wave 1, max wave 0, max wave 1}.  A reduction needs a single
+    // barrier when the previous user of its slot is separated from it by at least one block barrier; the slot is a
+    // compile-time argument chosen per call site so that two reductions that can follow each other without an
+    // intervening sync() never share one (the last reduction of primal_infeasible and the first of dual_infeasible).
+    template <int SLOT>
     __device__ __forceinline__ double bsum(double v) const {
         v = wave_sum(v);
-        if constexpr (kTwo) { if (lane == 0) RED[wv] = v; __syncthreads(); v = RED[0] + RED[1]; __syncthreads(); }
+        if constexpr (kTwo) { double *r = RED + 64 + 4 * SLOT; if (lane == 0) r[wv] = v; __syncthreads(); v = r[0] + r[1]; }
         return v;
     }
+    template <int SLOT>
     __device__ __forceinline__ double bmax(double v) const {
         v = wave_max(v);
-        if constexpr (kTwo) { if (lane == 0) RED[wv] = v; __syncthreads(); v = fmax(RED[0], RED[1]); __syncthreads(); }
+        if constexpr (kTwo) { double *r = RED + 64 + 4 * SLOT; if (lane == 0) r[2 + wv] = v; __syncthreads(); v = fmax(r[2], r[3]); }
         return v;
+    }
+    // sum of s and max of m over the instance with one barrier (returned by value: see the note at PolishOut)
+    struct SumMax { double s, m; };
+    template <int SLOT>
+    __device__ __forceinline__ SumMax bsum_bmax(double s_, double m_) const {
+        s_ = wave_sum(s_); m_ = wave_max(m_);
+        if constexpr (kTwo) {
+            double *r = RED + 64 + 4 * SLOT;
+            if (lane == 0) { r[wv] = s_; r[2 + wv] = m_; }
+            __syncthreads();
+            s_ = r[0] + r[1]; m_ = fmax(r[2], r[3]);
+        }
+        return SumMax{s_, m_};
     }
 
     // ---- operators on the scaled problem ---------------------------------------------------------
@@ -265,8 +284,9 @@ struct Solver {
                 psum += P_colnorm(e >> 3, tj);
                 qmax = fmax(qmax, fabs(c * D[e] * Qv[e]));
             }
-            psum = bsum(psum) / (double)ntrue;
-            qmax = limit_scaling(bmax(qmax));
+            const SumMax pq = bsum_bmax<0>(psum, qmax);
+            psum = pq.s / (double)ntrue;
+            qmax = limit_scaling(pq.m);
             const double ct = limit_scaling(fmax(psum, qmax));
             c *= 1.0 / ct;
         }
@@ -466,6 +486,9 @@ struct Solver {
         double *const vrow = (ti == 0) ? VT + tj : SINK + lane;
         double *const vcol = (tj == 0) ? VT + ti : SINK + lane;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
+        // The right-hand side of the middle stage is read by BOTH waves in the backward sweep while wave 0 stores x_m
+        // over it: keep a copy where nobody writes (RED[48..55]) so that a late wave 1 cannot pick up x_m instead.
+        if (!BOT && lane < 8) RED[48 + lane] = XT[kMid * 8 + lane];
         double yc = XT[stage(0) * 8 + ti], yr = 0.0;
         double bq[3];
         bq[1] = XT[stage(1) * 8 + tj];
@@ -512,13 +535,13 @@ struct Solver {
         // middle stage, computed by both waves: y_m = b_m - (L_t y_{m-1}) - (L_b y_{m+1}),  x_m = S_m^-1 y_m
         // first chain step: x_{P-1} = v_{P-1} - L_link' x_m
         if (kLastOdd) {     // contributions / y_m in column form -> x_m in row form -> (via the register transpose) column form
-            const double ym = XT[kMid * 8 + ti] - (RED[32 + ti] + RED[40 + ti]);
+            const double ym = RED[48 + ti] - (RED[32 + ti] + RED[40 + ti]);
             const double xm_row = red_i(rSm * ym);                          // x_m[tj]
             if (!BOT) xrow[kMid * 8] = xm_row;
             const double xm_col = __shfl(xm_row, ti);                       // lane (0, ti) holds x_m[ti]
             xr = VT[stage(P - 1) * 8 + tj] - red_i(link * xm_col); xrow[stage(P - 1) * 8] = xr;
         } else {
-            const double ym = XT[kMid * 8 + tj] - (RED[32 + tj] + RED[40 + tj]);
+            const double ym = RED[48 + tj] - (RED[32 + tj] + RED[40 + tj]);
             const double xm_col = red_j(rSm * ym);                          // x_m[ti]
             if (!BOT) xcol[kMid * 8] = xm_col;
             const double xm_row = __shfl(xm_col, tj * 8);                   // lane (tj, 0) holds x_m[tj]
@@ -677,7 +700,7 @@ struct Solver {
         sync();
         double v = 0.0;
         for (int e = tid; e < NS * 8; e += kStride) v += xv[e] * (0.5 * VT[e] + Qv[e]);
-        v = bsum(v) * cinv;
+        v = bsum<1>(v) * cinv;
         sync();
         return v;
     }
@@ -697,7 +720,7 @@ struct Solver {
             DYb[e] = dy;
             nd = fmax(nd, fmax(fabs(Ed[e] * DYd[e]), fabs(Eb[e] * dy)));
         }
-        nd = bmax(nd);
+        nd = bmax<0>(nd);
         sync();
         bool res = false;
         if (nd > eps) {
@@ -707,13 +730,13 @@ struct Solver {
                 lhs += b * fmax(dyd, 0.0) + b * fmin(dyd, 0.0);
                 lhs += Hi[e] * fmax(dyb, 0.0) + Lo[e] * fmin(dyb, 0.0);
             }
-            lhs = bsum(lhs);
+            lhs = bsum<1>(lhs);
             if (lhs < -eps * nd) {
                 At_mul(DYd, DYb, AT);
                 sync();
                 double na = 0.0;
                 for (int e = tid; e < NS * 8; e += kStride) na = fmax(na, fabs(AT[e] / D[e]));
-                na = bmax(na);
+                na = bmax<2>(na);
                 res = na < eps * nd;
                 sync();
             }
@@ -723,14 +746,14 @@ struct Solver {
     __device__ __forceinline__ bool dual_infeasible(double eps) {
         double nd = 0.0, qdx = 0.0;
         for (int e = tid; e < NS * 8; e += kStride) { nd = fmax(nd, fabs(D[e] * DX[e])); qdx += Qv[e] * DX[e]; }
-        nd = bmax(nd); qdx = bsum(qdx);
+        { const SumMax qn = bsum_bmax<3>(qdx, nd); qdx = qn.s; nd = qn.m; }
         bool res = false;
         if (nd > eps && qdx < -c * eps * nd) {
             P_mul(DX, VT);
             sync();
             double np = 0.0;
             for (int e = tid; e < NS * 8; e += kStride) np = fmax(np, fabs(VT[e] / D[e]));
-            np = bmax(np);
+            np = bmax<0>(np);
             sync();
             if (np < c * eps * nd) {
                 A_mul(DX, ZTd, ZTb);
@@ -744,7 +767,7 @@ struct Solver {
                         if ((Hi[e] < kInfty * kMinScaling && v > eps * nd) || (Lo[e] > -kInfty * kMinScaling && v < -eps * nd)) bad = 1.0;
                     }
                 }
-                res = bmax(bad) == 0.0;
+                res = bmax<1>(bad) == 0.0;
                 sync();
             }
         }
@@ -1143,7 +1166,7 @@ int solve_has_fast_path(int kind, int N) {
 
 size_t solve_lds_bytes(int kind, int N) {
     const bool fast = solve_has_fast_path(kind, N) != 0;
-    return ((size_t)(N + 1) * ((fast ? 1 : 3) * kTS + 19 * 8 + 8) + 16 + 64 + 8 + 64 + 64) * sizeof(double);
+    return ((size_t)(N + 1) * ((fast ? 1 : 3) * kTS + 19 * 8 + 8) + 16 + 64 + 8 + 80 + 64) * sizeof(double);
 }
 
 // kernel_variant: 0 = best available, 1 = run-time-horizon kernel (factor tiles in LDS), 2 = compile-time horizon

@@ -240,6 +240,41 @@ def test_runtime_horizon_kernel_other_N(lpvmpc, N):
         _agree(out, ref, b, 6, 1e-6)
 
 
+def test_full_occupancy_runs_are_reproducible(lpvmpc):
+    """Two runs of the same 1024-instance batch (every CU holds four instances, two wavefronts each) give bit-identical
+    outputs and identical iteration counts.  Regression test for a race in the two-wavefront elimination: wave 0 stored
+    x_mid over the middle right-hand side that a delayed wave 1 had not read yet, which only showed under full load as
+    iteration counts that changed from run to run."""
+    from lpvmpc import workloads
+    w = workloads.controller_batch(1024, N=20, seed=0)
+    eng = workloads.make_solver(w)
+    runs = [eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"]) for _ in range(3)]
+    eng.close()
+    for r in runs[1:]:
+        assert np.array_equal(r["iters"], runs[0]["iters"]) and np.array_equal(r["status"], runs[0]["status"])
+        assert np.array_equal(r["uPred"], runs[0]["uPred"]) and np.array_equal(r["xPred"], runs[0]["xPred"])
+    ref = O.ctrl_tick_batch(w, nthreads=8)
+    assert np.array_equal(runs[0]["iters"], ref["iters"]) and np.array_equal(runs[0]["status"], ref["status"])
+
+
+def test_planner_n40_batch_against_oracle(lpvmpc):
+    """512 planner instances at the launch file's horizon N = 40 (two-wavefront kernel with the largest register
+    footprint) against the C oracle tick: statuses, iteration counts, polish outcome by its effect on the solution.
+    Regression test for a miscompiled register copy that made the polish step accept wrong candidates."""
+    from lpvmpc import workloads
+    w = workloads.planner_batch(512, N=40, seed=1)
+    eng = workloads.make_solver(w)
+    out = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+    eng.close()
+    ref = O.plan_tick_batch(w, nthreads=8)
+    sane = ref["iters"] > 0                                  # (one instance in 2048 leaves the oracle after 0 iterations)
+    assert np.array_equal(out["status"][sane], ref["status"][sane]) and np.mean(out["iters"][sane] == ref["iters"][sane]) >= 0.995
+    fin = np.isfinite(ref["uPred"]).all(axis=(1, 2)) & sane
+    assert np.array_equal(fin, np.isfinite(out["uPred"]).all(axis=(1, 2)) & sane)
+    d = np.abs(out["uPred"][fin] - ref["uPred"][fin]).max(axis=(1, 2))
+    assert np.mean(d <= 1e-6) >= 0.99 and np.max(d) <= 2e-3, (np.mean(d <= 1e-6), np.max(d))
+
+
 def test_maximum_horizon(lpvmpc):
     """LPVMPC_MAX_N = 52 for both problem kinds (largest LDS footprint, run-time-horizon kernel) against the C oracle;
     one more stage is refused at creation."""

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Scan gfx950 assembly (hipcc -save-temps / -S output) for vector instructions that sit in front of the
+`s_or_b64 exec, exec, s[..]` which re-opens the execution mask at the top of a control-flow join block.
+
+Such an instruction runs with the mask of ONE branch only, so a whole-register copy placed there (seen from LLVM's
+machine-sink pass under register pressure: `v_mov_b32 v200, v188` in front of the restore, v200 read by other
+lanes later) leaves the remaining lanes of its destination stale: a miscompile that showed up as wrong block
+reductions in the N = 40 planner kernel.  Only plain VGPR / AGPR copies are reported.  Exit code 1 on a suspect."""
+import re
+import sys
+
+
+def scan(path, window=8):
+    suspects = []
+    kernel = None
+    lines = open(path).read().split("\n")
+    i = 0
+    while i < len(lines):
+        ln = lines[i]
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            kernel = m.group(1)
+        if re.match(r"^\.LBB\d+_\d+:", ln):
+            label = ln.split(":")[0]
+            body = []
+            j = i + 1
+            while j < len(lines) and len(body) < window:
+                t = lines[j].strip()
+                j += 1
+                if not t or t.startswith(";") or t.startswith("."):
+                    if re.match(r"^\.LBB", t):
+                        break
+                    continue
+                body.append(t)
+            for k, t in enumerate(body):
+                if re.match(r"s_or_b64\s+exec,\s*exec,", t):
+                    # plain whole-register copies are what the register allocator / machine-sink insert; computations,
+                    # stores and v_writelane (exec-independent SGPR spills) in front of the mask restore are normally the
+                    # legitimate tail of the branch that falls through into the join block
+                    pre = [b for b in body[:k] if re.match(r"(v_mov_b32_e32\s+v\d+,\s*v\d+$|v_mov_b64_e32\s+v\[[\d:]+\],\s*v\[|v_accvgpr_(read|write)_b32)", b)]
+                    if pre:
+                        suspects.append((kernel, label, pre, t))
+                    break
+                if re.match(r"s_(cbranch|branch|barrier|endpgm)", t):
+                    break
+        i += 1
+    return suspects
+
+
+if __name__ == "__main__":
+    bad = 0
+    for p in sys.argv[1:]:
+        for kernel, label, pre, t in scan(p):
+            bad += 1
+            print("%s: %s %s: vector instruction(s) before '%s': %s" % (p, kernel, label, t, "; ".join(pre)))
+    print("%d suspect join-block prologue(s)" % bad)
+    sys.exit(1 if bad else 0)
