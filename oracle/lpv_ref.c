@@ -174,7 +174,11 @@ int oracle_ctrl_tick_batch(int B, int N, double dt, const double *params, const 
                     for (int t2 = 0; t2 < 4; t2++) yw[2 * N + 4 * k + t2] = yp[2 * N + 4 * ks + t2]; }
                 xws = xw; yws = yw;
             }
-            osqp_ref_solve_ws(nz, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, perm, &st, xws, yws, xo, yo, &info);
+            if (osqp_ref_solve_ws(nz, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, perm, &st, xws, yws, xo, yo, &info) != 0) {
+                for (int i = 0; i < nz; i++) xo[i] = NAN;          /* KKT factorisation broke down: no answer from the oracle */
+                for (int i = 0; i < m; i++) yo[i] = NAN;
+                info.status_val = -10; info.iter = 0;
+            }
             memcpy(xPred + (size_t)b * (N + 1) * nx, xo, sizeof(double) * (N + 1) * nx);
             memcpy(uPred + (size_t)b * N * nu, xo + (N + 1) * nx, sizeof(double) * N * nu);
             if (z_sol) memcpy(z_sol + (size_t)b * nz, xo, sizeof(double) * nz);
@@ -292,7 +296,11 @@ int oracle_plan_tick_batch(int B, int N, double dt, const double *params, const 
             for (int k = 0; k <= N; k++) for (int a = 0; a < nx; a++) { l[me + k * nx + a] = xmin[a]; u[me + k * nx + a] = xmax[a]; }
             for (int k = 0; k < N; k++) for (int j = 0; j < nu; j++) { l[me + (N + 1) * nx + k * nu + j] = umin[j]; u[me + (N + 1) * nx + k * nu + j] = umax[j]; }
             osqp_ref_info info;
-            osqp_ref_solve_ws(nz, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, perm, &st, 0, 0, xo, yo, &info);
+            if (osqp_ref_solve_ws(nz, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, perm, &st, 0, 0, xo, yo, &info) != 0) {
+                /* the KKT factorisation broke down (seen with a diverged roll-out, |A| ~ 1e65): no answer from the oracle */
+                for (int i = 0; i < nz; i++) xo[i] = NAN;
+                info.status_val = -10; info.iter = 0;
+            }
             memcpy(xPred + (size_t)b * (N + 1) * nx, xo, sizeof(double) * (N + 1) * nx);
             memcpy(uPred + (size_t)b * N * nu, xo + (N + 1) * nx, sizeof(double) * N * nu);
             if (status) status[b] = info.status_val;

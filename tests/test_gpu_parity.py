@@ -267,7 +267,7 @@ def test_planner_n40_batch_against_oracle(lpvmpc):
     out = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
     eng.close()
     ref = O.plan_tick_batch(w, nthreads=8)
-    sane = ref["iters"] > 0                                  # (one instance in 2048 leaves the oracle after 0 iterations)
+    sane = ref["status"] != -10                              # (the oracle gives up on a diverged roll-out: |A| ~ 1e65, 1 in 2048)
     assert np.array_equal(out["status"][sane], ref["status"][sane]) and np.mean(out["iters"][sane] == ref["iters"][sane]) >= 0.995
     fin = np.isfinite(ref["uPred"]).all(axis=(1, 2)) & sane
     assert np.array_equal(fin, np.isfinite(out["uPred"]).all(axis=(1, 2)) & sane)
