@@ -79,6 +79,7 @@ extern "C" int lpvmpc_handoff_setup(lpvmpc_handle *h, const lpvmpc_handoff_confi
 }
 
 extern "C" int lpvmpc_handoff_batch(lpvmpc_handle *h, int32_t B, const double *xPred, double *SS, double *pose, double *sig, double *refs) {
+    if (h && B == 0) return LPVMPC_OK;
     int rc = lpvmpc_check_common(h, B, "lpvmpc_handoff_batch"); if (rc) return rc;
     if (!h->d_Wop) return fail(h, LPVMPC_E_ARG, "lpvmpc_handoff_batch: call lpvmpc_handoff_setup first");
     if (!xPred || !SS || !pose || !refs) return fail(h, LPVMPC_E_ARG, "lpvmpc_handoff_batch: NULL argument");

@@ -240,6 +240,7 @@ int lpvmpc_check_common(lpvmpc_handle *h, int B, const char *who) {
 extern "C" int lpvmpc_lpv_batch(lpvmpc_handle *h, int32_t B, const double *x0, const double *u_prev,
                                 const double *vel_ref, const double *curv_s, double cf_new, int32_t lap,
                                 double *states, double *A, double *Bm) {
+    if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
     int rc = lpvmpc_check_common(h, B, "lpvmpc_lpv_batch"); if (rc) return rc;
     const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
     if (!x0 || !u_prev) return fail(h, LPVMPC_E_ARG, "lpvmpc_lpv_batch: x0 / u_prev is NULL");
@@ -269,6 +270,7 @@ extern "C" int lpvmpc_lpv_batch(lpvmpc_handle *h, int32_t B, const double *x0, c
 
 extern "C" int lpvmpc_estimate_abc_batch(lpvmpc_handle *h, int32_t B, const double *xlast, const double *delta,
                                          double *A, double *Bm) {
+    if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
     int rc = lpvmpc_check_common(h, B, "lpvmpc_estimate_abc_batch"); if (rc) return rc;
     if (!xlast || !delta) return fail(h, LPVMPC_E_ARG, "lpvmpc_estimate_abc_batch: NULL input");
     rc = lpvmpc_need_track(h, "lpvmpc_estimate_abc_batch"); if (rc) return rc;
@@ -305,6 +307,7 @@ extern "C" int lpvmpc_solve_batch_AB(lpvmpc_handle *h, int32_t B, const double *
                                      const double *vel_ref, const double *u_old, const double *max_ey,
                                      double *xPred, double *uPred, int32_t *status, int32_t *iters, double *resid,
                                      int32_t *polish) {
+    if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
     int rc = lpvmpc_check_common(h, B, "lpvmpc_solve_batch_AB"); if (rc) return rc;
     const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
     if (!x0 || !A || !Bm) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_AB: x0 / A / B is NULL");
@@ -335,6 +338,7 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
                                       const double *vel_ref, const double *curv_s, const double *u_old,
                                       const double *max_ey, double cf_new, int32_t lap, double *xPred, double *uPred,
                                       int32_t *status, int32_t *iters, double *resid, int32_t *polish, void *stream) {
+    if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
     int rc = lpvmpc_check_common(h, B, "lpvmpc_solve_batch_dev"); if (rc) return rc;
     const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
     if (!x0 || !u_prev || !xPred || !uPred) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_dev: NULL x0 / u_prev / xPred / uPred");
@@ -355,6 +359,7 @@ extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0,
                                   const double *vel_ref, const double *curv_s, const double *u_old,
                                   const double *max_ey, double cf_new, int32_t lap, double *xPred, double *uPred,
                                   int32_t *status, int32_t *iters, double *resid, int32_t *polish) {
+    if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
     int rc = lpvmpc_check_common(h, B, "lpvmpc_solve_batch"); if (rc) return rc;
     const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
     if (!x0 || !u_prev) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch: x0 / u_prev is NULL");
@@ -379,6 +384,7 @@ extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0,
 // caller-side helpers of the reference, batched on the device
 // ------------------------------------------------------------------------------------------------
 extern "C" int lpvmpc_local_position_batch(lpvmpc_handle *h, int32_t B, const double *xy_psi, double half_width, double slack, double *out) {
+    if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
     int rc = lpvmpc_check_common(h, B, "lpvmpc_local_position_batch"); if (rc) return rc;
     if (!xy_psi || !out) return fail(h, LPVMPC_E_ARG, "lpvmpc_local_position_batch: NULL argument");
     rc = lpvmpc_need_track(h, "lpvmpc_local_position_batch"); if (rc) return rc;
@@ -392,6 +398,7 @@ extern "C" int lpvmpc_local_position_batch(lpvmpc_handle *h, int32_t B, const do
 }
 
 extern "C" int lpvmpc_global_position_batch(lpvmpc_handle *h, int32_t B, const double *s_ey, double *out) {
+    if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
     int rc = lpvmpc_check_common(h, B, "lpvmpc_global_position_batch"); if (rc) return rc;
     if (!s_ey || !out) return fail(h, LPVMPC_E_ARG, "lpvmpc_global_position_batch: NULL argument");
     rc = lpvmpc_need_track(h, "lpvmpc_global_position_batch"); if (rc) return rc;
@@ -409,6 +416,7 @@ lpvmpc::PlantCfg lpvmpc_plant_cfg(const lpvmpc_handle *h, int n_sub, double dt_s
 }
 
 extern "C" int lpvmpc_plant_step_batch(lpvmpc_handle *h, int32_t B, double *state, const double *u, int32_t n_sub, double dt_sim, double mu_sim) {
+    if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
     int rc = lpvmpc_check_common(h, B, "lpvmpc_plant_step_batch"); if (rc) return rc;
     if (!state || !u || n_sub < 1 || !(dt_sim > 0)) return fail(h, LPVMPC_E_ARG, "lpvmpc_plant_step_batch: bad argument");
     hipStream_t st = h->stream;

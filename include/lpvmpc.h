@@ -10,7 +10,8 @@
  * Conventions
  *   - plain C, no exceptions across the boundary; every int-returning call gives 0 on success or a
  *     negative LPVMPC_E_* code, and lpvmpc_last_error() returns a message for the last failure;
- *   - all arrays are float64, row-major ("C order"), instance-major: [B][...];
+ *   - all arrays are float64, row-major ("C order"), instance-major: [B][...]; a batch call with B = 0 is a no-op
+ *     that returns LPVMPC_OK (fleet engines need B >= 1);
  *   - the caller owns every buffer; nothing passed in is retained after the call returns;
  *   - one handle per (device, stream); a handle is not thread-safe, different handles are;
  *   - there is NO CPU fallback: without a usable HIP device every compute call fails with

@@ -299,6 +299,23 @@ def test_maximum_horizon(lpvmpc):
     assert e.value.code == -1                                # LPVMPC_E_ARG, not "no device"
 
 
+def test_empty_and_single_instance_batches(lpvmpc):
+    """B = 0 is a no-op with empty outputs; B = 1 equals the first instance of a larger batch bit for bit."""
+    from lpvmpc import workloads
+    w = workloads.controller_batch(5, N=20, seed=2)
+    eng = workloads.make_solver(w)
+    e = eng.solve(w["x0"][:0], w["u_prev"][:0], w["vel_ref"][:0], w["curv_s"][:0], w["u_old"][:0], None, w["cf_new"], w["lap"])
+    assert e["xPred"].shape == (0, 21, 6) and e["uPred"].shape == (0, 20, 2) and e["status"].shape == (0,)
+    S, A, Bm = eng.lpv(w["x0"][:0], w["u_prev"][:0], w["vel_ref"][:0], w["curv_s"][:0])
+    assert S.shape == (0, 20, 6) and A.shape == (0, 20, 6, 6)
+    assert eng.global_position(np.zeros((0, 2))).shape == (0, 3)
+    full = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"])
+    one = eng.solve(w["x0"][:1], w["u_prev"][:1], w["vel_ref"][:1], w["curv_s"][:1], w["u_old"][:1], None, w["cf_new"], w["lap"])
+    eng.close()
+    assert np.array_equal(one["xPred"][0], full["xPred"][0]) and np.array_equal(one["uPred"][0], full["uPred"][0])
+    assert one["iters"][0] == full["iters"][0]
+
+
 def test_bad_arguments_fail_cleanly(lpvmpc):
     from lpvmpc import workloads
     w = workloads.controller_batch(4, N=20, seed=0)
