@@ -144,7 +144,7 @@ struct Solver {
         if constexpr (kTwo) { double *r = RED + 64 + 4 * SLOT; if (lane == 0) r[2 + wv] = v; __syncthreads(); v = fmax(r[2], r[3]); }
         return v;
     }
-    // sum of s and max of m over the instance with one barrier (returned by value: see the note at PolishOut)
+    // sum of s and max of m over the instance with one barrier
     struct SumMax { double s, m; };
     template <int SLOT>
     __device__ __forceinline__ SumMax bsum_bmax(double s_, double m_) const {
@@ -1041,6 +1041,8 @@ struct Solver {
     // ---- polish (OSQP polish.c) on the reduced form ----------------------------------------------
     // active rows carry weight 1/delta in K_pol = P + delta I + A_act' A_act / delta; W > 0 marks
     // upper-active, W < 0 lower-active rows (|W| = 1/delta), W = 0 inactive.
+    // Results come back by value.  (An earlier version used reference parameters and returned wrong values in the N = 40
+    // instantiation; the cause turned out to be the machine-sink placement described in the Makefile, not the references.)
     struct PolishOut { int flag; double pri, dua, obj; };
     __device__ __forceinline__ PolishOut polish(double pri_res, double dua_res, double obj) {
         const double delta = cfg.delta, dinv = 1.0 / cfg.delta;
