@@ -1163,7 +1163,7 @@ static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveA
 
 // 1 if (kind, N) has a register-tile instantiation
 int solve_has_fast_path(int kind, int N) {
-    return (kind == 0 && (N == 20 || N == 10)) || (kind == 1 && (N == 30 || N == 40));
+    return (kind == 0 && (N == 20 || N == 10 || N == 8)) || (kind == 1 && (N == 30 || N == 40));
 }
 
 size_t solve_lds_bytes(int kind, int N) {
@@ -1178,6 +1178,7 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
     if (cfg.kind == 0) {
         if (!generic && cfg.N == 20) return one_wave ? launch_one<6, 20, 1>(cfg, dcfg, a, stream) : launch_one<6, 20, 2>(cfg, dcfg, a, stream);
         if (!generic && cfg.N == 10) return launch_one<6, 10, 1>(cfg, dcfg, a, stream);
+        if (!generic && cfg.N == 8) return launch_one<6, 8, 1>(cfg, dcfg, a, stream);      // the launch file's controller horizon (MAIN_LAUNCH.launch:117)
         return launch_one<6, 0, 1>(cfg, dcfg, a, stream);
     }
     if (!generic && cfg.N == 30) return one_wave ? launch_one<5, 30, 1>(cfg, dcfg, a, stream) : launch_one<5, 30, 2>(cfg, dcfg, a, stream);

@@ -150,7 +150,8 @@ def test_kernel_variants_agree(lpvmpc):
     differ in elimination order, i.e. in round-off only), solutions equal to 1e-6 (1e-8 when polished)."""
     from lpvmpc import workloads
     for w in (workloads.controller_batch(128, N=20, seed=5), workloads.planner_batch(64, N=30, seed=6),
-              workloads.planner_batch(48, N=40, seed=7), workloads.controller_batch(64, N=10, seed=8)):
+              workloads.planner_batch(48, N=40, seed=7), workloads.controller_batch(64, N=10, seed=8),
+              workloads.controller_batch(64, N=8, seed=9)):
         outs = []
         for variant in (0, 1, 2):
             eng = workloads.make_solver(w)
