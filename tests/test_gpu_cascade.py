@@ -159,9 +159,10 @@ def test_cascade_fleet_vs_oracle():
 
 
 def test_infeasible_planner_instance_stays_contained():
-    """With this start the planner QP of vehicle 0 (and later of a few others) turns primal infeasible: its own predicted
-    state leaves the box it is constrained to (quirk Q7).  The reference's node would publish NaN references from then
-    on; here such a vehicle carries NaN, every other vehicle is untouched and the engine keeps ticking."""
+    """With this start the planner QP of vehicle 0 (and later of a few others) turns primal infeasible (at vx ~ 1.1 m/s the
+    forward-Euler lateral dynamics of the planner model are unstable at dt = 0.05, the 40-step prediction blows up).
+    The reference's node would publish NaN references from then on; here such a vehicle carries NaN, every other
+    vehicle is untouched and the engine keeps ticking."""
     c = load("cascade")
     B = 8
     plant0 = fleet_start(c, 16, B)
