@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Planner + controller + plant cascade for a Monte-Carlo fleet (BASELINE.json configs[4] shape, one GPU's share):
 throughput in vehicle-ticks/s, real-time factor, how many vehicles are still alive (the reference's planner QP turns
-infeasible for some starts, quirk Q7: those vehicles carry NaN from then on), laps completed.
+infeasible for some starts -- its forward-Euler model is unstable below ~1.5 m/s at dt = 0.05 -- and those vehicles carry NaN
+from then on), laps completed.
 
 Start: the state at the reference's lap event (tests/golden/cascade.npz: plant0 / cmd0 / uPred0) with per-vehicle
 perturbations of lateral position, heading and speed (seed 3).
