@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+# (test infrastructure: uses the oracle as a checker; lives under tests/ for that reason)
+"""Seed / track sweep on a GPU box: default kernels against the C oracle tick on many random batches."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import lpvmpc
+from lpvmpc import workloads
+from oracle import osqp_ref as O
+
+tot = dict(n=0, st=0, it=0, close=0, fin=0)
+worst = 0.0
+for shape in ("oval", "L_shape", "3110", "Euge_Track"):
+    for seed in range(6):
+        for kind, N, lap in (("controller", 20, 1), ("controller", 20, 0), ("controller", 8, 1), ("planner", 30, 1), ("planner", 40, 1)):
+            B = 1024 if kind == "controller" else 512
+            w = workloads.controller_batch(B, N=N, seed=100 + seed, shape=shape) if kind == "controller" else workloads.planner_batch(B, N=N, seed=200 + seed, shape=shape)
+            w["lap"] = lap
+            eng = workloads.make_solver(w)
+            if kind == "controller":
+                a = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], lap)
+                ref = O.ctrl_tick_batch(w, nthreads=16)
+            else:
+                a = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+                ref = O.plan_tick_batch(w, nthreads=16)
+            eng.close()
+            # no answer from the oracle: KKT breakdown (-10), or a rolled-out abscissa outside the track table, where the
+            # reference's Curvature() raises (the C oracle marks it with NaN, the device uses the first / last segment)
+            sane = (ref["status"] != -10) & ~(np.isnan(ref["uPred"]).any(axis=(1, 2)) & (ref["status"] == 1))
+            fin = np.isfinite(ref["uPred"]).all(axis=(1, 2)) & np.isfinite(a["uPred"]).all(axis=(1, 2)) & sane
+            d = np.abs(a["uPred"][fin] - ref["uPred"][fin]).max(axis=(1, 2)) if fin.any() else np.zeros(0)
+            st = int(np.sum(a["status"][sane] == ref["status"][sane])); it = int(np.sum(a["iters"][sane] == ref["iters"][sane]))
+            tot["n"] += int(sane.sum()); tot["st"] += st; tot["it"] += it; tot["close"] += int(np.sum(d <= 1e-6)); tot["fin"] += int(fin.sum())
+            worst = max(worst, float(d.max()) if d.size else 0.0)
+            if st != sane.sum() or it < 0.995 * sane.sum() or (d.size and np.mean(d <= 1e-6) < 0.98):
+                print("ATTENTION %s seed %d %s N=%d lap=%d: status %d/%d iters %d/%d close %d/%d max %.2e" % (shape, seed, kind, N, lap, st, sane.sum(), it, sane.sum(), np.sum(d <= 1e-6), fin.sum(), d.max() if d.size else 0), flush=True)
+    print(shape, "done", tot, "worst du %.2e" % worst, flush=True)
