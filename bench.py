@@ -8,6 +8,9 @@ in HBM.  With --gpus N every rank (one process per GPU) runs its own 1024-instan
 independent instances, no data-path collective; torch.distributed over RCCL only for the barrier and the
 final max-time / iteration-count reduction).
 
+--workload cfg3 / cfg5 measure configs[2] (planner batch) and configs[4] (planner + controller + plant cascade) with the
+same contract; they are extra measurements, the headline is the default.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      algorithmic bytes of the ADMM solve kernel / its HIP-event-measured duration vs 8 TB/s
   cpu_baseline  the CPU oracle port (oracle/lpv_ref.c + oracle/osqp_ref.c) timed on the host cores
@@ -48,9 +51,10 @@ def main():
     ap.add_argument("--streams", type=int, default=32,
                     help="HIP streams the K steps are issued on round-robin (independent batches overlap, so the few "
                          "slow instances of one batch do not leave the GPU idle); 1 = strictly back-to-back steps")
-    ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg5"], default="cfg2",
                     help="cfg2 = configs[1] (the headline, default); cfg3 = configs[2]: planner LPV-MPP, N=30, L-shape "
-                         "(use --batch 4096) -- extra measurement, not the headline")
+                         "(use --batch 4096); cfg5 = configs[4]: planner + controller + plant cascade, a step is one 30 Hz "
+                         "controller tick of --batch vehicles per GPU (default 8192 / gpus) -- extra measurements, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -73,6 +77,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.workload == "cfg5":
+        return bench_cascade(args, rank, local_rank, world, dev)
     planner = args.workload == "cfg3"
     B, N = args.batch, (30 if planner else HORIZON)
     nx = 5 if planner else 6
@@ -227,6 +233,91 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def bench_cascade(args, rank, local_rank, world, dev):
+    """configs[4] shape: Monte-Carlo fleet, planner (N = 40 @ 20 Hz, the launch file's horizon: N = 30 cannot be handed
+    off) + Controller_TT (N = 20 @ 30 Hz) + plant, everything on the device; vehicles are split over
+    the ranks, no collective on the data path.  value = vehicle-ticks/s (all vehicles, dead ones included)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import lpvmpc
+    from lpvmpc import workloads as W
+    from lpvmpc.distributed import reduce_stats
+    B = args.batch if args.batch != BATCH else max(1, 8192 // world)
+    c = np.load(os.path.join(ROOT, "tests", "golden", "cascade.npz"))          # state at the reference's lap event (fixture data)
+    mp = lpvmpc.Map("L_shape", 0.2)
+    rng = np.random.default_rng(3 + 1000 * rank)
+    plant0 = np.tile(c["plant0"], (B, 1))
+    plant0[:, 1] += rng.normal(0, 0.01, B); plant0[:, 6] += rng.normal(0, 0.01, B); plant0[:, 2] += rng.uniform(-0.05, 0.3, B)
+    Qr, Rr, dRr = W.CTRL_TUNINGS["race"]
+    plan = lpvmpc.BatchedSolver("planner", 40, 0.05, W.PLAN_Q, W.PLAN_R, W.PLAN_dR, L_cf=W.PLAN_L, track=mp.PointAndTangent, device=local_rank)
+    plan.handoff_setup()
+    ctrl = lpvmpc.BatchedSolver("controller", 20, 1 / 30.0, Qr, Rr, dRr, track=mp.PointAndTangent, device=local_rank)
+    ctrl.cascade_init(plan, plant0, np.tile(c["cmd0"], (B, 1)), np.tile(c["uPred0"], (B, 1, 1)), half_width=mp.halfWidth, slack=mp.slack,
+                      plan_max_ey=0.2)
+
+    def fence():
+        ctrl.cascade_read(full=False)
+        if world > 1:
+            dist.barrier()
+
+    if args.warmup > 0:
+        ctrl.cascade_tick(args.warmup)
+    ctrl.set_timing(True); plan.set_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    ctrl.cascade_tick(args.steps)
+    o = ctrl.cascade_read(full=False)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    alive = np.all(np.isfinite(o["plant"]), axis=1)
+    pms, pn = plan.kernel_time_stats(); cms, cn = ctrl.kernel_time_stats()
+    elapsed, agg = reduce_stats(elapsed, [float(alive.sum())], device=dev)
+    if rank == 0:
+        it = o["plan_iters"].astype(np.int64)
+        bytes_launch, bytes_iter = algorithmic_bytes(it, N=40, nx=5, m_rows=41 * 5 + 41 * 5 + 40 * 2)
+        k_avg_s = pms / max(pn, 1) * 1e-3
+        out = {"metric": "closed-loop vehicle-ticks/sec (planner N=40 @20 Hz + controller N=20 @30 Hz + plant)", "value": B * world * args.steps / elapsed,
+               "unit": "vehicle-ticks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "strong" if args.batch == BATCH else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "configs[4]: %d vehicles per GPU, planner + controller cascade per 30 Hz tick, L-shape track, Monte-Carlo starts "
+                                      "around the lap-event state, cold start" % B, "vehicles_per_gpu": B, "alive_fraction": agg[0] / (B * world),
+                          "real_time_factor": (args.steps / 30.0) / elapsed, "planner_ticks": int(o["ticks"][1]),
+                          "ctrl_kernel_avg_ms": cms / max(cn, 1)},
+               "roofline": {"bound": "hbm", "achieved": bytes_launch / k_avg_s / 1e9 if pn else float("nan"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": (bytes_launch / k_avg_s / 1e9 / HBM_PEAK_GBS) if pn else float("nan"), "traffic": None,
+                            "kernel": "admm_solve_kernel<5, 40, 2>", "kernel_avg_ms": pms / max(pn, 1), "launches": pn,
+                            "note": "planner solve kernel (95 % of a tick); algorithmic bytes from the iteration counts of the last planner tick"}}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_cascade(c, mp, W)
+        print(json.dumps(out), flush=True)
+    ctrl.close(); plan.close()
+
+
+def cpu_baseline_cascade(c, mp, W, vehicles=64, ticks=60):
+    """The oracle cascade (oracle/cascade_ref.py) on a small fleet, all usable host cores."""
+    import numpy as np
+    from oracle import cascade_ref
+    cores = usable_cores()
+    rng = np.random.default_rng(3)
+    plant0 = np.tile(c["plant0"], (vehicles, 1))
+    plant0[:, 1] += rng.normal(0, 0.01, vehicles); plant0[:, 6] += rng.normal(0, 0.01, vehicles); plant0[:, 2] += rng.uniform(0.0, 0.3, vehicles)
+    ref = cascade_ref.CascadeRef(mp.PointAndTangent, W.CTRL_TUNINGS["race"], (W.PLAN_Q, W.PLAN_R, W.PLAN_dR, W.PLAN_L), plant0,
+                                 np.tile(c["cmd0"], (vehicles, 1)), np.tile(c["uPred0"], (vehicles, 1, 1)), half_width=mp.halfWidth,
+                                 slack=mp.slack, plan_max_ey=0.2, nthreads=cores)
+    t0 = time.perf_counter(); done = 0
+    try:
+        for _ in range(ticks):
+            ref.tick(); done += 1
+    except ValueError:            # a planner instance turned infeasible (NaN references): stop the sample there
+        pass
+    t = time.perf_counter() - t0
+    return {"value": vehicles * max(done, 1) / t, "unit": "vehicle-ticks/s", "cores": cores, "kind": "port",
+            "sample": "%d vehicles x %d controller ticks of oracle/cascade_ref.py (C tick functions under OpenMP, hand-off and plant in numpy), %.1f s"
+                      % (vehicles, done, t)}
 
 
 def cpu_baseline(w, target_s=12.0, planner=False):
