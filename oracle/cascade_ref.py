@@ -57,10 +57,17 @@ class CascadeRef:
             self.plan = osqp_ref.plan_tick_batch(w, nthreads=self.nthreads)
         self.pxPred, self.puPred = self.plan["xPred"], self.plan["uPred"]
         refs = []
+        M = H.n_resampled(Np, dtp)
         for b in range(B):
-            SS, last, xp, yp, yaw, vel, curv = H.planner_pose_refs(self.track, self.pxPred[b], self.SS[b], tuple(self.pose[b]), dtp)
-            self.SS[b] = SS; self.pose[b] = last
-            refs.append(H.resample_refs(xp, yp, yaw, vel, curv, dtp))
+            try:
+                SS, last, xp, yp, yaw, vel, curv = H.planner_pose_refs(self.track, self.pxPred[b], self.SS[b], tuple(self.pose[b]), dtp)
+                self.SS[b] = SS; self.pose[b] = last
+                refs.append(H.resample_refs(xp, yp, yaw, vel, curv, dtp))
+            except ValueError:
+                # NaN plan (an infeasible planner QP): the reference's node would publish NaN from here on; this vehicle is
+                # lost, the others go on (what the device engine does, tests/test_gpu_cascade.py)
+                self.SS[b] = np.nan; self.pose[b] = np.nan
+                refs.append(np.full((5, M), np.nan))
         self.refs = np.array(refs)
         self.plan_ticks += 1
 
