@@ -111,3 +111,32 @@ def test_ros_entry_points_exist_and_seeds_match_the_oracle():
     for f in ("controllerMain.py", "plannerMain.py"):
         assert os.access(os.path.join(root, "ros", f), os.X_OK)
     assert callable(ros_nodes.controller_main) and callable(ros_nodes.planner_main)
+
+
+def test_bench_algorithmic_bytes_follow_survey_8d():
+    """bytes per ADMM iteration of SURVEY 8(d): 28 656 B (controller N = 20) and 36 096 B (planner N = 30) in float64."""
+    import bench
+    it = np.array([50, 75, 25])
+    total, per_iter = bench.algorithmic_bytes(it)
+    assert per_iter == 28656
+    F, n_z = 21 * (36 + 64), 166
+    per_solve = 8 * (2 * F + 20 * (36 + 12) + (6 + 40 + 42 + 2) + (n_z + 4))
+    assert total == 150 * 28656 + 3 * per_solve
+    _, per_iter_p = bench.algorithmic_bytes(it, N=30, nx=5, m_rows=31 * 5 + 31 * 5 + 30 * 2)
+    assert per_iter_p == 36096
+    assert bench.usable_cores() >= 1
+
+
+def test_shard_range_property():
+    from hypothesis import given, settings, strategies as st
+    from lpvmpc.distributed import shard_range
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(0, 100000), st.integers(1, 64))
+    def prop(total, world):
+        cuts = [shard_range(total, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+    prop()
