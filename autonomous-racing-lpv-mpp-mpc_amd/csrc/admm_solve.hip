@@ -211,7 +211,7 @@ struct Solver {
     // row a of the stage-k Hessian block times (D_k .* v_k), plus the slew-rate coupling to the neighbouring
     // stages; ABS = true gives the infinity norm of the (scaled) column instead.  Branch-free: the Pm row is
     // zero outside its diagonal block, the stage-N input rows are switched off explicitly.
-    template <bool ABS>
+    template <bool ABS, bool RAW = false>
     __device__ __forceinline__ double P_row(int k, const double *v) const {
         const int a = tj, e = k * 8 + a;
         const double2 *pr = reinterpret_cast<const double2 *>(Pm + a * 8);
@@ -235,6 +235,7 @@ struct Solver {
         const double dn = (k + 1 < N) ? D[en] : 0.0, dp = (k >= 1) ? D[ep] : 0.0;
         if (ABS) { acc = fmax(acc, fabs(cpl) * dn); acc = fmax(acc, fabs(cpl) * dp); }
         else acc -= cpl * (dn * v[en] + dp * v[ep]);
+        if (RAW) return (inp && k >= N) ? 0.0 : acc;           // the caller applies (acc * c) * D[e]
         return (inp && k >= N) ? 0.0 : acc * c * D[e];
     }
     // dst = P * src   (P = c D P0 D)
@@ -243,15 +244,21 @@ struct Solver {
     }
     // infinity norm of column (k, tj) of the scaled Hessian
     __device__ __forceinline__ double P_colnorm(int k, int) const { return P_row<true>(k, D); }
+    // the same without the final scaling by c D[e] (it depends on D only: reusable until D changes)
+    __device__ __forceinline__ double P_colacc(int k) const { return P_row<true, true>(k, D); }
 
     // ---- Ruiz equilibration (OSQP scale_data) ----------------------------------------------------
     // D, E and c are accumulated while the [A|B] tiles stay UNSCALED (entries are multiplied by the current
     // E and D on the fly when the norms are taken); the tiles are scaled once at the end.
     __device__ __forceinline__ void scale_data() {
         const int ntrue = NS * NX + N * 2;
+        // rounds of the element loops; with a compile-time horizon the un-scaled Hessian column norms of the cost
+        // normalisation are kept for the next iteration's column norms (D does not change in between): one pass less
+        constexpr int kRounds = kReg ? ((NT + 1) * 8 + kStride - 1) / kStride : 1;
+        double pacc[kRounds];
         for (int it = 0; it < cfg.scaling; ++it) {
             // infinity norms of the columns of [P A'; A 0] -> step factors in XT (variables), ZTd / ZTb (rows)
-            for (int e = tid; e < NS * 8; e += kStride) {
+            auto norms = [&](int e, double pcol) {
                 const int k = e >> 3, a = tj, kn = k < N ? k + 1 : N, kp = k > 0 ? k - 1 : 0;
                 const double de = D[e], ede = Ed[e], ebe = Eb[e];
                 const double *col = tA + k * kTS + a, *row = tA + kp * kTS + a * 8;
@@ -262,7 +269,7 @@ struct Solver {
                 for (int b = 0; b < NB; ++b) rmax = fmax(rmax, fabs(row[b]) * D[kp * 8 + b]);
                 double dn = 0.0;
                 if (a < nvar(k)) {
-                    dn = fmax(P_colnorm(k, a), cmax * de);
+                    dn = fmax(pcol, cmax * de);
                     if (r0 < nbox(k)) dn = fmax(dn, Eb[k * 8 + r0] * de);
                     if (r1 < nbox(k)) dn = fmax(dn, Eb[k * 8 + r1] * de);
                     if (a < NX) dn = fmax(dn, ede * de);
@@ -274,15 +281,36 @@ struct Solver {
                 XT[e] = inv_sqrt(limit_scaling(dn));
                 ZTd[e] = inv_sqrt(limit_scaling(en));
                 ZTb[e] = inv_sqrt(limit_scaling(bn));
+            };
+            if constexpr (kReg) {
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r) {
+                    const int e = tid + r * kStride;
+                    if (e < NS * 8) norms(e, it == 0 ? P_colnorm(e >> 3, tj) : pacc[r] * c * D[e]);
+                }
+            } else {
+                for (int e = tid; e < NS * 8; e += kStride) norms(e, P_colnorm(e >> 3, tj));
             }
             sync();
             for (int e = tid; e < NS * 8; e += kStride) { D[e] *= XT[e]; Ed[e] *= ZTd[e]; Eb[e] *= ZTb[e]; }
             sync();
             // cost normalisation
             double psum = 0.0, qmax = 0.0;
-            for (int e = tid; e < NS * 8; e += kStride) {
-                psum += P_colnorm(e >> 3, tj);
-                qmax = fmax(qmax, fabs(c * D[e] * Qv[e]));
+            if constexpr (kReg) {
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r) {
+                    const int e = tid + r * kStride;
+                    if (e < NS * 8) {
+                        pacc[r] = P_colacc(e >> 3);
+                        psum += pacc[r] * c * D[e];
+                        qmax = fmax(qmax, fabs(c * D[e] * Qv[e]));
+                    }
+                }
+            } else {
+                for (int e = tid; e < NS * 8; e += kStride) {
+                    psum += P_colnorm(e >> 3, tj);
+                    qmax = fmax(qmax, fabs(c * D[e] * Qv[e]));
+                }
             }
             const SumMax pq = bsum_bmax<0>(psum, qmax);
             psum = pq.s / (double)ntrue;
