@@ -681,7 +681,10 @@ struct Solver {
     }
 
     // ---- residuals (OSQP update_info) -----------------------------------------------------------
-    struct Res { double pri, dua, nAx, nz, nPx, nAty, nq, s_pri, s_dua, s_Ax, s_z, s_Px, s_Aty, s_q; };
+    // pri / dua: residual norms; nAxz = max(|Ax|, |z|), nPAq = max(|Px|, |A'y|, |q|) (all that OSQP's tolerances need);
+    // s_*: the same in the scaled problem (adaptive rho).  Maxima are exact, so merging them before the cross-lane
+    // reductions changes nothing but the number of reductions (8 instead of 14).
+    struct Res { double pri, dua, nAxz, nPAq, s_pri, s_dua, s_Axz, s_PAq; };
 
     // (xv, zd/zb, yd/yb) -> residual norms; leaves A x in ZT*, P x in VT, A'y in AT
     __device__ __forceinline__ Res residuals(const double *xv, const double *zd, const double *zb, const double *yd, const double *yb) {
@@ -689,37 +692,33 @@ struct Solver {
         P_mul(xv, VT);
         At_mul(yd, yb, AT);
         sync();
-        Res r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        Res r = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int e = tid; e < NS * 8; e += kStride) {
             const double eid = 1.0 / Ed[e], eib = 1.0 / Eb[e], di = 1.0 / D[e];
             const double rd = ZTd[e] - zd[e], rb = ZTb[e] - zb[e];
             r.s_pri = fmax(r.s_pri, fmax(fabs(rd), fabs(rb)));
             r.pri = fmax(r.pri, fmax(fabs(eid * rd), fabs(eib * rb)));
-            r.s_Ax = fmax(r.s_Ax, fmax(fabs(ZTd[e]), fabs(ZTb[e])));
-            r.nAx = fmax(r.nAx, fmax(fabs(eid * ZTd[e]), fabs(eib * ZTb[e])));
-            r.s_z = fmax(r.s_z, fmax(fabs(zd[e]), fabs(zb[e])));
-            r.nz = fmax(r.nz, fmax(fabs(eid * zd[e]), fabs(eib * zb[e])));
+            r.s_Axz = fmax(r.s_Axz, fmax(fmax(fabs(ZTd[e]), fabs(ZTb[e])), fmax(fabs(zd[e]), fabs(zb[e]))));
+            r.nAxz = fmax(r.nAxz, fmax(fmax(fabs(eid * ZTd[e]), fabs(eib * ZTb[e])), fmax(fabs(eid * zd[e]), fabs(eib * zb[e]))));
             const double dr = Qv[e] + VT[e] + AT[e];
             r.s_dua = fmax(r.s_dua, fabs(dr));       r.dua = fmax(r.dua, fabs(di * dr));
-            r.s_Px = fmax(r.s_Px, fabs(VT[e]));      r.nPx = fmax(r.nPx, fabs(di * VT[e]));
-            r.s_Aty = fmax(r.s_Aty, fabs(AT[e]));    r.nAty = fmax(r.nAty, fabs(di * AT[e]));
-            r.s_q = fmax(r.s_q, fabs(Qv[e]));        r.nq = fmax(r.nq, fabs(di * Qv[e]));
+            r.s_PAq = fmax(r.s_PAq, fmax(fmax(fabs(VT[e]), fabs(AT[e])), fabs(Qv[e])));
+            r.nPAq = fmax(r.nPAq, fmax(fmax(fabs(di * VT[e]), fabs(di * AT[e])), fabs(di * Qv[e])));
         }
-        double m_[14] = {r.pri, r.dua, r.nAx, r.nz, r.nPx, r.nAty, r.nq, r.s_pri, r.s_dua, r.s_Ax, r.s_z, r.s_Px, r.s_Aty, r.s_q};
+        double m_[8] = {r.pri, r.dua, r.nAxz, r.nPAq, r.s_pri, r.s_dua, r.s_Axz, r.s_PAq};
 #pragma unroll
-        for (int i = 0; i < 14; ++i) m_[i] = wave_max(m_[i]);
+        for (int i = 0; i < 8; ++i) m_[i] = wave_max(m_[i]);
         if constexpr (kTwo) {
             if (lane == 0) {
 #pragma unroll
-                for (int i = 0; i < 14; ++i) RED[wv * 16 + i] = m_[i];
+                for (int i = 0; i < 8; ++i) RED[wv * 16 + i] = m_[i];
             }
             sync();
 #pragma unroll
-            for (int i = 0; i < 14; ++i) m_[i] = fmax(RED[i], RED[16 + i]);
+            for (int i = 0; i < 8; ++i) m_[i] = fmax(RED[i], RED[16 + i]);
         }
-        r.pri = m_[0]; r.dua = cinv * m_[1]; r.nAx = m_[2]; r.nz = m_[3];
-        r.nPx = cinv * m_[4]; r.nAty = cinv * m_[5]; r.nq = cinv * m_[6];
-        r.s_pri = m_[7]; r.s_dua = m_[8]; r.s_Ax = m_[9]; r.s_z = m_[10]; r.s_Px = m_[11]; r.s_Aty = m_[12]; r.s_q = m_[13];
+        r.pri = m_[0]; r.dua = cinv * m_[1]; r.nAxz = m_[2]; r.nPAq = cinv * m_[3];
+        r.s_pri = m_[4]; r.s_dua = m_[5]; r.s_Axz = m_[6]; r.s_PAq = m_[7];
         sync();
         return r;
     }
@@ -957,7 +956,7 @@ struct Solver {
         const double alpha = cfg.alpha, sigma = cfg.sigma;
         int status = LPVMPC_UNSOLVED_, iter = 0, status_polish = 0;
         double pri_res = 0, dua_res = 0, obj = __builtin_nan("");
-        Res R = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        Res R = {0, 0, 0, 0, 0, 0, 0, 0};
         bool checked = false;
         for (iter = 1; iter <= cfg.max_iter; ++iter) {
             checked = cfg.check_termination > 0 && (iter % cfg.check_termination == 0);
@@ -1049,9 +1048,9 @@ struct Solver {
         if (R.pri > kInfty || R.dua > kInfty) return LPVMPC_NON_CVX_;
         if (approx) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
         bool prc = false, drc = false, pic = false, dic = false;
-        const double ep = ea + er * fmax(R.nz, R.nAx);
+        const double ep = ea + er * R.nAxz;
         if (R.pri < ep) prc = true; else pic = primal_infeasible(epi);
-        const double ed = ea + er * fmax(R.nq, fmax(R.nAty, R.nPx));
+        const double ed = ea + er * R.nPAq;
         if (R.dua < ed) drc = true; else dic = dual_infeasible(edi);
         if (prc && drc) return approx ? LPVMPC_SOLVED_INACC_ : LPVMPC_SOLVED_;
         if (pic) return approx ? LPVMPC_PRIMAL_INFEASIBLE_INACC_ : LPVMPC_PRIMAL_INFEASIBLE_;
@@ -1060,8 +1059,8 @@ struct Solver {
     }
     // OSQP compute_rho_estimate (scaled-space norms)
     __device__ __forceinline__ double rho_estimate(const Res &R, double rho) const {
-        const double pr = R.s_pri / (fmax(R.s_z, R.s_Ax) + 1e-10);
-        const double dr = R.s_dua / (fmax(R.s_q, fmax(R.s_Aty, R.s_Px)) + 1e-10);
+        const double pr = R.s_pri / (R.s_Axz + 1e-10);
+        const double dr = R.s_dua / (R.s_PAq + 1e-10);
         const double rn = rho * sqrt(pr / (dr + 1e-10));
         return fmin(fmax(rn, kRhoMin), kRhoMax);
     }
