@@ -107,6 +107,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->d_status = h->d_iters = h->d_polish = nullptr; h->d_state = nullptr; h->warm_mode = 0; h->state_valid_B = 0;
     h->cl_plant = h->cl_local = h->cl_cmd = nullptr; h->cl_B = 0; h->cl_first_it = 1; h->cl_q9 = 1; h->cl_ticks = 0;
     h->d_Wop = h->d_FWop = nullptr; h->ho_M = 0; h->cascade = nullptr; h->cascade_prefetch = 1;
+    h->h_pack_in = h->h_pack_out = h->d_pack_in = h->d_pack_out = nullptr;
     DevCfg &d = h->dev;
     std::memset(&d, 0, sizeof(d));
     d.kind = cfg->kind; d.N = cfg->N; d.track_rows = cfg->track_rows; d.max_iter = cfg->max_iter;
@@ -147,6 +148,10 @@ extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
     if (h->cl_local) (void)hipFree(h->cl_local);
     if (h->cl_cmd) (void)hipFree(h->cl_cmd);
     if (h->cascade) lpvmpc_cascade_free(h);
+    if (h->h_pack_in) (void)hipHostFree(h->h_pack_in);
+    if (h->h_pack_out) (void)hipHostFree(h->h_pack_out);
+    if (h->d_pack_in) (void)hipFree(h->d_pack_in);
+    if (h->d_pack_out) (void)hipFree(h->d_pack_out);
     if (h->d_Wop) (void)hipFree(h->d_Wop);
     if (h->d_FWop) (void)hipFree(h->d_FWop);
     if (h->d_cfg) (void)hipFree(h->d_cfg);
@@ -237,6 +242,59 @@ int lpvmpc_check_common(lpvmpc_handle *h, int B, const char *who) {
 }
 
 
+
+// ------------------------------------------------------------------------------------------------
+// Small batches (the 30 Hz control loop calls with B = 1): every host array of a call travels through ONE pinned
+// staging buffer and ONE copy per direction instead of one pageable copy per array (11 copies per fused tick).
+// Large batches keep the direct copies.  in() / out() return the device pointer the kernels must use.
+// ------------------------------------------------------------------------------------------------
+static const size_t kPackBytes = 512 * 1024;
+struct IoPack {
+    lpvmpc_handle *h; hipStream_t st; bool on; size_t in_off, out_off;
+    struct Out { void *user, *dev; size_t off, bytes; } outs[8];
+    int n_out;
+    static size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
+    int begin(lpvmpc_handle *h_, hipStream_t st_, size_t in_bytes, size_t out_bytes, int n_arrays) {
+        h = h_; st = st_; in_off = out_off = 0; n_out = 0;
+        on = in_bytes + 256 * (size_t)n_arrays <= kPackBytes && out_bytes + 256 * (size_t)n_arrays <= kPackBytes;
+        if (on && !h->h_pack_in) {
+            HIP_TRY(h, hipHostMalloc((void **)&h->h_pack_in, kPackBytes)); HIP_TRY(h, hipHostMalloc((void **)&h->h_pack_out, kPackBytes));
+            HIP_TRY(h, hipMalloc((void **)&h->d_pack_in, kPackBytes)); HIP_TRY(h, hipMalloc((void **)&h->d_pack_out, kPackBytes));
+        }
+        return LPVMPC_OK;
+    }
+    // host staging area of an input (packed mode) -- lets a caller write a re-laid-out array directly
+    void *in_slot(size_t bytes, void **dev) { void *p = h->h_pack_in + in_off; *dev = h->d_pack_in + in_off; in_off += al(bytes); return p; }
+    int in(const void *src, void *dev_default, size_t bytes, void **dev) {
+        if (!on) { *dev = dev_default; HIP_TRY(h, hipMemcpyAsync(dev_default, src, bytes, hipMemcpyHostToDevice, st)); return LPVMPC_OK; }
+        std::memcpy(in_slot(bytes, dev), src, bytes);
+        return LPVMPC_OK;
+    }
+    int flush_in() {
+        if (on && in_off) HIP_TRY(h, hipMemcpyAsync(h->d_pack_in, h->h_pack_in, in_off, hipMemcpyHostToDevice, st));
+        return LPVMPC_OK;
+    }
+    void *out(void *user, void *dev_default, size_t bytes) {          // user may be NULL (result not wanted)
+        void *dev = on ? (void *)(h->d_pack_out + out_off) : dev_default;
+        outs[n_out++] = Out{user, dev, out_off, bytes};
+        if (on) out_off += al(bytes);
+        return dev;
+    }
+    const void *host_of(int i) const { return h->h_pack_out + outs[i].off; }           // valid after flush_out in packed mode
+    int flush_out() {
+        if (on) {
+            if (out_off) HIP_TRY(h, hipMemcpyAsync(h->h_pack_out, h->d_pack_out, out_off, hipMemcpyDeviceToHost, st));
+            HIP_TRY(h, hipStreamSynchronize(st));
+            for (int i = 0; i < n_out; ++i) if (outs[i].user) std::memcpy(outs[i].user, h->h_pack_out + outs[i].off, outs[i].bytes);
+        } else {
+            for (int i = 0; i < n_out; ++i) if (outs[i].user) HIP_TRY(h, hipMemcpyAsync(outs[i].user, outs[i].dev, outs[i].bytes, hipMemcpyDeviceToHost, st));
+            HIP_TRY(h, hipStreamSynchronize(st));
+        }
+        return LPVMPC_OK;
+    }
+};
+#define IO_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
 extern "C" int lpvmpc_lpv_batch(lpvmpc_handle *h, int32_t B, const double *x0, const double *u_prev,
                                 const double *vel_ref, const double *curv_s, double cf_new, int32_t lap,
                                 double *states, double *A, double *Bm) {
@@ -250,21 +308,31 @@ extern "C" int lpvmpc_lpv_batch(lpvmpc_handle *h, int32_t B, const double *x0, c
     if ((ctrl && lap == 0) || !ctrl) { rc = lpvmpc_need_track(h, "lpvmpc_lpv_batch"); if (rc) return rc; }
     const size_t N = h->cfg.N, nx = h->nx, nb = h->nb, b = B;
     hipStream_t st = h->stream;
-    H2D(h->d_x0, x0, b * nx * 8); H2D(h->d_uprev, u_prev, b * N * 2 * 8);
-    if (ctrl) H2D(h->d_vel, vel_ref, b * (N + 1) * 8);
-    if (curv_s) H2D(h->d_curv, curv_s, b * (ctrl ? N : N + 1) * 8);
-    rc = launch_lpv(h, B, h->d_x0, h->d_uprev, h->d_vel, h->d_curv, cf_new, lap, h->d_states, h->d_AB, st); if (rc) return rc;
+    const size_t n_ab = b * N * nx * nb, n_st = b * N * nx;
+    IoPack io;
+    IO_TRY(io.begin(h, st, (b * nx + b * N * 2 + b * (N + 1) * 2) * 8, (n_ab + n_st) * 8, 6));
+    void *p_x0, *p_up, *p_vel = nullptr, *p_curv = nullptr;
+    IO_TRY(io.in(x0, h->d_x0, b * nx * 8, &p_x0)); IO_TRY(io.in(u_prev, h->d_uprev, b * N * 2 * 8, &p_up));
+    if (ctrl) IO_TRY(io.in(vel_ref, h->d_vel, b * (N + 1) * 8, &p_vel));
+    if (curv_s) IO_TRY(io.in(curv_s, h->d_curv, b * (ctrl ? N : N + 1) * 8, &p_curv));
+    IO_TRY(io.flush_in());
     std::vector<double> ab;
-    if (A || Bm) { ab.resize(b * N * nx * nb); D2H(ab.data(), h->d_AB, ab.size() * 8); }
-    if (states) D2H(states, h->d_states, b * N * nx * 8);
-    HIP_TRY(h, hipStreamSynchronize(st));
-    if (A || Bm)
+    if (!io.on && (A || Bm)) ab.resize(n_ab);
+    // packed mode: [A|B] is de-interleaved straight from the staging buffer (no user copy of the raw block)
+    double *p_ab = (double *)io.out(io.on ? nullptr : (void *)ab.data(), h->d_AB, n_ab * 8);
+    double *p_states = (double *)io.out(states, h->d_states, n_st * 8);
+    rc = launch_lpv(h, B, (const double *)p_x0, (const double *)p_up, (const double *)p_vel, (const double *)p_curv, cf_new, lap, p_states, p_ab, st);
+    if (rc) return rc;
+    IO_TRY(io.flush_out());
+    if (A || Bm) {
+        const double *src = io.on ? (const double *)io.host_of(0) : ab.data();
         for (size_t t = 0; t < b * N; ++t)
             for (size_t r = 0; r < nx; ++r) {
-                const double *row = ab.data() + (t * nx + r) * nb;
+                const double *row = src + (t * nx + r) * nb;
                 if (A) for (size_t a = 0; a < nx; ++a) A[(t * nx + r) * nx + a] = row[a];
                 if (Bm) { Bm[(t * nx + r) * 2 + 0] = row[nx]; Bm[(t * nx + r) * 2 + 1] = row[nx + 1]; }
             }
+    }
     return LPVMPC_OK;
 }
 
@@ -290,19 +358,6 @@ extern "C" int lpvmpc_estimate_abc_batch(lpvmpc_handle *h, int32_t B, const doub
     return LPVMPC_OK;
 }
 
-static int copy_out(lpvmpc_handle *h, int B, double *xPred, double *uPred, int32_t *status, int32_t *iters,
-                    double *resid, int32_t *polish, hipStream_t st) {
-    const size_t N = h->cfg.N, nx = h->nx, b = B;
-    if (xPred) D2H(xPred, h->d_xPred, b * (N + 1) * nx * 8);
-    if (uPred) D2H(uPred, h->d_uPred, b * N * 2 * 8);
-    if (status) D2H(status, h->d_status, b * 4);
-    if (iters) D2H(iters, h->d_iters, b * 4);
-    if (resid) D2H(resid, h->d_resid, b * 4 * 8);
-    if (polish) D2H(polish, h->d_polish, b * 4);
-    HIP_TRY(h, hipStreamSynchronize(st));
-    return LPVMPC_OK;
-}
-
 extern "C" int lpvmpc_solve_batch_AB(lpvmpc_handle *h, int32_t B, const double *x0, const double *A, const double *Bm,
                                      const double *vel_ref, const double *u_old, const double *max_ey,
                                      double *xPred, double *uPred, int32_t *status, int32_t *iters, double *resid,
@@ -314,24 +369,37 @@ extern "C" int lpvmpc_solve_batch_AB(lpvmpc_handle *h, int32_t B, const double *
     if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_AB: controller needs vel_ref");
     if (!ctrl && !max_ey) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_AB: planner needs max_ey");
     const size_t N = h->cfg.N, nx = h->nx, nb = h->nb, b = B;
-    std::vector<double> ab(b * N * nx * nb);
+    hipStream_t st = h->stream;
+    const size_t n_ab = b * N * nx * nb, n_x = b * (N + 1) * nx, n_u = b * N * 2;
+    IoPack io;
+    IO_TRY(io.begin(h, st, (b * nx + n_ab + b * (N + 1) + b * 3) * 8, (n_x + n_u + b * 4) * 8 + b * 12, 12));
+    void *p_x0, *p_ab, *p_vel = nullptr, *p_uold = nullptr, *p_mey = nullptr;
+    IO_TRY(io.in(x0, h->d_x0, b * nx * 8, &p_x0));
+    std::vector<double> ab;
+    double *abh;
+    if (io.on) abh = (double *)io.in_slot(n_ab * 8, &p_ab);                 // interleave [A|B] straight into the staging buffer
+    else { ab.resize(n_ab); abh = ab.data(); }
     for (size_t t = 0; t < b * N; ++t)
         for (size_t r = 0; r < nx; ++r) {
-            double *row = ab.data() + (t * nx + r) * nb;
+            double *row = abh + (t * nx + r) * nb;
             for (size_t a = 0; a < nx; ++a) row[a] = A[(t * nx + r) * nx + a];
             row[nx] = Bm[(t * nx + r) * 2 + 0]; row[nx + 1] = Bm[(t * nx + r) * 2 + 1];
         }
-    hipStream_t st = h->stream;
-    H2D(h->d_x0, x0, b * nx * 8); H2D(h->d_AB, ab.data(), ab.size() * 8);
-    if (ctrl) H2D(h->d_vel, vel_ref, b * (N + 1) * 8);
-    if (u_old) H2D(h->d_uold, u_old, b * 2 * 8);
-    if (!ctrl) H2D(h->d_maxey, max_ey, b * 8);
-    SolveArgs a{B, h->d_x0, h->d_AB, ctrl ? h->d_vel : nullptr, u_old ? h->d_uold : nullptr, ctrl ? nullptr : h->d_maxey,
-                h->d_xPred, h->d_uPred, h->d_status, h->d_iters, h->d_polish, h->d_resid,
+    if (!io.on) { p_ab = h->d_AB; H2D(h->d_AB, ab.data(), n_ab * 8); }
+    if (ctrl) IO_TRY(io.in(vel_ref, h->d_vel, b * (N + 1) * 8, &p_vel));
+    if (u_old) IO_TRY(io.in(u_old, h->d_uold, b * 2 * 8, &p_uold));
+    if (!ctrl) IO_TRY(io.in(max_ey, h->d_maxey, b * 8, &p_mey));
+    IO_TRY(io.flush_in());
+    double *o_x = (double *)io.out(xPred, h->d_xPred, n_x * 8), *o_u = (double *)io.out(uPred, h->d_uPred, n_u * 8);
+    int32_t *o_st = (int32_t *)io.out(status, h->d_status, b * 4), *o_it = (int32_t *)io.out(iters, h->d_iters, b * 4);
+    double *o_res = (double *)io.out(resid, h->d_resid, b * 4 * 8);
+    int32_t *o_pol = (int32_t *)io.out(polish, h->d_polish, b * 4);
+    SolveArgs a{B, (const double *)p_x0, (const double *)p_ab, (const double *)p_vel, (const double *)p_uold, (const double *)p_mey,
+                o_x, o_u, o_st, o_it, o_pol, o_res,
                 h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0, h->nx};
     rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
     if (h->warm_mode) h->state_valid_B = B;
-    return copy_out(h, B, xPred, uPred, status, iters, resid, polish, st);
+    return io.flush_out();
 }
 
 extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double *x0, const double *u_prev,
@@ -368,16 +436,24 @@ extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0,
     if (!ctrl && (!curv_s || !max_ey)) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch: planner needs SS and max_ey");
     const size_t N = h->cfg.N, nx = h->nx, b = B;
     hipStream_t st = h->stream;
-    H2D(h->d_x0, x0, b * nx * 8); H2D(h->d_uprev, u_prev, b * N * 2 * 8);
-    if (ctrl) H2D(h->d_vel, vel_ref, b * (N + 1) * 8);
-    if (curv_s) H2D(h->d_curv, curv_s, b * (ctrl ? N : N + 1) * 8);
-    if (u_old) H2D(h->d_uold, u_old, b * 2 * 8);
-    if (!ctrl) H2D(h->d_maxey, max_ey, b * 8);
-    rc = lpvmpc_solve_batch_dev(h, B, h->d_x0, h->d_uprev, ctrl ? h->d_vel : nullptr, curv_s ? h->d_curv : nullptr,
-                                u_old ? h->d_uold : nullptr, ctrl ? nullptr : h->d_maxey, cf_new, lap, h->d_xPred,
-                                h->d_uPred, h->d_status, h->d_iters, h->d_resid, h->d_polish, (void *)st);
+    const size_t n_x = b * (N + 1) * nx, n_u = b * N * 2;
+    IoPack io;
+    IO_TRY(io.begin(h, st, (b * nx + n_u + b * (N + 1) * 2 + b * 3) * 8, (n_x + n_u + b * 4) * 8 + b * 12, 12));
+    void *p_x0, *p_up, *p_vel = nullptr, *p_curv = nullptr, *p_uold = nullptr, *p_mey = nullptr;
+    IO_TRY(io.in(x0, h->d_x0, b * nx * 8, &p_x0)); IO_TRY(io.in(u_prev, h->d_uprev, n_u * 8, &p_up));
+    if (ctrl) IO_TRY(io.in(vel_ref, h->d_vel, b * (N + 1) * 8, &p_vel));
+    if (curv_s) IO_TRY(io.in(curv_s, h->d_curv, b * (ctrl ? N : N + 1) * 8, &p_curv));
+    if (u_old) IO_TRY(io.in(u_old, h->d_uold, b * 2 * 8, &p_uold));
+    if (!ctrl) IO_TRY(io.in(max_ey, h->d_maxey, b * 8, &p_mey));
+    IO_TRY(io.flush_in());
+    double *o_x = (double *)io.out(xPred, h->d_xPred, n_x * 8), *o_u = (double *)io.out(uPred, h->d_uPred, n_u * 8);
+    int32_t *o_st = (int32_t *)io.out(status, h->d_status, b * 4), *o_it = (int32_t *)io.out(iters, h->d_iters, b * 4);
+    double *o_res = (double *)io.out(resid, h->d_resid, b * 4 * 8);
+    int32_t *o_pol = (int32_t *)io.out(polish, h->d_polish, b * 4);
+    rc = lpvmpc_solve_batch_dev(h, B, (const double *)p_x0, (const double *)p_up, (const double *)p_vel, (const double *)p_curv,
+                                (const double *)p_uold, (const double *)p_mey, cf_new, lap, o_x, o_u, o_st, o_it, o_res, o_pol, (void *)st);
     if (rc) return rc;
-    return copy_out(h, B, xPred, uPred, status, iters, resid, polish, st);
+    return io.flush_out();
 }
 
 // ------------------------------------------------------------------------------------------------

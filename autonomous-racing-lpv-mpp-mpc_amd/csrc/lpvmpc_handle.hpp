@@ -42,6 +42,8 @@ struct lpvmpc_handle {
     int force_generic;                  // 1: always use the run-time-horizon kernel (validation)
     double last_ms;
     std::string err;
+    // small-batch I/O staging (lpvmpc_api.hip, IoPack): one pinned host buffer and one device buffer per direction
+    char *h_pack_in, *h_pack_out, *d_pack_in, *d_pack_out;
     // planner -> controller hand-off operators (lpvmpc_handoff_setup, planner handles): [M][N] row-major each
     double *d_Wop, *d_FWop;
     int ho_M;
