@@ -115,7 +115,8 @@ int lpvmpc_last_error_code(void);
  * "force_generic_kernel" (0/1) is shorthand for variants 0 / 1.  Used by the tests to cross-check the kernels.
  * "warm_start": 0 = every solve starts from x = z = y = 0 like the reference (fresh OSQP object per call,
  * CTRL:302,316 / PLAN:204-208; default); 1 = start from the previous solve's (x, y) of the same handle and
- * batch size; 2 = the same shifted by one stage (receding horizon).  Opt-in, changes iteration counts, not optima. */
+ * batch size; 2 = the same shifted by one stage (receding horizon).  Opt-in, changes iteration counts, not optima.
+ * "cascade_prefetch" (0/1, default 1): read by lpvmpc_cascade_init on the controller handle, see there. */
 int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value);
 
 /* Pre-size the device workspace for batches up to B (otherwise grown on demand). */
