@@ -84,3 +84,30 @@ def test_c_planner_tick_matches_python_assembly():
         if np.all(np.isfinite(rr.x)):
             xP, uP, _ = L.unpack_solution(rr.x, 5, 2, 30)
             assert max(np.abs(r["xPred"][b] - xP).max(), np.abs(r["uPred"][b] - uP).max()) <= 1e-8
+
+
+def test_primal_infeasibility_verdicts_agree_with_an_lp_solver():
+    """Independent pin of the oracle's OSQP infeasibility certificate logic: on 96 planner instances of the cfg 3
+    distribution every instance the oracle calls primal infeasible (status -3 / 3) has an empty constraint set according
+    to scipy's HiGHS, and every instance it solves has a non-empty one."""
+    from scipy import sparse
+    from scipy.optimize import linprog
+    from lpvmpc import workloads
+    w = workloads.planner_batch(96, N=30, seed=1)
+    ref = O.plan_tick_batch(w, nthreads=4)
+    seen = {1: 0, -3: 0}
+    for b in range(96):
+        st = int(ref["status"][b])
+        if st not in (1, -3, 3) or (st == 1 and seen[1] >= 12):
+            continue
+        S, A, Bm = L.plan_lpv_prediction(L.DEFAULT_PARAMS, w["dt"], 30, w["track"], w["x0"][b], w["curv_s"][b], w["u_prev"][b])
+        qp = L.plan_build_qp(w["Q"], w["R"], w["dR"], w["L_cf"], 30, A, Bm, w["x0"][b], w["u_old"][b], 0.2, 5.0, 0.9)
+        Aq = sparse.csr_matrix(qp.A)
+        eq = np.isclose(qp.l, qp.u)
+        Ai, li, ui = Aq[~eq], qp.l[~eq], qp.u[~eq]
+        Aub = sparse.vstack([Ai, -Ai]); bub = np.concatenate([ui, -li]); fin = np.isfinite(bub)
+        r = linprog(np.zeros(Aq.shape[1]), A_ub=Aub[fin], b_ub=bub[fin], A_eq=Aq[eq], b_eq=qp.u[eq],
+                    bounds=[(None, None)] * Aq.shape[1], method="highs")
+        assert (r.status == 0) == (st == 1), (b, st, r.status)
+        seen[1 if st == 1 else -3] += 1
+    assert seen[1] >= 10 and seen[-3] >= 8
