@@ -317,6 +317,32 @@ def test_empty_and_single_instance_batches(lpvmpc):
     assert one["iters"][0] == full["iters"][0]
 
 
+def test_small_batch_staging_path_equals_direct_copies(lpvmpc):
+    """Host-array calls whose arrays fit 512 KB go through one pinned staging buffer per direction, larger ones use a
+    copy per array: the first 48 instances of a 640-instance call (direct copies) equal a 48-instance call (staged) bit
+    for bit, for the fused tick, LPVPrediction and solve-with-given-A/B entry points of both problem kinds."""
+    from lpvmpc import workloads
+    for w in (workloads.controller_batch(640, N=20, seed=31), workloads.planner_batch(640, N=30, seed=32)):
+        ctrl = w["kind"] == "controller"
+        cut = lambda n: {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == 640 and k != "track" else v) for k, v in w.items()}
+        eng = workloads.make_solver(w)
+        res = []
+        for n in (640, 48):
+            c = cut(n)
+            full = eng.solve(c["x0"], c["u_prev"], c["vel_ref"], c["curv_s"], c["u_old"], c["max_ey"], c["cf_new"], c["lap"])
+            S, A, Bm = eng.lpv(c["x0"], c["u_prev"], c["vel_ref"], c["curv_s"], cf_new=c["cf_new"], lap=c["lap"])
+            ab = eng.solve_AB(c["x0"], A, Bm, c["vel_ref"], c["u_old"], None if ctrl else c["max_ey"])
+            res.append((full, S, A, Bm, ab))
+        eng.close()
+        (f0, S0, A0, B0, ab0), (f1, S1, A1, B1, ab1) = res
+        for k in ("xPred", "uPred", "status", "iters", "polish", "resid"):
+            assert np.array_equal(f0[k][:48], f1[k], equal_nan=True), k
+            assert np.array_equal(ab0[k][:48], ab1[k], equal_nan=True), k
+        assert np.array_equal(S0[:48], S1) and np.array_equal(A0[:48], A1) and np.array_equal(B0[:48], B1)
+        # the two-call route (LPVPrediction, then solve with its A / B) is the fused tick
+        assert np.array_equal(ab1["iters"], f1["iters"]) and np.array_equal(ab1["uPred"], f1["uPred"], equal_nan=True)
+
+
 def test_bad_arguments_fail_cleanly(lpvmpc):
     from lpvmpc import workloads
     w = workloads.controller_batch(4, N=20, seed=0)
