@@ -279,7 +279,8 @@ int lpvmpc_handoff_batch(lpvmpc_handle *planner, int32_t B, const double *xPred,
  * lpvmpc_cascade_tick enqueues n_ticks controller ticks without synchronising; lpvmpc_cascade_read synchronises and copies
  * (any pointer may be NULL): plant [B][8], local_state [B][6], cmd [B][2], ctrl_iters / ctrl_status [B], lap / lap_tick [B]
  * (lap counter and the controller tick of the last lap event), refs [B][5][M] and plan_xPred [B][Np+1][5] / plan_iters /
- * plan_status [B] of the most recent planner tick, ticks [2] = {controller ticks, planner ticks} enqueued so far. */
+ * plan_status [B] of the most recent planner tick, ticks [2] = {controller ticks, planner ticks} enqueued so far.
+ * The planner handle must outlive the cascade (it ends with the controller handle, or with the next lpvmpc_cascade_init). */
 int lpvmpc_cascade_init(lpvmpc_handle *ctrl, lpvmpc_handle *planner, int32_t B, const double *plant0, const double *cmd0,
                         const double *uPred0, int32_t lap0, double half_width, double slack, double plan_max_ey,
                         int32_t q9_swap, const int32_t *n_sub, double dt_sim, double mu_sim);
