@@ -141,3 +141,70 @@ def test_node_shims_reproduce_the_cascade_fixture():
         assert np.max(np.abs(np.array(out["cmd"]) - c["ctrl_cmd"][k])) <= 1e-4, k
         assert out["iters"] == c["ctrl_iters"][k] and out["status"] == 1
         plant = eng.plant_step(plant, np.array([[out["cmd"][1], out["cmd"][0]]]), n_sub=(7, 7, 6)[k % 3])
+
+
+def test_ros_wiring_with_stub_rospy(monkeypatch):
+    """controller_main / planner_main against stub `rospy` and `barc.msg` modules: topics, message fields and the
+    publish-then-solve order of the reference's loops (no ROS in this image; the stubs stand in for the middleware only)."""
+    import sys
+    import types
+    from lpvmpc import ros_nodes
+
+    published = {}
+    callbacks = {}
+    ticks = {"n": 0, "limit": 4}
+
+    class Msg(object):
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    class Pub(object):
+        def __init__(self, topic, cls, queue_size=1):
+            self.topic = topic
+            published.setdefault(topic, [])
+
+        def publish(self, m):
+            published[self.topic].append(dict(m.__dict__))
+
+    def subscriber(topic, cls, cb, queue_size=1):
+        callbacks[topic] = cb
+        if topic == "pos_info":
+            cb(Msg(v_x=1.0, v_y=0.0, psiDot=0.0, x=0.3, y=0.01, psi=0.0))
+        if topic == "Racing_Info":
+            cb(Msg(LapNumber=1))
+
+    def is_shutdown():
+        ticks["n"] += 1
+        return ticks["n"] > ticks["limit"]
+
+    params = {"/control/N": 8, "/TrajectoryPlanner/N": 40, "/TrajectoryPlanner/halfWidth": 0.2, "/TrajectoryPlanner/Frecuency": 20,
+              "trackShape": "L_shape", "lf": 0.125, "lr": 0.125, "m": 1.98, "Iz": 0.03, "Cf": 60.0, "Cr": 60.0, "mu": 0.05,
+              "/TrajectoryPlanner/max_vel": 5.0, "/TrajectoryPlanner/min_vel": 0.9}
+    rospy = types.ModuleType("rospy")
+    rospy.init_node = lambda name: None
+    rospy.Publisher = Pub
+    rospy.Subscriber = subscriber
+    rospy.get_param = lambda k, *a: params[k]
+    rospy.Rate = lambda hz: types.SimpleNamespace(sleep=lambda: None)
+    rospy.sleep = lambda s: None
+    rospy.is_shutdown = is_shutdown
+    barc = types.ModuleType("barc"); msg = types.ModuleType("barc.msg")
+    for name in ("ECU", "My_Planning", "Racing_Info", "pos_info", "prediction"):
+        setattr(msg, name, type(name, (Msg,), {}))
+    barc.msg = msg
+    for k, v in (("rospy", rospy), ("barc", barc), ("barc.msg", msg)):
+        monkeypatch.setitem(sys.modules, k, v)
+    monkeypatch.delitem(sys.modules, "trackInitialization", raising=False)
+
+    ros_nodes.controller_main()
+    assert len(published["ecu"]) == 4 and len(published["OL_predictions"]) == 4 and len(published["Racing_Info"]) == 4
+    assert published["ecu"][0] == {"servo": 0.0, "motor": 0.0}                       # the first command goes out before the first solve
+    assert all(np.isfinite([m["servo"], m["motor"]]).all() for m in published["ecu"]) and published["ecu"][1]["motor"] != 0.0
+    assert len(published["OL_predictions"][-1]["s"]) == 9 and published["OL_predictions"][-1]["ex"] == []     # N + 1 = 9 stages
+    assert published["Racing_Info"][-1]["LapNumber"] == 0
+
+    ticks["n"] = 0; ticks["limit"] = 3
+    ros_nodes.planner_main()
+    refs = published["My_Planning"]
+    assert len(refs) == 3 and all(len(refs[-1][k]) == 61 for k in ("x_d", "y_d", "psi_d", "vx_d", "curv_d"))
+    assert np.all(np.isfinite(refs[-1]["vx_d"])) and refs[-1]["vx_d"][0] >= 0.9
