@@ -138,7 +138,9 @@ __device__ inline double inv_sqrt(double x) {
     y = y * (1.5 - 0.5 * x * y * y);
     return y;
 }
-__device__ inline double clipd(double t, double lo, double hi) { return t < lo ? lo : (t > hi ? hi : t); }
+// projection on [lo, hi] (lo <= hi): two instructions (v_max_f64, v_min_f64) instead of compare / select pairs; equal to
+// t < lo ? lo : (t > hi ? hi : t) for every non-NaN t (a NaN maps to lo, as OSQP's c_min(c_max(z, l), u) does)
+__device__ inline double clipd(double t, double lo, double hi) { return fmin(fmax(t, lo), hi); }
 
 
 }  // namespace lpvmpc
