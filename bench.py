@@ -218,6 +218,7 @@ def main():
                          "kernel": "admm_solve_kernel<%d, %d, 2>" % (nx, N), "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
                          "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_admm_iteration": bytes_iter,
                          "aggregate_algorithmic_GBps": bytes_launch * args.steps * world / elapsed / 1e9,
+                         "aggregate_frac_per_gpu": bytes_launch * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
                          "note": "algorithmic bytes per SURVEY 8(d) (factor + vectors streamed once per ADMM "
                                  "iteration); the kernel keeps them in LDS/registers, so real HBM traffic is far lower. "
                                  "With --streams > 1 launches overlap, so the per-launch duration includes time "
