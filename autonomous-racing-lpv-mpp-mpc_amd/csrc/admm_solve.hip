@@ -1190,7 +1190,7 @@ static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveA
 
 // 1 if (kind, N) has a register-tile instantiation
 int solve_has_fast_path(int kind, int N) {
-    return (kind == 0 && (N == 20 || N == 10 || N == 8)) || (kind == 1 && (N == 30 || N == 40));
+    return (kind == 0 && (N == 20 || N == 10 || N == 8)) || (kind == 1 && (N == 30 || N == 40 || N == 20));
 }
 
 size_t solve_lds_bytes(int kind, int N) {
@@ -1210,6 +1210,7 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
     }
     if (!generic && cfg.N == 30) return one_wave ? launch_one<5, 30, 1>(cfg, dcfg, a, stream) : launch_one<5, 30, 2>(cfg, dcfg, a, stream);
     if (!generic && cfg.N == 40) return launch_one<5, 40, 2>(cfg, dcfg, a, stream);
+    if (!generic && cfg.N == 20) return launch_one<5, 20, 2>(cfg, dcfg, a, stream);      // the planner half of configs[3]
     return launch_one<5, 0, 1>(cfg, dcfg, a, stream);
 }
 

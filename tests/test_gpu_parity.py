@@ -151,7 +151,7 @@ def test_kernel_variants_agree(lpvmpc):
     from lpvmpc import workloads
     for w in (workloads.controller_batch(128, N=20, seed=5), workloads.planner_batch(64, N=30, seed=6),
               workloads.planner_batch(48, N=40, seed=7), workloads.controller_batch(64, N=10, seed=8),
-              workloads.controller_batch(64, N=8, seed=9)):
+              workloads.controller_batch(64, N=8, seed=9), workloads.planner_batch(64, N=20, seed=10)):
         outs = []
         for variant in (0, 1, 2):
             eng = workloads.make_solver(w)
