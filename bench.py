@@ -51,9 +51,10 @@ def main():
     ap.add_argument("--streams", type=int, default=32,
                     help="HIP streams the K steps are issued on round-robin (independent batches overlap, so the few "
                          "slow instances of one batch do not leave the GPU idle); 1 = strictly back-to-back steps")
-    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg5"], default="cfg2",
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
                     help="cfg2 = configs[1] (the headline, default); cfg3 = configs[2]: planner LPV-MPP, N=30, L-shape "
-                         "(use --batch 4096); cfg5 = configs[4]: planner + controller + plant cascade, a step is one 30 Hz "
+                         "(use --batch 4096); cfg4 = configs[3]: --batch (default 65536 / gpus) instances per GPU, half controller, half "
+                         "planner, N=20; cfg5 = configs[4]: planner + controller + plant cascade, a step is one 30 Hz "
                          "controller tick of --batch vehicles per GPU (default 8192 / gpus) -- extra measurements, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -79,6 +80,8 @@ def main():
 
     if args.workload == "cfg5":
         return bench_cascade(args, rank, local_rank, world, dev)
+    if args.workload == "cfg4":
+        return bench_mixed(args, rank, local_rank, world, dev)
     planner = args.workload == "cfg3"
     B, N = args.batch, (30 if planner else HORIZON)
     nx = 5 if planner else 6
@@ -244,6 +247,101 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def bench_mixed(args, rank, local_rank, world, dev):
+    """configs[3] shape: B instances per GPU, half LPV-MPC controller (cfg2 distribution) and half LPV-MPP planner (cfg3
+    distribution on the L-shape track), both N = 20, seed 2; a step solves one such mixed batch (the two halves on two
+    streams), steps are pipelined over --streams stream pairs.  value = solves/s over both kinds."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from lpvmpc import workloads
+    from lpvmpc.distributed import reduce_stats
+    B = args.batch if args.batch != BATCH else max(2, 65536 // world)
+    Bh = B // 2
+    ws = [workloads.controller_batch(Bh, N=20, seed=2 + 1000 * rank), workloads.planner_batch(Bh, N=20, seed=2 + 1000 * rank)]
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dev_in = [{k: t(w[k]) for k in ("x0", "u_prev", "vel_ref", "curv_s", "u_old", "max_ey")} for w in ws]
+    S = max(1, min(args.streams, 8))                      # 8192 instances per launch fill the GPU: a few pairs in flight are enough
+    lanes = []
+    for _ in range(S):
+        pair = []
+        for w, nx in zip(ws, (6, 5)):
+            e = workloads.make_solver(w, device=local_rank); e.reserve(Bh)
+            o = dict(xPred=torch.empty((Bh, 21, nx), dtype=torch.float64, device=dev), uPred=torch.empty((Bh, 20, 2), dtype=torch.float64, device=dev),
+                     status=torch.empty(Bh, dtype=torch.int32, device=dev), iters=torch.empty(Bh, dtype=torch.int32, device=dev),
+                     resid=torch.empty((Bh, 4), dtype=torch.float64, device=dev), polish=torch.empty(Bh, dtype=torch.int32, device=dev))
+            pair.append((e, o, torch.cuda.Stream(device=dev)))
+        lanes.append(pair)
+    counter = [0]
+
+    def step(n_inst=Bh):
+        pair = lanes[counter[0] % S]; counter[0] += 1
+        for (e, o, st), d, w in zip(pair, dev_in, ws):
+            e.solve_dev(n_inst, d["x0"], d["u_prev"], d["vel_ref"], d["curv_s"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"], o["status"],
+                        o["iters"], o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"], stream=st.cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(S):
+        step(1)                                           # set-up: queues and code objects (see main)
+    counter[0] = 0
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    for pair in lanes:
+        for e, _, _ in pair:
+            e.set_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kms = [0.0, 0.0]; kn = [0, 0]
+    for pair in lanes:
+        for i, (e, _, _) in enumerate(pair):
+            ms_, n_ = e.kernel_time_stats(); kms[i] += ms_; kn[i] += n_
+    its = [lanes[0][i][1]["iters"].cpu().numpy().astype(np.int64) for i in range(2)]
+    sts = [lanes[0][i][1]["status"].cpu().numpy() for i in range(2)]
+    elapsed, agg = reduce_stats(elapsed, [float(its[0].sum()), float(its[1].sum()), float((sts[0] == 1).sum() + (sts[1] == 1).sum())], device=dev)
+    if rank == 0:
+        bl_c, _ = algorithmic_bytes(its[0])
+        bl_p, bi_p = algorithmic_bytes(its[1], N=20, nx=5, m_rows=21 * 5 + 21 * 5 + 20 * 2)
+        k_avg_s = kms[1] / max(kn[1], 1) * 1e-3
+        out = {"metric": "MPC solves/sec (mixed planner + controller, N=20)", "value": 2 * Bh * world * args.steps / elapsed, "unit": "solves/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "strong" if args.batch == BATCH else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "configs[3]: %d instances per GPU, half LPV-MPC controller (oval), half LPV-MPP planner (L-shape), N=20, "
+                                      "OSQP defaults + polish, cold start" % (2 * Bh), "batch_per_gpu": 2 * Bh, "horizon": 20,
+                          "mean_admm_iters_controller": agg[0] / (Bh * world), "mean_admm_iters_planner": agg[1] / (Bh * world),
+                          "solved_fraction": agg[2] / (2 * Bh * world), "stream_pairs": S,
+                          "controller_kernel_avg_ms": kms[0] / max(kn[0], 1)},
+               "roofline": {"bound": "hbm", "achieved": bl_p / k_avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bl_p / k_avg_s / 1e9 / HBM_PEAK_GBS,
+                            "traffic": None, "kernel": "admm_solve_kernel<5, 20, 2>", "kernel_avg_ms": kms[1] / max(kn[1], 1), "launches": kn[1],
+                            "algorithmic_bytes_per_launch": bl_p, "bytes_per_admm_iteration": bi_p,
+                            "aggregate_algorithmic_GBps": (bl_c + bl_p) * args.steps * world / elapsed / 1e9,
+                            "note": "dominant kernel = the planner half (about 12x the controller's iterations)"}}
+        if not args.no_cpu_baseline:
+            from oracle import osqp_ref
+            cores = usable_cores()
+            n = 256
+            sub = lambda w: {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == Bh and k != "track" else v) for k, v in w.items()}
+            t1 = time.perf_counter(); reps = 0
+            while time.perf_counter() - t1 < 10.0:
+                osqp_ref.ctrl_tick_batch(sub(ws[0]), nthreads=cores); osqp_ref.plan_tick_batch(sub(ws[1]), nthreads=cores); reps += 1
+            tt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": 2 * n * reps / tt, "unit": "solves/s", "cores": cores, "kind": "port",
+                                   "sample": "%d x (256 controller + 256 planner instances of the same batch), oracle C ticks under OpenMP, %.1f s" % (reps, tt)}
+        print(json.dumps(out), flush=True)
+    for pair in lanes:
+        for e, _, _ in pair:
+            e.close()
 
 
 def bench_cascade(args, rank, local_rank, world, dev):
