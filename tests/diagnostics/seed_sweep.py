@@ -13,7 +13,7 @@ tot = dict(n=0, st=0, it=0, close=0, fin=0)
 worst = 0.0
 for shape in ("oval", "L_shape", "3110", "Euge_Track"):
     for seed in range(6):
-        for kind, N, lap in (("controller", 20, 1), ("controller", 20, 0), ("controller", 8, 1), ("planner", 30, 1), ("planner", 40, 1)):
+        for kind, N, lap in (("controller", 20, 1), ("controller", 20, 0), ("controller", 8, 1), ("planner", 20, 1), ("planner", 30, 1), ("planner", 40, 1)):
             B = 1024 if kind == "controller" else 512
             w = workloads.controller_batch(B, N=N, seed=100 + seed, shape=shape) if kind == "controller" else workloads.planner_batch(B, N=N, seed=200 + seed, shape=shape)
             w["lap"] = lap
