@@ -57,7 +57,17 @@ def main():
                          "planner, N=20; cfg5 = configs[4]: planner + controller + plant cascade, a step is one 30 Hz "
                          "controller tick of --batch vehicles per GPU (default 8192 / gpus) -- extra measurements, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise the launcher, the sharding and the collectives with the gloo backend and no device work "
+                         "(CPU test of the N > 1 path; the printed line carries \"dry_run\": true and no measurement)")
     args = ap.parse_args()
+
+    # --gpus N given to a plain `python bench.py`: become the launcher.  Nothing has touched the GPU yet (torch is not
+    # even imported), the children are fresh processes (never an exec of a process that initialised HIP).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+    if args.dry_run:
+        return dry_run(args)
 
     # independent batches are pipelined over several HIP streams; give the runtime as many hardware queues
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(8, args.streams))))
@@ -70,6 +80,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let --gpus spawn them)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -78,10 +90,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    if args.workload == "cfg5":
-        return bench_cascade(args, rank, local_rank, world, dev)
-    if args.workload == "cfg4":
-        return bench_mixed(args, rank, local_rank, world, dev)
+    if args.workload in ("cfg5", "cfg4"):
+        try:
+            return (bench_cascade if args.workload == "cfg5" else bench_mixed)(args, rank, local_rank, world, dev)
+        finally:
+            if world > 1:
+                dist.destroy_process_group()
     planner = args.workload == "cfg3"
     B, N = args.batch, (30 if planner else HORIZON)
     nx = 5 if planner else 6
@@ -178,8 +192,12 @@ def main():
 
     it_host = iters.cpu().numpy().astype(np.int64)
     st_host = status.cpu().numpy()
-    from lpvmpc.distributed import reduce_stats
+    from lpvmpc.distributed import reduce_stats, gather_results
     elapsed, agg = reduce_stats(elapsed, [float(it_host.sum()), float((st_host == 1).sum())], device=dev)
+    # the one collective of the path, after the timed region: first input, status and iteration count of every
+    # instance of the job on every rank (B x 4 words per rank over RCCL)
+    g_u0, g_status, g_iters = gather_results(outs[0]["uPred"][:, 0, :].cpu().numpy(), st_host, it_host, B * world, device=dev)
+    assert g_u0.shape == (B * world, 2) and int(g_iters.astype(np.int64).sum()) == int(agg[0])
 
     if rank == 0:
         total = B * world * args.steps
@@ -235,6 +253,66 @@ def main():
         e.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, same command line);
+    returns the exit code for the launcher: 0 only if every rank succeeded.  The launcher itself never imports torch."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = []
+    try:
+        for p in procs:
+            codes.append(p.wait())
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()        # exactly the PIDs started here
+    bad = [c for c in codes if c != 0]
+    return 0 if len(codes) == n and not bad else (bad[0] if bad else 1)
+
+
+def dry_run(args):
+    """The multi-rank plumbing of the benchmark without a device: gloo process group, contiguous sharding of ONE global
+    batch (configs[3] / configs[4] shapes split it; the headline gives every rank its own 1024), barrier, MAX-over-ranks
+    time, SUM of counters and the final (u0, status, iters) all-gather of SURVEY.md section 8e -- on stand-in results."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from lpvmpc.distributed import shard_range, reduce_stats, gather_results
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = {"cfg2": args.batch * world, "cfg3": args.batch * world, "cfg4": 65536, "cfg5": 8192}[args.workload]
+    a, b = shard_range(total, rank, world)
+    n = b - a
+    u0 = np.stack([np.arange(a, b, dtype=np.float64), -np.arange(a, b, dtype=np.float64)], axis=1)      # stand-in results
+    status = np.ones(n, dtype=np.int32); iters = (25 * (1 + np.arange(a, b) % 3)).astype(np.int32)
+    if world > 1:
+        dist.barrier()
+    elapsed, agg = reduce_stats(1e-3 * (rank + 1), [float(iters.sum()), float(n)])
+    g_u0, g_status, g_iters = gather_results(u0, status, iters, total)
+    ok = bool(g_u0.shape == (total, 2) and np.array_equal(g_u0[:, 0], np.arange(total)) and int(g_iters.sum()) == int(agg[0])
+              and int(agg[1]) == total and g_status.shape == (total,))
+    if rank == 0:
+        print(json.dumps({"metric": "MPC solves/sec (N=20, nx=6, nu=2)", "value": None, "unit": "solves/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": "weak",
+                          "config": {"workload": args.workload, "global_instances": total, "shard_rank0": [a, b],
+                                     "max_elapsed_s": elapsed, "gather_ok": ok}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
 
 
 def usable_cores():

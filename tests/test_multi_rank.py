@@ -43,3 +43,47 @@ def test_two_rank_sharding_and_reduction(tmp_path):
     from lpvmpc import workloads
     full = workloads.controller_batch(50, 20, seed=7)["x0"]
     assert r[0][5] + r[1][5] == pytest.approx(full.sum())     # the two slices tile the batch
+
+
+def _bench_line(cmd, env=None):
+    import json, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+def test_bench_launcher_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` (no torchrun): bench.py's own launcher starts the ranks; --dry-run swaps the device work
+    for stand-in results and runs the real sharding + barrier + reductions + the final all-gather over gloo."""
+    import sys
+    for wl, total in (("cfg2", 2048), ("cfg4", 65536), ("cfg5", 8192)):
+        out = _bench_line([sys.executable, "bench.py", "--gpus", "2", "--dry-run", "--workload", wl])
+        assert out["n_gpus"] == 2 and out["dry_run"] is True
+        assert out["config"]["global_instances"] == total and out["config"]["gather_ok"] is True
+        assert out["config"]["shard_rank0"] == [0, total // 2]
+        assert out["config"]["max_elapsed_s"] == pytest.approx(2e-3)
+
+
+@pytest.mark.timeout(300)
+def test_bench_under_the_drivers_launcher():
+    """The driver's form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2."""
+    import sys
+    out = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                       "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--dry-run"])
+    assert out["n_gpus"] == 2 and out["config"]["gather_ok"] is True
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    import subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-run"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
