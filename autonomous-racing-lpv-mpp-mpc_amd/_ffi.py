@@ -28,7 +28,7 @@ _d, _i = C.c_double, C.c_int32
 class Config(C.Structure):
     """Mirror of ``struct lpvmpc_config`` (include/lpvmpc.h) -- keep field order identical."""
     _fields_ = [
-        ("kind", _i), ("N", _i), ("device", _i), ("reserved0", _i),
+        ("kind", _i), ("N", _i), ("device", _i), ("steering_delay", _i),
         ("dt", _d),
         ("lf", _d), ("lr", _d), ("m", _d), ("Iz", _d), ("Cf", _d), ("Cr", _d), ("mu", _d),
         ("max_vel", _d), ("min_vel", _d),
@@ -47,7 +47,7 @@ class Config(C.Structure):
 SETTING_FIELDS = ("rho", "sigma", "alpha", "eps_abs", "eps_rel", "eps_prim_inf", "eps_dual_inf", "polish_delta",
                   "adaptive_rho_tolerance", "max_iter", "check_termination", "scaling", "adaptive_rho",
                   "adaptive_rho_interval", "polish", "polish_refine_iter",
-                  "ctrl_vx_min", "ctrl_delta_max", "ctrl_a_max", "ctrl_a_min_abs")
+                  "ctrl_vx_min", "ctrl_delta_max", "ctrl_a_max", "ctrl_a_min_abs", "steering_delay")
 
 
 class LpvMpcError(RuntimeError):
@@ -131,9 +131,7 @@ def load():
                  "lpvmpc_cascade_init", "lpvmpc_cascade_tick", "lpvmpc_cascade_read"):
         getattr(lib, name).restype = C.c_int
     for name in ("lpvmpc_local_position_batch", "lpvmpc_global_position_batch", "lpvmpc_plant_step_batch",
-                 "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read",
-           "lpvmpc_handoff_default_config", "lpvmpc_handoff_length", "lpvmpc_handoff_operators", "lpvmpc_handoff_setup",
-           "lpvmpc_handoff_batch", "lpvmpc_cascade_init", "lpvmpc_cascade_tick", "lpvmpc_cascade_read"):
+                 "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read"):
         getattr(lib, name).restype = C.c_int
     for name in ("lpvmpc_reserve", "lpvmpc_lpv_batch", "lpvmpc_estimate_abc_batch", "lpvmpc_solve_batch_AB",
                  "lpvmpc_solve_batch", "lpvmpc_solve_batch_dev", "lpvmpc_set_timing"):

@@ -176,7 +176,7 @@ class BatchedSolver:
         A = f64(A, (B, N, nx, nx), "A"); Bm = f64(Bm, (B, N, nx, 2), "B")
         ctrl = self.kind == KIND_CONTROLLER
         vel_ref = f64(vel_ref, (B, N + 1), "vel_ref") if ctrl else None
-        u_old = None if u_old is None else f64(u_old, (B, 2), "u_old")
+        u_old = None if u_old is None else f64(u_old, (B, 2 + self.cfg.steering_delay), "u_old")
         max_ey = None if ctrl else f64(np.broadcast_to(np.asarray(max_ey, float), (B,)), (B,), "max_ey")
         o = self._outputs(B)
         self._chk(self._lib.lpvmpc_solve_batch_AB(self._h, B, ptr(x0), ptr(A), ptr(Bm), ptr(vel_ref), ptr(u_old),
@@ -194,7 +194,7 @@ class BatchedSolver:
         vel_ref = f64(vel_ref, (B, N + 1), "vel_ref") if ctrl else None
         if curv_s is not None:
             curv_s = f64(curv_s, (B, N) if ctrl else (B, N + 1), "curv_ref" if ctrl else "SS")
-        u_old = None if u_old is None else f64(u_old, (B, 2), "u_old")
+        u_old = None if u_old is None else f64(u_old, (B, 2 + self.cfg.steering_delay), "u_old")
         max_ey = None if ctrl else f64(np.broadcast_to(np.asarray(max_ey, float), (B,)), (B,), "max_ey")
         o = self._outputs(B)
         self._chk(self._lib.lpvmpc_solve_batch(self._h, B, ptr(x0), ptr(u_prev), ptr(vel_ref), ptr(curv_s), ptr(u_old),
@@ -352,12 +352,11 @@ class PathFollowingLPV_MPC(_DropInBase):
     Same constructor arguments; ``params`` (vehicle parameters dict) and ``device`` are optional extras for
     use without ROS.  ``Solver`` is accepted for signature compatibility: the solve always runs the HIP
     ADMM path (the reference's mains only ever pass "OSQP", controllerMain.py:142,150).
-    Input delays (steeringDelay > 0, CTRL:518-527) are not supported (the reference runs with 0)."""
+    ``steeringDelay`` > 0 adds the pinned-steering equality rows of CTRL:518-527 (``OldSteering`` then has 1 + delay
+    entries, CTRL:71); ``velocityDelay`` is stored and, as in the reference, never used."""
 
     def __init__(self, Q, R, dR, N, vt, dt, map, Solver="OSQP", steeringDelay=0, velocityDelay=0,
                  params=None, device=0, **settings):
-        if int(steeringDelay) != 0:
-            raise NotImplementedError("steeringDelay > 0 is not supported by the MI355X solve path")
         p = _vehicle_params(params, need_min_vel=False)
         self.lf, self.lr, self.m, self.I = p["lf"], p["lr"], p["m"], p["Iz"]
         self.Cf, self.Cr, self.mu, self.g = p["Cf"], p["Cr"], p["mu"], 9.81
@@ -381,7 +380,7 @@ class PathFollowingLPV_MPC(_DropInBase):
         self.Solver = Solver
         self.verbose_status = True
         self._eng = BatchedSolver("controller", N, dt, self.Q, self.R, self.dR, track=map.PointAndTangent,
-                                  params=p, device=device, **settings)
+                                  params=p, device=device, steering_delay=int(steeringDelay), **settings)
 
     def solve(self, x0, Last_xPredicted, uPred, NN_LPV_MPC, vel_ref, A_L, B_L, C_L, first_it):
         """CTRL:89-162.  Results in .xPred (N+1,6), .uPred (N,2), .LinPoints; returns None."""
@@ -400,7 +399,9 @@ class PathFollowingLPV_MPC(_DropInBase):
         self.C = [np.zeros((6, 1)) for _ in range(N)]
         vr = np.asarray(vel_ref, dtype=np.float64).reshape(-1)
         vfull = np.concatenate((vr[:N], vr[-1:]))                         # CTRL:434-438: stage N tracks vel_ref[-1]
-        u_old = np.array([[self.OldSteering[0], self.OldAccelera[0]]], dtype=np.float64)   # CTRL:395
+        d = int(self.steeringDelay)
+        # CTRL:395 (uOld) followed by the pinned commands OldSteering[1 .. delay] of CTRL:523
+        u_old = np.array([[self.OldSteering[0], self.OldAccelera[0]] + [float(v) for v in self.OldSteering[1:1 + d]]], dtype=np.float64)
         self.linearizationTime = datetime.datetime.now() - start
         start = datetime.datetime.now()
         out = self._eng.solve_AB(np.asarray(x0, float).reshape(1, 6), A[None], Bm[None], vfull[None], u_old)

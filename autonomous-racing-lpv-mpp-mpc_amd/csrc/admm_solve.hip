@@ -50,6 +50,7 @@ struct Solver {
 
     const DevCfg &cfg;
     const int N, NS, tid, wv, lane, ti, tj;
+    const int delay;      // controller: stages 0 .. delay-1 carry a pinned-steering equality row in box slot 6 (CTRL:518-527)
     // tiles: scaled [A|B] always in LDS; S^-1 and L in LDS (run-time horizon) or registers (kReg)
     double *tS, *tL, *tA;
     double rS[kRS], rL[kRS];
@@ -69,12 +70,12 @@ struct Solver {
     bool pol;
     double rho, rho_eq, rinv, rinv_eq;
     // per-lane constants of the compact layout (component = lane & 7 in every 64-element round)
-    int r0, r1, bvar;     // box rows acting on variable tj (7 = none, its coefficient is 0); variable of box row tj
+    int r0, r1, r2, bvar; // box rows acting on variable tj (7 = none, its coefficient is 0; r2 = the delay row on delta); variable of box row tj
     double rmask;         // 1 if tj is a real dynamics row
 
     __device__ __forceinline__ Solver(const DevCfg &cf, double *smem)
         : cfg(cf), N(kReg ? NT : cf.N), NS((kReg ? NT : cf.N) + 1), tid(threadIdx.x), wv(threadIdx.x >> 6), lane(threadIdx.x & 63),
-          ti((threadIdx.x & 63) >> 3), tj(threadIdx.x & 7) {
+          ti((threadIdx.x & 63) >> 3), tj(threadIdx.x & 7), delay(kCtrl ? cf.steering_delay : 0) {
         double *p = smem;
         tA = p; p += NS * kTS;
         tS = tL = nullptr;
@@ -86,6 +87,7 @@ struct Solver {
         Lo = p; p += V; Hi = p; p += V;
         beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; RED = p; p += 80; SINK = p; p += 64 + 8 * NS;
         { int first, cnt; rows_on(tj, first, cnt); r0 = cnt >= 1 ? first : 7; r1 = cnt >= 2 ? first + 1 : 7; }
+        r2 = (kCtrl && tj == 6) ? 6 : 7;
         bvar = box_var(tj); rmask = tj < NX ? 1.0 : 0.0;
         c = 1.0; cinv = 1.0; pol = false; rho = rho_eq = rinv = rinv_eq = 0.0; rSm = rLt = rLb = 0.0;
     }
@@ -95,8 +97,8 @@ struct Solver {
 
     // ---- problem structure ---------------------------------------------------------------------
     __device__ __forceinline__ int nvar(int k) const { return k < N ? NB : NX; }
-    __device__ __forceinline__ int nbox(int k) const { return kCtrl ? (k < N ? 6 : 0) : (k < N ? 7 : 5); }
-    __device__ __forceinline__ static int box_var(int r) { return kCtrl ? (r < 2 ? 0 : (r < 4 ? 6 : 7)) : r; }
+    __device__ __forceinline__ int nbox(int k) const { return kCtrl ? (k < N ? (k < delay ? 7 : 6) : 0) : (k < N ? 7 : 5); }
+    __device__ __forceinline__ static int box_var(int r) { return kCtrl ? (r < 2 ? 0 : (r < 4 ? 6 : (r < 6 ? 7 : 6))) : r; }
     __device__ __forceinline__ static double box_sign(int r) { return kCtrl ? ((r == 0 || r == 3 || r == 5) ? -1.0 : 1.0) : 1.0; }
     __device__ __forceinline__ static void rows_on(int a, int &first, int &cnt) {
         if (kCtrl) { first = (a == 0) ? 0 : (a == 6 ? 2 : 4); cnt = (a == 0 || a == 6 || a == 7) ? 2 : 0; }
@@ -202,7 +204,9 @@ struct Solver {
         double acc0 = c_[0] * d_[0] + c_[1] * d_[1], acc1 = c_[2] * d_[2] + c_[3] * d_[3];
 #pragma unroll
         for (int r = 4; r < NX; ++r) acc0 += c_[r] * d_[r];
-        return (sb0 * w0 + sb1 * w1) + (ei * wd - (acc0 + acc1));
+        double boxes = sb0 * w0 + sb1 * w1;
+        if (kCtrl && delay > 0) boxes += Sb(k, r2) * srcB[k * 8 + r2];        // pinned-steering row (uniform branch)
+        return boxes + (ei * wd - (acc0 + acc1));
     }
     // dst = A' * (srcD, srcB)
     __device__ __forceinline__ void At_mul(const double *srcD, const double *srcB, double *dst) const {
@@ -272,6 +276,7 @@ struct Solver {
                     dn = fmax(pcol, cmax * de);
                     if (r0 < nbox(k)) dn = fmax(dn, Eb[k * 8 + r0] * de);
                     if (r1 < nbox(k)) dn = fmax(dn, Eb[k * 8 + r1] * de);
+                    if (r2 < nbox(k)) dn = fmax(dn, Eb[k * 8 + r2] * de);
                     if (a < NX) dn = fmax(dn, ede * de);
                 }
                 double en = 0.0;          // dynamics row (k, a)
@@ -349,6 +354,7 @@ struct Solver {
             kd += sig;
             int first, cnt; rows_on(ti, first, cnt);
             for (int t = 0; t < cnt; ++t) { const int r = first + t; const double sb = Sb(k, r); kd += w_box(k * 8 + r) * sb * sb; }
+            if (kCtrl && ti == 6 && delay > 0) { const double sb = Sb(k, 6); kd += w_box(k * 8 + 6) * sb * sb; }   // 0 where the row does not exist
             { const double ei = Eid(k, ti); kd += w_dyn(k * 8 + ti) * ei * ei; }
         }
         if (k < N) {
@@ -897,7 +903,8 @@ struct Solver {
                 tA[k * kTS + r * 8 + col] = v;
             }
         }
-        const double uo0 = a.u_old ? a.u_old[(size_t)inst * 2 + 0] : 0.0, uo1 = a.u_old ? a.u_old[(size_t)inst * 2 + 1] : 0.0;
+        const size_t uos = 2 + delay;       // u_old row: [OldSteering[0], OldAccelera[0], OldSteering[1 .. delay]]
+        const double uo0 = a.u_old ? a.u_old[(size_t)inst * uos + 0] : 0.0, uo1 = a.u_old ? a.u_old[(size_t)inst * uos + 1] : 0.0;
         const double mey = (!kCtrl && a.max_ey) ? a.max_ey[inst] : 0.0;
         bad |= !__builtin_isfinite(uo0) || !__builtin_isfinite(uo1) || !__builtin_isfinite(mey);
         for (int e = tid; e < NS * 8; e += kStride) {
@@ -914,6 +921,7 @@ struct Solver {
             if (r < nbox(k)) {
                 double lo = cfg.box_lo[r], hi = cfg.box_hi[r];
                 if (!kCtrl && r == 3) { lo = -mey; hi = mey; }
+                if (kCtrl && r == 6) { lo = hi = a.u_old ? a.u_old[(size_t)inst * (2 + delay) + 2 + k] : 0.0; bad |= !__builtin_isfinite(lo); }   // delta_k = OldSteering[k+1]
                 Lo[e] = fmax(lo, -kInfty); Hi[e] = fmin(hi, kInfty);
             }
         }

@@ -76,7 +76,7 @@ static int ensure_ws(lpvmpc_handle *h, int B) {
     const size_t N = h->cfg.N, nx = h->nx, nb = h->nb, b = B;
 #define ALLOC(p, n) HIP_TRY(h, hipMalloc((void **)&(p), (n)))
     ALLOC(h->d_x0, b * nx * 8); ALLOC(h->d_uprev, b * N * 2 * 8); ALLOC(h->d_vel, b * (N + 1) * 8);
-    ALLOC(h->d_curv, b * (N + 1) * 8); ALLOC(h->d_uold, b * 2 * 8); ALLOC(h->d_maxey, b * 8);
+    ALLOC(h->d_curv, b * (N + 1) * 8); ALLOC(h->d_uold, b * (2 + h->cfg.steering_delay) * 8); ALLOC(h->d_maxey, b * 8);
     ALLOC(h->d_AB, b * N * nx * nb * 8); ALLOC(h->d_states, b * N * nx * 8);
     ALLOC(h->d_xPred, b * (N + 1) * nx * 8); ALLOC(h->d_uPred, b * N * 2 * 8); ALLOC(h->d_resid, b * 4 * 8);
     ALLOC(h->d_xlast, b * N * 6 * 8); ALLOC(h->d_delta, b * N * 8);
@@ -91,6 +91,8 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     if (!cfg) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: cfg is NULL"); return nullptr; }
     if (cfg->kind != LPVMPC_KIND_CONTROLLER && cfg->kind != LPVMPC_KIND_PLANNER) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: bad kind %d", cfg->kind); return nullptr; }
     if (cfg->N < 8 || cfg->N > LPVMPC_MAX_N) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: N=%d outside [8,%d]", cfg->N, LPVMPC_MAX_N); return nullptr; }
+    if (cfg->steering_delay < 0 || cfg->steering_delay > 8 || cfg->steering_delay >= cfg->N || (cfg->kind == LPVMPC_KIND_PLANNER && cfg->steering_delay != 0)) {
+        fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: steering_delay=%d (controller: 0..8 and < N; planner: 0)", cfg->steering_delay); return nullptr; }
     if (cfg->track_rows < 0 || cfg->track_rows > LPVMPC_MAX_TRACK_ROWS) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: track_rows=%d outside [0,%d]", cfg->track_rows, LPVMPC_MAX_TRACK_ROWS); return nullptr; }
     if (!(cfg->dt > 0) || !(cfg->rho > 0) || !(cfg->sigma > 0) || !(cfg->alpha > 0 && cfg->alpha < 2) || !(cfg->polish_delta > 0)) {
         fail(nullptr, LPVMPC_E_ARG, "lpvmpc_create: dt, rho, sigma, polish_delta must be > 0 and 0 < alpha < 2"); return nullptr; }
@@ -113,6 +115,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     d.kind = cfg->kind; d.N = cfg->N; d.track_rows = cfg->track_rows; d.max_iter = cfg->max_iter;
     d.check_termination = cfg->check_termination; d.scaling = cfg->scaling; d.adaptive_rho = cfg->adaptive_rho;
     d.adaptive_rho_interval = cfg->adaptive_rho_interval; d.polish = cfg->polish; d.polish_refine_iter = cfg->polish_refine_iter;
+    d.steering_delay = cfg->steering_delay;
     d.dt = cfg->dt; d.lf = cfg->lf; d.lr = cfg->lr; d.m = cfg->m; d.Iz = cfg->Iz; d.Cf = cfg->Cf; d.Cr = cfg->Cr; d.mu = cfg->mu;
     d.max_vel = cfg->max_vel; d.min_vel = cfg->min_vel;
     std::memcpy(d.Q, cfg->Q, sizeof(d.Q)); std::memcpy(d.R, cfg->R, sizeof(d.R));
@@ -372,7 +375,7 @@ extern "C" int lpvmpc_solve_batch_AB(lpvmpc_handle *h, int32_t B, const double *
     hipStream_t st = h->stream;
     const size_t n_ab = b * N * nx * nb, n_x = b * (N + 1) * nx, n_u = b * N * 2;
     IoPack io;
-    IO_TRY(io.begin(h, st, (b * nx + n_ab + b * (N + 1) + b * 3) * 8, (n_x + n_u + b * 4) * 8 + b * 12, 12));
+    IO_TRY(io.begin(h, st, (b * nx + n_ab + b * (N + 1) + b * (3 + h->cfg.steering_delay)) * 8, (n_x + n_u + b * 4) * 8 + b * 12, 12));
     void *p_x0, *p_ab, *p_vel = nullptr, *p_uold = nullptr, *p_mey = nullptr;
     IO_TRY(io.in(x0, h->d_x0, b * nx * 8, &p_x0));
     std::vector<double> ab;
@@ -387,7 +390,7 @@ extern "C" int lpvmpc_solve_batch_AB(lpvmpc_handle *h, int32_t B, const double *
         }
     if (!io.on) { p_ab = h->d_AB; H2D(h->d_AB, ab.data(), n_ab * 8); }
     if (ctrl) IO_TRY(io.in(vel_ref, h->d_vel, b * (N + 1) * 8, &p_vel));
-    if (u_old) IO_TRY(io.in(u_old, h->d_uold, b * 2 * 8, &p_uold));
+    if (u_old) IO_TRY(io.in(u_old, h->d_uold, b * (2 + h->cfg.steering_delay) * 8, &p_uold));
     if (!ctrl) IO_TRY(io.in(max_ey, h->d_maxey, b * 8, &p_mey));
     IO_TRY(io.flush_in());
     double *o_x = (double *)io.out(xPred, h->d_xPred, n_x * 8), *o_u = (double *)io.out(uPred, h->d_uPred, n_u * 8);
@@ -438,12 +441,12 @@ extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0,
     hipStream_t st = h->stream;
     const size_t n_x = b * (N + 1) * nx, n_u = b * N * 2;
     IoPack io;
-    IO_TRY(io.begin(h, st, (b * nx + n_u + b * (N + 1) * 2 + b * 3) * 8, (n_x + n_u + b * 4) * 8 + b * 12, 12));
+    IO_TRY(io.begin(h, st, (b * nx + n_u + b * (N + 1) * 2 + b * (3 + h->cfg.steering_delay)) * 8, (n_x + n_u + b * 4) * 8 + b * 12, 12));
     void *p_x0, *p_up, *p_vel = nullptr, *p_curv = nullptr, *p_uold = nullptr, *p_mey = nullptr;
     IO_TRY(io.in(x0, h->d_x0, b * nx * 8, &p_x0)); IO_TRY(io.in(u_prev, h->d_uprev, n_u * 8, &p_up));
     if (ctrl) IO_TRY(io.in(vel_ref, h->d_vel, b * (N + 1) * 8, &p_vel));
     if (curv_s) IO_TRY(io.in(curv_s, h->d_curv, b * (ctrl ? N : N + 1) * 8, &p_curv));
-    if (u_old) IO_TRY(io.in(u_old, h->d_uold, b * 2 * 8, &p_uold));
+    if (u_old) IO_TRY(io.in(u_old, h->d_uold, b * (2 + h->cfg.steering_delay) * 8, &p_uold));
     if (!ctrl) IO_TRY(io.in(max_ey, h->d_maxey, b * 8, &p_mey));
     IO_TRY(io.flush_in());
     double *o_x = (double *)io.out(xPred, h->d_xPred, n_x * 8), *o_u = (double *)io.out(uPred, h->d_uPred, n_u * 8);
@@ -509,6 +512,7 @@ extern "C" int lpvmpc_cl_init(lpvmpc_handle *h, int32_t B, const double *plant0,
     int rc = lpvmpc_check_common(h, B, "lpvmpc_cl_init"); if (rc) return rc;
     if (h->cfg.kind != LPVMPC_KIND_CONTROLLER) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_init: controller handles only");
     if (h->cfg.N > 20) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_init: the reference's seed trajectories have 20 rows (N <= 20)");
+    if (h->cfg.steering_delay != 0) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_init: the fleet engines run the reference's steeringDelay = 0 (CMAIN:49)");
     if (!plant0 || n_sub < 1 || !(dt_sim > 0)) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_init: bad argument");
     rc = lpvmpc_need_track(h, "lpvmpc_cl_init"); if (rc) return rc;
     if (h->cl_plant) { (void)hipFree(h->cl_plant); (void)hipFree(h->cl_local); (void)hipFree(h->cl_cmd); h->cl_plant = h->cl_local = h->cl_cmd = nullptr; }

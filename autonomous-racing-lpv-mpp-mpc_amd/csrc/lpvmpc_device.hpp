@@ -16,7 +16,7 @@ constexpr double kMinScaling = 1e-4, kMaxScaling = 1e4;
 struct DevCfg {
     int32_t kind, N, track_rows, max_iter;
     int32_t check_termination, scaling, adaptive_rho, adaptive_rho_interval;
-    int32_t polish, polish_refine_iter, pad0, pad1;
+    int32_t polish, polish_refine_iter, steering_delay, pad1;
     double dt, lf, lr, m, Iz, Cf, Cr, mu, max_vel, min_vel;
     double Q[36], R[4], dR[2], Lcf[6];
     double box_lo[8], box_hi[8];   // per-stage box rows, unscaled (planner row 3 = ey is per instance)
@@ -44,7 +44,7 @@ struct SolveArgs {
     const double *x0;       // [B][x0_stride], first NX used
     const double *AB;       // [B][N][NX][NX+2]
     const double *vel_ref;  // [B][N+1]   controller
-    const double *u_old;    // [B][2] or null
+    const double *u_old;    // [B][2 + steering_delay] or null
     const double *max_ey;   // [B]        planner
     double *xPred;          // [B][N+1][NX]
     double *uPred;          // [B][N][2]

@@ -62,7 +62,8 @@ typedef struct lpvmpc_config {
     int32_t kind;            /* LPVMPC_KIND_* */
     int32_t N;               /* horizon (ctor arg N, CTRL:35 / PLAN:34) */
     int32_t device;          /* HIP device ordinal */
-    int32_t reserved0;
+    int32_t steering_delay;  /* controller: ctor arg steeringDelay (CTRL:35,68-71): the first steering_delay stages get an equality
+                              * row delta_i = OldSteering[i+1] (CTRL:518-527); 0 (the reference's mains, CMAIN:49) .. 8.  Planner: 0 */
     double  dt;              /* sample time (ctor arg dt) */
     /* vehicle parameters the reference reads from ROS (CTRL:38-48, PLAN:70-82) */
     double  lf, lr, m, Iz, Cf, Cr, mu;
@@ -153,7 +154,8 @@ int lpvmpc_estimate_abc_batch(lpvmpc_handle *h, int32_t B, const double *xlast, 
  *   A       [B][N][nx][nx]   Bm [B][N][nx][2]
  *   vel_ref [B][N+1]   controller tracking reference: entries 0..N-1 = vel_ref[i], entry N = vel_ref[-1]
  *                      (CTRL:434-438); NULL for the planner
- *   u_old   [B][2]     [OldSteering[0], OldAccelera[0]] (CTRL:395, PLAN:114); NULL = zeros
+ *   u_old   [B][2 + steering_delay]  [OldSteering[0], OldAccelera[0], OldSteering[1 .. steering_delay]] (CTRL:395, 523;
+ *                      PLAN:114); NULL = zeros
  *   max_ey  [B]        planner lateral bound (solve arg max_ey, PLAN:176-177); NULL for the controller
  * outputs:
  *   xPred [B][N+1][nx], uPred [B][N][2]  (NaN for instances without a solution, as OSQP returns)

@@ -305,12 +305,14 @@ class QP:
     meta: dict = field(default_factory=dict)
 
 
-def ctrl_build_qp(Q, R, dR, N, A, B, x0, u_old, vel_ref, max_vel):
+def ctrl_build_qp(Q, R, dR, N, A, B, x0, u_old, vel_ref, max_vel, steer_hist=()):
     """QP of PathFollowingLPV_MPC.solve (CTRL:89-162 with a4/a5/a6/a8 of
     SURVEY section 8): inequalities first, then equalities (CTRL:303-308).
 
     ``u_old`` = [OldSteering[0], OldAccelera[0]] (CTRL:395).  The vel_ref
-    tracking point of stage N is vel_ref[-1] (CTRL:438)."""
+    tracking point of stage N is vel_ref[-1] (CTRL:438).  ``steer_hist`` =
+    OldSteering[1:] (length steeringDelay): one equality row per entry, appended
+    after the dynamics rows, pins u_i[0] = OldSteering[i+1] (CTRL:518-527)."""
     nx, nu = 6, 2
     Q = np.asarray(Q, float); R = np.asarray(R, float); dR = np.asarray(dR, float)
     vel_ref = np.asarray(vel_ref, float).reshape(-1)
@@ -340,6 +342,12 @@ def ctrl_build_qp(Q, R, dR, N, A, B, x0, u_old, vel_ref, max_vel):
         F[r + 3, c + 1] = -1.0; b[r + 3] = 1.0
     G, E = eq_constraints(A, B, nx, nu, N)
     beq = E @ np.asarray(x0, float).reshape(nx)          # quirk Q1: Eu*uOld dropped
+    steer_hist = np.asarray(steer_hist, float).reshape(-1)
+    if steer_hist.size:                                  # CTRL:518-527: Gdelay rows, L = OldSteering[i+1]
+        Gd = np.zeros((steer_hist.size, nz))
+        for i in range(steer_hist.size):
+            Gd[i, (N + 1) * nx + i * nu] = 1.0
+        G = np.vstack([G, Gd]); beq = np.concatenate([beq, steer_hist])
     Aqp = np.vstack([F, G])
     l = np.concatenate([-np.inf * np.ones(6 * N), beq])
     u = np.concatenate([b, beq])

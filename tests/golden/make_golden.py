@@ -151,10 +151,11 @@ def certified_optimum(c):
     return xs, ys, np.array(kkt_cert.kkt_residuals(c["P"], c["q"], c["A"], l, u, xs, ys))
 
 
-def ctrl_case(CTRL, mp, tuning, N, dt, x0, u_prev, vel_ref, curv_ref, lap, old_u, cf_new=60.0):
+def ctrl_case(CTRL, mp, tuning, N, dt, x0, u_prev, vel_ref, curv_ref, lap, old_u, cf_new=60.0, steer_hist=()):
+    """steer_hist = OldSteering[1:] (length steeringDelay): the pinned steering commands of CTRL:518-527."""
     Q, R, dR = TUNINGS[tuning]
-    c = CTRL.PathFollowingLPV_MPC(Q, R, dR, N, 1, dt, mp, "OSQP", 0, 0)
-    c.OldSteering = [float(old_u[0])]; c.OldAccelera = [float(old_u[1])]
+    c = CTRL.PathFollowingLPV_MPC(Q, R, dR, N, 1, dt, mp, "OSQP", len(steer_hist), 0)
+    c.OldSteering = [float(old_u[0])] + [float(v) for v in steer_hist]; c.OldAccelera = [float(old_u[1])]
     S, A_L, B_L, C_L = c.LPVPrediction(x0, u_prev, vel_ref, curv_ref, cf_new, lap)
     CAPTURE.clear()
     c.solve(x0, 0.0, u_prev, False, vel_ref, A_L, B_L, C_L, 10)
@@ -162,7 +163,7 @@ def ctrl_case(CTRL, mp, tuning, N, dt, x0, u_prev, vel_ref, curv_ref, lap, old_u
     xs, ys, cert = certified_optimum(cap)
     return dict(x0=x0, u_prev=u_prev, vel_ref=np.asarray(vel_ref, float), curv_ref=np.asarray(curv_ref, float),
                 lap=lap, old_u=np.asarray(old_u, float), cf_new=cf_new, Q=Q, R=R, dR=dR, N=N, dt=dt,
-                states=S, A=stackL(A_L), B=stackL(B_L), P=cap["P"], q=cap["q"], Aqp=cap["A"], l=cap["l"], u=cap["u"],
+                steer_hist=np.asarray(steer_hist, float), states=S, A=stackL(A_L), B=stackL(B_L), P=cap["P"], q=cap["q"], Aqp=cap["A"], l=cap["l"], u=cap["u"],
                 x_orc=cap["x"], y_orc=cap["y"], iter_orc=cap["iter"], status_orc=cap["status_val"],
                 polish_orc=cap["status_polish"], x_star=xs, y_star=ys, cert=cert,
                 xPred=np.array(c.xPred), uPred=np.array(c.uPred), LinPoints=np.array(c.LinPoints))
@@ -378,6 +379,22 @@ def main():
     try:
         if "handoff" in sys.argv[1:]:                       # regenerate only handoff.npz / cascade.npz
             gen_handoff(CTRL, PLAN, TRACK, UTIL)
+            return
+        if "delay" in sys.argv[1:]:                         # only ctrl_n20_delay.npz (steeringDelay = 1, 2, 3; CTRL:518-527)
+            oval = make_map(TRACK, "oval")
+            rng = np.random.default_rng(5)
+            N = 20; dt = 1.0 / 30.0
+            cases = []
+            for i in range(8):
+                delay = (1, 2, 2, 3)[i % 4]
+                s = rng.uniform(0, 13); vx = rng.uniform(0.8, 3.0)
+                x0 = np.array([vx, rng.normal(0, 0.05), rng.normal(0, 0.3), rng.normal(0, 0.1), s, rng.normal(0, 0.1)])
+                u_prev = np.tile([rng.normal(0, 0.05), rng.normal(0.2, 0.3)], (N, 1))
+                hist = rng.normal(0, 0.08, delay) if i < 6 else np.array([0.249, -0.249, 0.1][:delay])   # last two: pinned at the box
+                curv = np.full(N, UTIL.Curvature(s, oval.PointAndTangent))
+                cases.append(ctrl_case(CTRL, oval, "race" if i % 2 == 0 else "path", N, dt, x0, u_prev, np.full(N + 1, vx), curv,
+                                       0 if i % 4 == 3 else 1, u_prev[0], steer_hist=hist))
+            save_cases("ctrl_n20_delay", cases)
             return
         # ---------------- track tables + curvature samples ----------------
         tracks = {}

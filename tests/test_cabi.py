@@ -79,8 +79,12 @@ def test_no_device_fails_loudly(ffi):
     m = lpvmpc.Map("oval")
     with pytest.raises(lpvmpc.LpvMpcError):
         lpvmpc.PathFollowingLPV_MPC(np.eye(6), np.eye(2), np.ones(2), 20, 1, 1 / 30.0, m, "OSQP", 0, 0)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(lpvmpc.LpvMpcError) as e:            # steeringDelay is supported: the failure is the missing device
         lpvmpc.PathFollowingLPV_MPC(np.eye(6), np.eye(2), np.ones(2), 20, 1, 1 / 30.0, m, "OSQP", 3, 0)
+    assert e.value.code == ffi.E_NODEVICE
+    with pytest.raises(lpvmpc.LpvMpcError) as e:            # argument checks come before the device probe
+        lpvmpc.BatchedSolver("controller", 20, 1 / 30.0, np.eye(6), np.eye(2), np.ones(2), steering_delay=9)
+    assert e.value.code == ffi.E_ARG and "steering_delay" in str(e.value)
 
 
 def test_device_assembly_has_no_copy_in_front_of_an_exec_restore(ffi):

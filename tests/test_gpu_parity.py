@@ -465,3 +465,41 @@ def test_full_size_cfg4_properties(lpvmpc):
     assert sol.mean() > 0.7
     assert np.all(np.isnan(op["xPred"][~sol])) and np.all(np.isfinite(op["xPred"][sol]))
     assert np.max(np.abs(op["xPred"][sol][:, 0, :] - wp["x0"][sol])) <= 5e-3
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_controller_steering_delay_matches_reference_fixture(lpvmpc, variant):
+    """the pinned-steering equality rows of _buildMatEqConst (CTRL:518-527; OldSteering of length 1 + delay,
+    CTRL:71) -- fixture generated with the reference's own class at steeringDelay = 1, 2, 3; every kernel variant."""
+    tab = lpvmpc.Map("oval", 0.2).PointAndTangent
+    for i, c in enumerate(cases("ctrl_n20_delay")):
+        N = int(c["N"]); d = int(c["steer_hist"].size)
+        eng = lpvmpc.BatchedSolver("controller", N, float(c["dt"]), c["Q"], c["R"], c["dR"], track=tab, steering_delay=d)
+        eng.set_option("kernel_variant", variant)
+        u_old = np.concatenate([c["old_u"], c["steer_hist"]])[None]
+        out = eng.solve_AB(c["x0"][None], c["A"][None], c["B"][None], vfull(c)[None], u_old)
+        eng.close()
+        assert int(out["status"][0]) == int(c["status_orc"]), (i, out["status"][0])
+        assert int(out["iters"][0]) == int(c["iter_orc"]), (i, out["iters"][0], c["iter_orc"])
+        assert int(out["polish"][0]) == int(c["polish_orc"]), i
+        tol = 1e-6 if int(c["polish_orc"]) == 1 else 2e-4
+        relclose(out["xPred"][0], c["xPred"], tol)
+        assert np.max(np.abs(out["uPred"][0] - c["uPred"])) <= tol, i
+        assert np.max(np.abs(out["uPred"][0][:d, 0] - c["steer_hist"])) <= 2e-4          # the pins hold
+        z = np.concatenate([out["xPred"][0].reshape(-1), out["uPred"][0].reshape(-1)])
+        ok, info = kkt_cert.osqp_termination_ok(c["P"], c["q"], c["Aqp"], np.where(c["l"] < -1e29, -np.inf, c["l"]), c["u"], z, c["y_orc"])
+        assert ok, info
+
+
+def test_dropin_controller_with_steering_delay(lpvmpc):
+    """The drop-in class with steeringDelay = 2: OldSteering has three entries (CTRL:71) and solve() pins u_0, u_1."""
+    c = cases("ctrl_n20_delay")[1]
+    assert c["steer_hist"].size == 2
+    mp = lpvmpc.Map("oval", 0.2)
+    ctl = lpvmpc.PathFollowingLPV_MPC(c["Q"], c["R"], c["dR"], int(c["N"]), 1, float(c["dt"]), mp, "OSQP", 2, 0)
+    assert len(ctl.OldSteering) == 3 and len(ctl.OldPredicted) == 1 + 2 + int(c["N"])
+    ctl.OldSteering = [float(c["old_u"][0])] + [float(v) for v in c["steer_hist"]]; ctl.OldAccelera = [float(c["old_u"][1])]
+    S, A_L, B_L, C_L = ctl.LPVPrediction(c["x0"], c["u_prev"], c["vel_ref"], c["curv_ref"], float(c["cf_new"]), int(c["lap"]))
+    ctl.solve(c["x0"], 0.0, c["u_prev"], False, c["vel_ref"], A_L, B_L, C_L, 10)
+    assert ctl.iters == int(c["iter_orc"]) and ctl.status_val == 1
+    relclose(ctl.xPred, c["xPred"], 1e-6); relclose(ctl.uPred, c["uPred"], 1e-6)
