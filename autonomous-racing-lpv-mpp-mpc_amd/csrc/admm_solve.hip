@@ -32,7 +32,7 @@ namespace lpvmpc {
 #define STAMP(slot) do { } while (0)
 #endif
 
-template <int NX, int NT, int NW>
+template <int NX, int NT, int NW, bool MF = false>
 struct Solver {
 #ifdef LPVMPC_STAMPS
     unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -41,11 +41,14 @@ struct Solver {
     static constexpr bool kCtrl = (NX == 6);
     static constexpr bool kReg = (NT > 0);          // factor tiles in registers, horizon known at compile time
     static constexpr bool kTwo = (NW == 2);         // two wavefronts per instance: two-sided ("twisted") elimination
+    static constexpr bool kMf = MF;                 // the two sweeps run on the matrix cores (v_mfma_f64_4x4x4_4b_f64), see mf_forward
+    static_assert(!MF || (NW == 2 && NT > 0), "the MFMA sweeps are written for the two-wavefront compile-time-horizon kernels");
     static_assert(NW == 1 || (NW == 2 && NT >= 16 && NT % 2 == 0), "two wavefronts need an even compile-time horizon >= 16");
     static constexpr bool kLastOdd = ((NT / 2 - 1) & 1) != 0;   // parity of the last chain position (both chains have NT/2 stages)
     static constexpr int kMid = NT / 2;             // NW == 2: wave 0 eliminates stages 0..kMid-1 upwards, wave 1 stages
     static constexpr int kP0 = kMid, kP1 = NT - kMid;   //         NT..kMid+1 downwards; stage kMid joins the two chains
-    static constexpr int kRS = kReg ? (kTwo ? (kP1 > kP0 ? kP1 : kP0) : NT + 1) : 1;
+    static constexpr int kRS = (kReg && !MF) ? (kTwo ? (kP1 > kP0 ? kP1 : kP0) : NT + 1) : 1;
+    static constexpr int kMP = MF ? kMid : 1;       // chain positions per wavefront in the MFMA sweeps
     static constexpr int kStride = 64 * NW;
 
     const DevCfg &cfg;
@@ -55,6 +58,13 @@ struct Solver {
     double *tS, *tL, *tA;
     double rS[kRS], rL[kRS];
     double rSm, rLt, rLb;    // NW == 2: pivot inverse of the middle stage and its two link tiles (wave 0; rLb also wave 1)
+    // MFMA sweeps: operand tiles in A layout, one "diagonal" and one "off-diagonal" register per chain step (each holds four
+    // 4x4 blocks: blocks 0, 1 = the two row halves of the chain tile, blocks 2, 3 = the row halves of a second, independent
+    // tile that multiplies the same vector).  Forward step p: {-L_p | S_{p-1}^-1}; backward step p: {-L_{p+1}' | [A|B] of the
+    // operand stage}; mid: S_m^-1 in all four blocks; tail (wave 0): {0 | [A|B]_0}.
+    double fD[kMP], fO[kMP], bD[kMP], bO[kMP], mD, mO, tD, tO;
+    int mr, mh, mw, mj, gD, gO, gDT, gOT;   // lane coordinates in the MFMA layouts and gather offsets into a row-major 8x8 tile
+    int li, lj, tlane;                      // "D form" of an 8x8 matrix (see mm8): row / column held by this lane, lane of the transposed element
     // variable-space vectors
     double *X, *Qv, *D, *XT, *DX, *VT, *AT;
     // dynamics rows / box rows (ZT*: scratch rows; DY*: delta_y, or the active-set flags during polish)
@@ -90,6 +100,14 @@ struct Solver {
         r2 = (kCtrl && tj == 6) ? 6 : 7;
         bvar = box_var(tj); rmask = tj < NX ? 1.0 : 0.0;
         c = 1.0; cinv = 1.0; pol = false; rho = rho_eq = rinv = rinv_eq = 0.0; rSm = rLt = rLb = 0.0;
+        mr = lane >> 4; mh = (lane >> 2) & 1; mw = (lane >> 3) & 1; mj = lane & 3;
+        gD = (4 * mh + mj) * 8 + 4 * mh + mr;            // A[i = mj][k = mr] = T[4h + i][4h + k]
+        gO = (4 * mh + mj) * 8 + 4 * (1 - mh) + mr;      //                    T[4h + i][4h' + k]
+        gDT = (4 * mh + mr) * 8 + 4 * mh + mj;           // the same of T'
+        gOT = (4 * (1 - mh) + mr) * 8 + 4 * mh + mj;
+        mD = mO = tD = tO = 0.0;
+        li = 4 * ((lane >> 3) & 1) + (lane >> 4); lj = lane & 7;
+        tlane = 8 * dgroup(lj) + li;
     }
     static __host__ __device__ size_t lds_doubles(int N) {
         return (size_t)(N + 1) * ((kReg ? 1 : 3) * kTS + 19 * 8 + 8) + 16 + 64 + 8 + 80 + 64;
@@ -122,6 +140,11 @@ struct Solver {
     __device__ __forceinline__ double w_box(int e) const { return pol ? fabs(DYb[e]) : rho_of(Lo[e], Hi[e], rho); }
     __device__ __forceinline__ double w_dyn(int e) const { return pol ? fabs(DYd[e]) : rho_eq; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // The same value, opaque to the optimiser.  The element loops of the ADMM iteration start from it so that their LDS
+    // addresses are formed inside the loop as (one per-lane base) + (immediate offset of the array) instead of being hoisted
+    // out of the iteration loop as one live address register per (array, access pattern) pair -- those registers, not the
+    // arithmetic, are what pushed the kernel into scratch spills.
+    __device__ __forceinline__ static int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
     // wave-local ordering of LDS traffic (one wavefront executes its DS instructions in order; this only stops
     // the compiler from moving them across)
     __device__ __forceinline__ void wsync() const {
@@ -441,9 +464,158 @@ struct Solver {
         for (int t = 0; t < 4; ++t) { const double2 a = rowi3[t], b = rowj3[t]; sinv += a.x * b.x; sinv += a.y * b.y; }
         return sinv;
     }
+    // ---- 8x8 matrices on the matrix cores ---------------------------------------------------------------------------
+    // "D form" of an 8x8 matrix M, seen as 2x2 blocks of 4x4: lane (r, b = 2I + J, c) -- r = lane >> 4, b = (lane >> 2) & 3,
+    // c = lane & 3 -- holds M[4I + r][4J + c].  It is what four-block MFMAs deliver, it is a B operand as it stands, and used
+    // as an A operand it acts as M' (A[i][k] sits in lane (r = k, c = i)).  Row i of M occupies the 8 consecutive lanes of
+    // group dgroup(i), column index = lane & 7: D form is the [ti][tj] layout of the other kernels with the rows permuted, so
+    // the Cholesky / inversion below is the same DPP code with the row index renamed.
+    __device__ __forceinline__ static constexpr int dgroup(int i) { return 2 * (i & 3) + (i >> 2); }
+    // c + A B, given at = D form of A' and b = D form of B: two MFMAs (k = 0..3, 4..7); the operand quads are replicated by
+    // DPP moves -- A operand of block (I, J): block (K, I) of at, B operand: block (K, J) of b
+    __device__ __forceinline__ static double mm8(double at, double b, double c) {
+        const double a0 = dpp_into<0x118, 0x8>(dpp_into<0x114, 0x6>(at, at), at);      // quads (0, 0, 1, 1) of at
+        const double a1 = dpp_into<0x108, 0x1>(dpp_into<0x104, 0x6>(at, at), at);      // quads (2, 2, 3, 3)
+        const double b0 = dpp_into<0x128, 0xC>(b, b), b1 = dpp_into<0x128, 0x3>(b, b); // quads (0, 1, 0, 1) / (2, 3, 2, 3) of b
+        return mfma4(a1, b1, mfma4(a0, b0, c));
+    }
+    __device__ __forceinline__ double transpose_d(double v) const { return __shfl(v, tlane); }
+    // Cholesky S = C C' merged with the forward substitution C W = I, in D form (see chol_inverse)
+    __device__ __forceinline__ double chol_inverse_d(double s) const {
+        double w = (li == lj) ? 1.0 : 0.0;
+#define LPVMPC_CHOL_STEP_D(T)                                                                                 \
+        {                                                                                                         \
+            constexpr int G = dgroup(T);                                                                          \
+            const double d = bcast_lane<G * 8 + (T)>(s);                                                          \
+            const double rs = inv_sqrt(d);                                                                        \
+            const double cit = bcast_row<(T)>(s) * rs;                                                            \
+            const double cjt = __shfl(s, G * 8 + lj) * rs;                                                        \
+            const double wtj = __shfl(w, G * 8 + lj) * rs;                                                        \
+            if (li > (T) && lj > (T)) s -= cit * cjt;                                                             \
+            if (li == (T)) w = wtj; else if (li > (T)) w -= cit * wtj;                                            \
+        }
+        LPVMPC_CHOL_STEP_D(0) LPVMPC_CHOL_STEP_D(1) LPVMPC_CHOL_STEP_D(2) LPVMPC_CHOL_STEP_D(3)
+        LPVMPC_CHOL_STEP_D(4) LPVMPC_CHOL_STEP_D(5) LPVMPC_CHOL_STEP_D(6) LPVMPC_CHOL_STEP_D(7)
+#undef LPVMPC_CHOL_STEP_D
+        return w;
+    }
+    // operand registers of the MFMA sweeps from D forms: x = D form of the TRANSPOSE of the chain tile (blocks 0, 1 of the pair),
+    // s2 = D form of the transpose of the second tile (blocks 2, 3).  Diagonal register: quads (x0, x3, s0, s3); off-diagonal
+    // register: quads (x2, x1, s2, s1)  (quad q = block (I, J) = (q >> 1, q & 1) of the D form).
+    struct MfPair { double d, o; };
+    __device__ __forceinline__ static MfPair sweep_pair(double x, double s2) {
+        double d = dpp_into<0x108, 0x2>(x, x);          // quad 1 <- x quad 3
+        d = dpp_into<0x118, 0x4>(d, s2);                // quad 2 <- s2 quad 0
+        d = dpp_into<0xE4, 0x8>(d, s2);                 // quad 3 <- s2 quad 3
+        double o = dpp_into<0x108, 0x1>(x, x);          // quad 0 <- x quad 2
+        o = dpp_into<0xE4, 0x4>(o, s2);                 // quad 2 <- s2 quad 2
+        o = dpp_into<0x118, 0x8>(o, s2);                // quad 3 <- s2 quad 1
+        return MfPair{d, o};
+    }
+    // diagonal block K_kk in D form; WDv / WBv: row weights of the dynamics / box rows (filled by factor())
+    __device__ __forceinline__ double kd_d(int k, double sig, const double *WDv, const double *WBv) const {
+        const int nv = nvar(k);
+        const bool inside = li < nv && lj < nv, dg = li == lj;
+        const int a = inside ? li : 0, b = inside ? lj : 0;
+        double kd = Pc(k, a, b) * c * D[k * 8 + a] * D[k * 8 + b];
+        // diagonal: sigma + the box rows acting on the variable + the identity part of its dynamics row (lj = tj: r0, r1, r2 apply)
+        const double sb0 = Sb(k, r0), sb1 = Sb(k, r1), sb2 = Sb(k, r2), ei = Eid(k, lj);
+        double dd = sig + WBv[k * 8 + r0] * sb0 * sb0 + WBv[k * 8 + r1] * sb1 * sb1 + WDv[k * 8 + lj] * ei * ei;
+        if (kCtrl && delay > 0) dd += WBv[k * 8 + r2] * sb2 * sb2;
+        kd = inside ? (dg ? kd + dd : kd) : (dg ? 1.0 : 0.0);
+        if (k < N) {        // + [A|B]_k' diag(w_{k+1}) [A|B]_k
+            const double ab = li < NX ? tA[k * kTS + li * 8 + lj] : 0.0;
+            kd = mm8(ab, WDv[(k + 1) * 8 + (li < NX ? li : 0)] * ab, kd);
+        }
+        return kd;
+    }
+    // element [a][b] of the coupling blocks (rows: variables of stage k; columns: variables of stage k-1 / k+1)
+    __device__ __forceinline__ double ko_down_at(int k, int a, int b, const double *WDv) const {
+        double ko = 0.0;
+        if (b < NB) {
+            if (a < NX) ko = -WDv[k * 8 + a] * Eid(k, a) * tA[(k - 1) * kTS + a * 8 + b];
+            else if (a == b && a < nvar(k)) ko = c * D[k * 8 + a] * (-2.0 * dRl[a - NX]) * D[(k - 1) * 8 + a];
+        }
+        return ko;
+    }
+    __device__ __forceinline__ double ko_up_at(int k, int a, int b, const double *WDv) const {
+        double ko = 0.0;
+        if (a < NB) {
+            if (b < NX) ko = -WDv[(k + 1) * 8 + b] * Eid(k + 1, b) * tA[k * kTS + b * 8 + a];
+            else if (a == b && b < nvar(k + 1)) ko = c * D[(k + 1) * 8 + b] * (-2.0 * dRl[b - NX]) * D[k * 8 + b];
+        }
+        return ko;
+    }
+    // entry g (row-major offset) of the scaled [A|B] tile of stage k as an MFMA operand: dynamics rows only (rows 6, 7 of the
+    // LDS tile cache row coefficients)
+    __device__ __forceinline__ double ab_entry(int k, int g) const { return (g >> 3) < NX ? tA[k * kTS + g] : 0.0; }
     __device__ __forceinline__ void factor(double sig) {
         sync();
-        if constexpr (kTwo) {
+        if constexpr (kMf) {
+            // Same two-sided elimination as the DPP kernel below (wave 0: stages 0 .. kMid-1 upwards, wave 1: N .. kMid+1
+            // downwards), with every 8x8 matrix in D form and every 8x8x8 product on the matrix cores (mm8), nothing staged
+            // through LDS.  Per stage: G' = W Ko' (W = C_pred^-1), S = Kd - G G', L' = W' G', L = G W, C C' = S, W <- C^-1,
+            // S^-1 = W' W; the finished step leaves its tiles in the operand registers of the MFMA sweeps.
+            double *const WDv = XT, *const WBv = DX, *const PUB = VT;       // free vectors: row weights, hand-over area (VT + AT)
+            for (int e = tid; e < NS * 8; e += kStride) { WDv[e] = w_dyn(e); WBv[e] = w_box(e); }
+            sync();
+            constexpr int P = kMid;
+            double wd = 0.0, wtd = 0.0, sinv = 0.0;       // D forms of W, W' and S^-1 of the stage eliminated last
+            for (int p = 0; p < P; ++p) {
+                const int k = wv ? N - p : p;
+#ifdef LPVMPC_STAMPS
+                tlast = __builtin_amdgcn_s_memtime();
+#endif
+                const double kd = kd_d(k, sig, WDv, WBv);
+                STAMP(4);
+                double sk = kd;
+                if (p >= 1) {
+                    const double kot = wv ? ko_up_at(k, lj, li, WDv) : ko_down_at(k, lj, li, WDv);     // D form of Ko'
+                    const double gt = mm8(wtd, kot, 0.0);          // G' = W Ko'
+                    sk = mm8(-gt, gt, kd);                         // S = Kd - G G'
+                    const double ltn = -mm8(wd, gt, 0.0);          // -L' = -W' G'
+                    const double ln = -mm8(gt, wd, 0.0);           // -L  = -G W
+                    // forward step p: {-L_p | S_{p-1}^-1}; backward step p - 1: {-L_p' | [A|B] of the operand stage k}
+                    const MfPair f = sweep_pair(ltn, sinv), b = sweep_pair(ln, ln);
+                    const double b0 = mw ? ab_entry(k, gD) : b.d, b1 = mw ? ab_entry(k, gO) : b.o;
+#pragma unroll
+                    for (int pp = 0; pp < kMP; ++pp) if (pp == p - 1) { fD[pp] = f.d; fO[pp] = f.o; bD[pp] = b0; bO[pp] = b1; }
+                }
+                STAMP(5);
+                wd = chol_inverse_d(sk);
+                wtd = transpose_d(wd);
+                STAMP(6);
+                sinv = mm8(wd, wd, 0.0);                           // S^-1 = W' W
+                STAMP(7);
+            }
+            if (wv == 1) { PUB[lane] = wd; PUB[64 + lane] = wtd; }
+            sync();
+            double ltn = 0.0, ln = 0.0, sm = 0.0;                  // -L_link', -L_link of this wave's chain; S_m^-1
+            if (wv == 0) {      // middle stage: S_m = K_mm - G_t G_t' - G_b G_b' with both neighbours' W
+                const double kd = kd_d(kMid, sig, WDv, WBv);
+                const double gtt = mm8(wtd, ko_down_at(kMid, lj, li, WDv), 0.0);
+                double sk = mm8(-gtt, gtt, kd);
+                ltn = -mm8(wd, gtt, 0.0); ln = -mm8(gtt, wd, 0.0);
+                const double wd1 = PUB[lane], wtd1 = PUB[64 + lane];
+                const double gtb = mm8(wtd1, ko_up_at(kMid, lj, li, WDv), 0.0);
+                sk = mm8(-gtb, gtb, sk);
+                PUB[128 + lane] = -mm8(wd1, gtb, 0.0); PUB[192 + lane] = -mm8(gtb, wd1, 0.0);
+                const double wm = chol_inverse_d(sk);
+                sm = mm8(wm, wm, 0.0);
+                PUB[256 + lane] = sm;
+            }
+            sync();
+            if (wv == 1) { ltn = PUB[128 + lane]; ln = PUB[192 + lane]; sm = PUB[256 + lane]; }
+            {
+                const MfPair f = sweep_pair(ltn, sinv), b = sweep_pair(ln, ln), m = sweep_pair(sm, sm);
+                fD[P - 1] = f.d; fO[P - 1] = f.o;
+                bD[P - 1] = mw ? ab_entry(kMid, gD) : b.d; bO[P - 1] = mw ? ab_entry(kMid, gO) : b.o;
+                mD = m.d; mO = m.o;
+                tD = mw ? ab_entry(0, gD) : 0.0; tO = mw ? ab_entry(0, gO) : 0.0;
+            }
+            sync();
+            return;
+        } else if constexpr (kTwo) {
             // ---- two-sided elimination: wave 0 runs stages 0 .. kMid-1 upwards, wave 1 stages N .. kMid+1 downwards ----
             double *const T = XT + wv * 256;
             const int P = wv ? kP1 : kP0;
@@ -593,8 +765,97 @@ struct Solver {
         }
     }
 
+    // ---- the two sweeps on the matrix cores -------------------------------------------------------------------------
+    // One v_mfma_f64_4x4x4_4b_f64 pair per chain step: blocks 0, 1 advance the chain (y_p = b_p - L_p y_{p-1}, or
+    // x_p = v_p - L_{p+1}' x_{p+1}), blocks 2, 3 multiply the same operand by a second tile -- the pivot product
+    // v_{p-1} = S_{p-1}^-1 y_{p-1} on the way up, the dynamics-row product [A|B]_k x_k (the z~ = A x~ of the ADMM update)
+    // on the way down.  The chain value comes out in the layout the next step reads it in; per step only the block-pair
+    // replication (2 DPP moves) and the half swap for the off-diagonal blocks (4 DPP moves, off the chain) are vector work.
+    template <bool BOT>
+    __device__ __forceinline__ void mf_forward() {
+        constexpr int P = kMid;
+        auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
+        const int ln = opaque(lane), elem = ((ln >> 2) & 1) * 4 + (ln >> 4);
+        const bool second = (ln >> 3) & 1, col0 = (ln & 3) == 0;          // blocks 2, 3; column j = 0 of a block (the lanes that store)
+        const double *const bsrc = XT + elem;
+        double *const vst = (col0 && second) ? VT + elem : SINK + ln;
+        if (!BOT && ln < 8) RED[48 + ln] = XT[kMid * 8 + ln];             // the middle right-hand side survives x_m (see twisted_forward)
+        double Y = bsrc[stage(0) * 8], Dlate = 0.0;
+        double bq[3];                                                       // right-hand sides are fetched two steps ahead
+        bq[1] = bsrc[stage(1) * 8];
+        bq[2] = (P > 2) ? bsrc[stage(2) * 8] : 0.0;
+#pragma unroll
+        for (int p = 1; p < P; ++p) {
+            const double bl = bq[p % 3];
+            if (p + 2 < P) bq[(p + 2) % 3] = bsrc[stage(p + 2) * 8];
+            __builtin_amdgcn_sched_barrier(0);          // keep the fetch up here: sunk to its use, every step waits for LDS
+            const double bp = second ? 0.0 : bl;
+            const double Ysw = swap_half(Y);
+            const double t = mfma4(fD[p - 1], Y, bp);
+            // the previous step's pivot product v_{p-2} (blocks 2, 3) is stored here, in the shadow of this step's first
+            // MFMA: a store of a fresh MFMA result sits ~45 cycles of result latency in front of the chain's next move
+            if (p >= 2) vst[stage(p - 2) * 8] = Dlate;
+            __builtin_amdgcn_sched_barrier(0);
+            const double D = mfma4(fO[p - 1], Ysw, t);
+            Dlate = D;
+            Y = dup01(D);
+        }
+        if (P >= 2) vst[stage(P - 2) * 8] = Dlate;
+        // last chain stage: its pivot product and this chain's contribution -L_link y_last to the middle right-hand side
+        double *const cst = col0 ? (second ? VT + stage(P - 1) * 8 + elem : RED + 32 + (BOT ? 8 : 0) + elem) : SINK + ln;
+        const double Ysw = swap_half(Y);
+        *cst = mfma4(fO[P - 1], Ysw, mfma4(fD[P - 1], Y, 0.0));
+    }
+    template <bool BOT>
+    __device__ __forceinline__ void mf_backward() {
+        constexpr int P = kMid;
+        auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
+        const int ln = opaque(lane), elem = ((ln >> 2) & 1) * 4 + (ln >> 4);
+        const bool second = (ln >> 3) & 1, col0 = (ln & 3) == 0;
+        const double *const vsrc = VT + elem;
+        double Dlate = 0.0;
+        double vq[3];                                                       // pivot products are fetched two steps ahead
+        vq[(P - 1) % 3] = vsrc[stage(P - 1) * 8];
+        if (P >= 2) vq[(P - 2) % 3] = vsrc[stage(P - 2) * 8];
+        const double ym = RED[48 + elem] + (RED[32 + elem] + RED[40 + elem]);
+        double X = mfma4(mO, swap_half(ym), mfma4(mD, ym, 0.0));        // x_m, identical in all four blocks and on both waves
+        *((!BOT && col0 && !second) ? XT + kMid * 8 + elem : SINK + ln) = X;
+        // blocks 0, 1 -> x_p; blocks 2, 3 -> [A|B]_k x_k of the operand stage k, filed under the dynamics rows of stage k + 1
+        double *const xonly = (col0 && !second) ? XT + elem : SINK + ln;
+        double *const xst = col0 ? (second ? AT + (BOT ? 0 : 16) + elem : XT + elem) : SINK + ln;
+#pragma unroll
+        for (int p = P - 1; p >= 0; --p) {
+            const double vl = vq[p % 3];
+            if (p - 2 >= 0) vq[(p - 2) % 3] = vsrc[stage(p - 2) * 8];
+            __builtin_amdgcn_sched_barrier(0);
+            const double vp = second ? 0.0 : vl;
+            const double Xsw = swap_half(X);
+            const double t = mfma4(bD[p], X, vp);
+            // the previous step's results are stored in the shadow of this step's first MFMA (see mf_forward); both waves'
+            // first step multiplies [A|B]_kMid x_m: wave 1 files it, wave 0 drops it
+            if (p <= P - 2) ((!BOT && p == P - 2) ? xonly : xst)[stage(p + 1) * 8] = Dlate;
+            __builtin_amdgcn_sched_barrier(0);
+            const double D = mfma4(bO[p], Xsw, t);
+            Dlate = D;
+            X = dup01(D);
+        }
+        ((!BOT && P == 1) ? xonly : xst)[stage(0) * 8] = Dlate;
+        if (!BOT) {     // [A|B]_0 x_0 -> dynamics rows of stage 1
+            const double Xsw = swap_half(X);
+            *((col0 && second) ? AT + 8 + elem : SINK + ln) = mfma4(tO, Xsw, mfma4(tD, X, 0.0));
+        }
+    }
+
     __device__ __forceinline__ void kkt_solve() {
-        if constexpr (kTwo) {
+        if constexpr (kMf) {
+            if (wv == 0) mf_forward<false>(); else mf_forward<true>();
+            sync();
+            STAMP(1);
+            if (wv == 0) mf_backward<false>(); else mf_backward<true>();
+            sync();
+            STAMP(2);
+            return;
+        } else if constexpr (kTwo) {
             if (wv == 0) twisted_forward<false>(); else twisted_forward<true>();
             sync();
             STAMP(1);
@@ -817,19 +1078,20 @@ struct Solver {
     }
     // XT = sigma x - q + A' (rho z - y)        (OSQP compute_rhs, x part, reduced form)
     __device__ __forceinline__ void build_rhs(double sigma) {
-        for (int e = tid; e < NS * 8; e += kStride) XT[e] = At_elem(e, ZTd, ZTb) + (sigma * X[e] - Qv[e]);
+        for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] = At_elem(e, ZTd, ZTb) + (sigma * X[e] - Qv[e]);
         sync();
     }
     // z~ = A x~ fused with OSQP update_x / update_z / update_y; leaves rho z - y in ZT*.
     // All LDS reads of a round are issued before any of its writes.
     __device__ __forceinline__ void update(double alpha, bool want_delta) {
         const double oma = 1.0 - alpha;
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             const int k = e >> 3;
             const double xt = XT[e], xo = X[e];
             const double zd = Zd[e], yd = Yd[e], zb = Zb[e], yb = Yb[e], lo = Lo[e], hi = Hi[e];
             const double b = dyn_bound(e), sb = Sb(k, tj), xv = XT[k * 8 + bvar], ei = Eid(k, tj);
-            const double dot = prev_stage_dot(k, XT);
+            // previous stage's dynamics-row product: left in AT by the backward MFMA sweep, or formed here
+            const double dot = kMf ? (k > 0 ? AT[e] : 0.0) : prev_stage_dot(k, XT);
             // dynamics row (k, tj): bounds l = u = b
             const double ztd = rmask * (ei * xt - dot);
             const double zrd = alpha * ztd + oma * zd;
@@ -966,9 +1228,18 @@ struct Solver {
         double pri_res = 0, dua_res = 0, obj = __builtin_nan("");
         Res R = {0, 0, 0, 0, 0, 0, 0, 0};
         bool checked = false;
-        for (iter = 1; iter <= cfg.max_iter; ++iter) {
-            checked = cfg.check_termination > 0 && (iter % cfg.check_termination == 0);
-            const bool adapt = cfg.adaptive_rho && cfg.adaptive_rho_interval > 0 && (iter % cfg.adaptive_rho_interval == 0);
+        // loop control on local copies and down-counters: the configuration block lives in global memory and stores to the
+        // outputs may alias it as far as the compiler knows, so every use inside the loop is a scalar load plus a wait, and
+        // iter % interval is a dozen scalar instructions per iteration
+        const int max_iter = cfg.max_iter, chk_every = cfg.check_termination > 0 ? cfg.check_termination : 0;
+        const int adp_every = (cfg.adaptive_rho && cfg.adaptive_rho_interval > 0) ? cfg.adaptive_rho_interval : 0;
+        const double rho_tol = cfg.rho_tol;
+        int to_chk = chk_every, to_adp = adp_every;
+        for (iter = 1; iter <= max_iter; ++iter) {
+            checked = chk_every > 0 && --to_chk == 0;
+            const bool adapt = adp_every > 0 && --to_adp == 0;
+            if (checked) to_chk = chk_every;
+            if (adapt) to_adp = adp_every;
 #ifdef LPVMPC_STAMPS
             tlast = __builtin_amdgcn_s_memtime();
 #endif
@@ -983,12 +1254,12 @@ struct Solver {
                 if (checked) { status = check_termination(R, false); if (status != LPVMPC_UNSOLVED_) break; }
                 if (adapt) {
                     const double rn = rho_estimate(R, rho);
-                    if (rn > rho * cfg.rho_tol || rn < rho / cfg.rho_tol) { set_rho(rn); factor(sigma); }
+                    if (rn > rho * rho_tol || rn < rho / rho_tol) { set_rho(rn); factor(sigma); }
                 }
                 recompute_w();              // the residual evaluation used ZT* as scratch (and rho may have changed)
             }
         }
-        if (iter > cfg.max_iter) iter = cfg.max_iter;
+        if (iter > max_iter) iter = max_iter;
         if (!checked) {
             R = residuals(X, Zd, Zb, Yd, Yb); pri_res = R.pri; dua_res = R.dua;
             status = check_termination(R, false);
@@ -1031,7 +1302,11 @@ struct Solver {
 #ifdef LPVMPC_STAMPS
         if (tid == 0 && a.resid) {     // diagnostic build: resid carries per-iteration cycle counts instead
             double *o = a.resid + (size_t)inst * 4;
+#if LPVMPC_STAMPS == 2
+            o[0] = (double)stamp[4]; o[1] = (double)stamp[5]; o[2] = (double)stamp[6]; o[3] = (double)stamp[7];      // factor phases, summed over the solve
+#else
             o[0] = (double)stamp[0] / iter; o[1] = (double)stamp[1] / iter; o[2] = (double)stamp[2] / iter; o[3] = (double)stamp[3] / iter;
+#endif
             if (a.status) a.status[inst] = status;
             if (a.iters) a.iters[inst] = iter;
             return;
@@ -1174,25 +1449,25 @@ constexpr int min_waves_per_simd() { return NW; }      // diagnostic: provoke re
 constexpr int min_waves_per_simd() { return (NW == 2 && NT <= 20) ? 2 : 1; }
 #endif
 
-template <int NX, int NT, int NW>
+template <int NX, int NT, int NW, bool MF = false>
 __global__ void __launch_bounds__(64 * NW, (min_waves_per_simd<NT, NW>())) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
     extern __shared__ __align__(16) double smem[];
     const int inst = blockIdx.x;
     if (inst >= a.B) return;
-    Solver<NX, NT, NW> s(*cfgp, smem);
+    Solver<NX, NT, NW, MF> s(*cfgp, smem);
     s.run(a, inst);
 }
 
-template <int NX, int NT, int NW>
+template <int NX, int NT, int NW, bool MF = false>
 static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream) {
-    const size_t lds = Solver<NX, NT, NW>::lds_doubles(cfg.N) * sizeof(double);
+    const size_t lds = Solver<NX, NT, NW, MF>::lds_doubles(cfg.N) * sizeof(double);
     static bool attr_set = false;      // per instantiation; the attribute is per function, set once
     if (!attr_set) {
-        hipError_t err = hipFuncSetAttribute((const void *)admm_solve_kernel<NX, NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t err = hipFuncSetAttribute((const void *)admm_solve_kernel<NX, NT, NW, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (err != hipSuccess) return err;
         attr_set = true;
     }
-    hipLaunchKernelGGL((admm_solve_kernel<NX, NT, NW>), dim3(a.B), dim3(64 * NW), lds, stream, dcfg, a);
+    hipLaunchKernelGGL((admm_solve_kernel<NX, NT, NW, MF>), dim3(a.B), dim3(64 * NW), lds, stream, dcfg, a);
     return hipGetLastError();
 }
 
@@ -1209,9 +1484,10 @@ size_t solve_lds_bytes(int kind, int N) {
 // kernel_variant: 0 = best available, 1 = run-time-horizon kernel (factor tiles in LDS), 2 = compile-time horizon
 // with one wavefront per instance (where instantiated)
 hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream, int kernel_variant) {
-    const bool generic = kernel_variant == 1, one_wave = kernel_variant == 2;
+    const bool generic = kernel_variant == 1, one_wave = kernel_variant == 2, dpp = kernel_variant == 3;
     if (cfg.kind == 0) {
-        if (!generic && cfg.N == 20) return one_wave ? launch_one<6, 20, 1>(cfg, dcfg, a, stream) : launch_one<6, 20, 2>(cfg, dcfg, a, stream);
+        if (!generic && cfg.N == 20) return one_wave ? launch_one<6, 20, 1>(cfg, dcfg, a, stream)
+                                          : (dpp ? launch_one<6, 20, 2>(cfg, dcfg, a, stream) : launch_one<6, 20, 2, true>(cfg, dcfg, a, stream));
         if (!generic && cfg.N == 10) return launch_one<6, 10, 1>(cfg, dcfg, a, stream);
         if (!generic && cfg.N == 8) return launch_one<6, 8, 1>(cfg, dcfg, a, stream);      // the launch file's controller horizon (MAIN_LAUNCH.launch:117)
         return launch_one<6, 0, 1>(cfg, dcfg, a, stream);

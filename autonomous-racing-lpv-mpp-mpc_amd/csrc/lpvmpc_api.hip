@@ -173,7 +173,7 @@ extern "C" int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t val
         if (value < 0 || value > 2) return fail(h, LPVMPC_E_ARG, "warm_start must be 0 (off), 1 (previous solution) or 2 (shifted by one stage)");
         h->warm_mode = value; h->state_valid_B = 0; return LPVMPC_OK;
     }
-    if (std::strcmp(name, "kernel_variant") == 0) { if (value < 0 || value > 2) return fail(h, LPVMPC_E_ARG, "kernel_variant must be 0, 1 or 2"); h->force_generic = value; return LPVMPC_OK; }
+    if (std::strcmp(name, "kernel_variant") == 0) { if (value < 0 || value > 3) return fail(h, LPVMPC_E_ARG, "kernel_variant must be 0, 1, 2 or 3"); h->force_generic = value; return LPVMPC_OK; }
     if (std::strcmp(name, "cascade_prefetch") == 0) { h->cascade_prefetch = value != 0 ? 1 : 0; return LPVMPC_OK; }   // read by lpvmpc_cascade_init
     return fail(h, LPVMPC_E_ARG, "lpvmpc_set_option: unknown option '%s'", name);
 }

@@ -127,6 +127,38 @@ __device__ inline void red_i2(double &a, double &b) {
     a = xor32_sum(a); b = xor32_sum(b);
 #endif
 }
+// ---- matrix-core primitives (v_mfma_f64_4x4x4_4b_f64, layouts measured on gfx950 by tools/microbench/mfma_f64_probe.hip) ----
+// Four independent 4x4x4 products per instruction; with r = lane >> 4, b = (lane >> 2) & 3, c = lane & 3:
+//   A[b][i][k] sits in lane (r = k, b, c = i),  B[b][k][j] in lane (r = k, b, c = j),  D[b][i][j] in lane (r = i, b, c = j).
+// A stage vector v[0..7] lives in "V layout": lane (r, b, c) holds v[4 (b & 1) + r] -- replicated over c and over b >> 1 --
+// so it is at once a B operand (every column j carries the vector) and, coming out as D, the next step's operand.
+__device__ inline double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+template <int CTRL, int BANK>
+__device__ inline double dpp_into(double old, double src) {          // src moved by CTRL into the quads of BANK, other quads keep old
+    int ol = __double2loint(old), oh = __double2hiint(old);
+    const int sl = __double2loint(src), sh = __double2hiint(src);
+    ol = __builtin_amdgcn_update_dpp(ol, sl, CTRL, 0xF, BANK, false);
+    oh = __builtin_amdgcn_update_dpp(oh, sh, CTRL, 0xF, BANK, false);
+    return __hiloint2double(oh, ol);
+}
+// lane ^ 4: swaps the two halves of a V-layout vector (row_shl:4 into quads 0, 2; row_shr:4 into quads 1, 3)
+__device__ inline double swap_half(double v) {
+#ifdef LPVMPC_USE_SHFL
+    return __shfl(v, (threadIdx.x & 63) ^ 4);
+#else
+    double any;                                      // every quad is written by one of the two moves: the start value is irrelevant
+    asm volatile("" : "=v"(any));
+    return dpp_into<0x114, 0xA>(dpp_into<0x104, 0x5>(any, v), v);
+#endif
+}
+// quads 2, 3 <- quads 0, 1 (lane & ~8): re-replicates the chain result over the second block pair
+__device__ inline double dup01(double v) {
+#ifdef LPVMPC_USE_SHFL
+    return __shfl(v, (threadIdx.x & 63) & ~8);
+#else
+    return dpp_into<0x128, 0xC>(v, v);
+#endif
+}
 __device__ inline double limit_scaling(double v) {
     v = v < kMinScaling ? 1.0 : v;
     return v > kMaxScaling ? kMaxScaling : v;

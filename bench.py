@@ -57,6 +57,8 @@ def main():
                          "planner, N=20; cfg5 = configs[4]: planner + controller + plant cascade, a step is one 30 Hz "
                          "controller tick of --batch vehicles per GPU (default 8192 / gpus) -- extra measurements, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-variant", type=int, default=0,
+                    help="diagnostic: lpvmpc_set_option(kernel_variant) on every engine (0 = default; 3 = the DPP two-wavefront kernel)")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise the launcher, the sharding and the collectives with the gloo backend and no device work "
                          "(CPU test of the N > 1 path; the printed line carries \"dry_run\": true and no measurement)")
@@ -112,6 +114,8 @@ def main():
     # one engine (workspace + output buffers) per stream: steps issued on different streams are independent
     S = max(1, args.streams)
     engines = [eng] + [workloads.make_solver(w, device=local_rank) for _ in range(S - 1)]
+    for e in engines:
+        e.set_option("kernel_variant", args.kernel_variant)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     outs = []
     for e in engines:
