@@ -21,6 +21,8 @@
 // LDS per instance (doubles): scaled [A|B] tiles [NS][72] and 19 vectors [NS][8] (NS = N+1, everything
 // padded to 8 per stage so that index = 8*stage + component): 37.7 KB at N = 20, i.e. 4 instances per
 // CU (one wavefront per SIMD), which is exactly BASELINE configs[1] (1024 instances) in one residency.
+#include <atomic>
+
 #include "lpvmpc_device.hpp"
 #include "wave_ops.hpp"
 
@@ -1461,11 +1463,17 @@ __global__ void __launch_bounds__(64 * NW, (min_waves_per_simd<NT, NW>())) admm_
 template <int NX, int NT, int NW, bool MF = false>
 static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream) {
     const size_t lds = Solver<NX, NT, NW, MF>::lds_doubles(cfg.N) * sizeof(double);
-    static bool attr_set = false;      // per instantiation; the attribute is per function, set once
-    if (!attr_set) {
+    // The LDS opt-in is a per-function AND per-device attribute: remember it per (instantiation, device ordinal).  Handles on
+    // different devices may launch from different threads (lpvmpc.h: thread-safe across handles), hence the atomic mask.
+    static std::atomic<uint64_t> attr_mask[4];           // 256 device ordinals
+    int dev = 0;
+    { hipError_t err = hipGetDevice(&dev); if (err != hipSuccess) return err; }
+    const uint64_t bit = 1ull << (dev & 63);
+    std::atomic<uint64_t> &word = attr_mask[(dev >> 6) & 3];
+    if (!(word.load(std::memory_order_acquire) & bit)) {
         hipError_t err = hipFuncSetAttribute((const void *)admm_solve_kernel<NX, NT, NW, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (err != hipSuccess) return err;
-        attr_set = true;
+        word.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL((admm_solve_kernel<NX, NT, NW, MF>), dim3(a.B), dim3(64 * NW), lds, stream, dcfg, a);
     return hipGetLastError();

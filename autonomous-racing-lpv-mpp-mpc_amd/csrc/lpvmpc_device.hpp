@@ -24,18 +24,27 @@ struct DevCfg {
     double track[kMaxSeg * 6];
 };
 
-// Piecewise-constant curvature lookup, reference UTIL:31-50 (Curvature).  Same comparisons
-// (s >= start && s < start + len) in float64.  Where the reference raises (no segment contains s:
-// s < 0 or s on a zero-length closing segment) this returns the first / last segment's curvature.
+// Piecewise-constant curvature lookup, reference UTIL:31-50 (Curvature).  Same wrap (repeated subtraction of the track
+// length, UTIL:36-40) and the same comparisons (s >= start && s < start + len) in float64.  Where the reference raises
+// (UTIL:44-48 finds no segment: s < 0, s exactly on the end of the closing segment) or would spin (s not finite, or more than
+// kMaxWrapLaps track lengths ahead: a diverged roll-out) the lookup returns NaN: the NaN travels through the LPV blocks into
+// the solve kernel, which runs no iteration on non-finite data and reports LPVMPC_UNSOLVED with NaN outputs -- the caller
+// sees the failure instead of a silently substituted segment.
+constexpr int kMaxWrapLaps = 4096;
+__device__ inline double wrap_track_s(double s, double L) {
+    if (!(s <= L * (double)kMaxWrapLaps)) return __builtin_nan("");     // also catches NaN and +Inf
+    for (int it = 0; it < kMaxWrapLaps && s > L; ++it) s -= L;
+    return s;
+}
 __device__ inline double track_curvature(const DevCfg &c, double s) {
     const int rows = c.track_rows;
     const double L = c.track[(rows - 1) * 6 + 3] + c.track[(rows - 1) * 6 + 4];
-    for (int it = 0; it < 1000000 && s > L; ++it) s -= L;
+    s = wrap_track_s(s, L);
     for (int i = 0; i < rows; ++i) {
         const double st = c.track[i * 6 + 3], ln = c.track[i * 6 + 4];
         if (s >= st && s < st + ln) return c.track[i * 6 + 5];
     }
-    return s < 0.0 ? c.track[5] : c.track[(rows - 1) * 6 + 5];
+    return __builtin_nan("");
 }
 
 // arguments of the solve kernel (device pointers)

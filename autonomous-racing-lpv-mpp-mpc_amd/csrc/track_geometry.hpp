@@ -86,7 +86,7 @@ __device__ inline void global_position(const DevCfg &c, double s, double ey, dou
     const double *T = c.track;
     const int rows = c.track_rows;
     const double L = T[(rows - 1) * 6 + 3] + T[(rows - 1) * 6 + 4];
-    for (int it = 0; it < 1000000 && s > L; ++it) s -= L;
+    s = wrap_track_s(s, L);      // NaN beyond kMaxWrapLaps laps / non-finite s: no segment below, NaNs returned
     int i = -1;
     for (int k = 0; k < rows; ++k) if (s >= T[k * 6 + 3] && s < T[k * 6 + 3] + T[k * 6 + 4]) { i = k; break; }
     if (i < 0) { x = y = th = __builtin_nan(""); return; }
