@@ -60,12 +60,12 @@ struct Solver {
     double *tS, *tL, *tA;
     double rS[kRS], rL[kRS];
     double rSm, rLt, rLb;    // NW == 2: pivot inverse of the middle stage and its two link tiles (wave 0; rLb also wave 1)
-    // MFMA sweeps: operand tiles in A layout, one "diagonal" and one "off-diagonal" register per chain step (each holds four
-    // 4x4 blocks: blocks 0, 1 = the two row halves of the chain tile, blocks 2, 3 = the row halves of a second, independent
-    // tile that multiplies the same vector).  Forward step p: {-L_p | S_{p-1}^-1}; backward step p: {-L_{p+1}' | [A|B] of the
-    // operand stage}; mid: S_m^-1 in all four blocks; tail (wave 0): {0 | [A|B]_0}.
-    double fD[kMP], fO[kMP], bD[kMP], bO[kMP], mD, mO, tD, tO;
-    int mr, mh, mw, mj, gD, gO, gDT, gOT;   // lane coordinates in the MFMA layouts and gather offsets into a row-major 8x8 tile
+    // MFMA sweeps: one A-operand register per 8x8 tile and chain step (all four 4x4 blocks of the instruction carry the
+    // tile, see mf_forward): fC / bC = the chain tiles (-L_p on the way up, -L_{p+1}' on the way down), fV = the pivot
+    // inverse S_{p-1}^-1 and bA = [A|B] of the operand stage (second, independent product of the same step); mS = S_m^-1,
+    // tT = [A|B]_0 (wave 0's last product).
+    double fC[kMP], fV[kMP], bC[kMP], bA[kMP], mS, tT;
+    int gA, gB;                             // gather offsets into a row-major 8x8 tile for the two step types (see mf_forward)
     int li, lj, tlane;                      // "D form" of an 8x8 matrix (see mm8): row / column held by this lane, lane of the transposed element
     // variable-space vectors
     double *X, *Qv, *D, *XT, *DX, *VT, *AT;
@@ -102,12 +102,12 @@ struct Solver {
         r2 = (kCtrl && tj == 6) ? 6 : 7;
         bvar = box_var(tj); rmask = tj < NX ? 1.0 : 0.0;
         c = 1.0; cinv = 1.0; pol = false; rho = rho_eq = rinv = rinv_eq = 0.0; rSm = rLt = rLb = 0.0;
-        mr = lane >> 4; mh = (lane >> 2) & 1; mw = (lane >> 3) & 1; mj = lane & 3;
-        gD = (4 * mh + mj) * 8 + 4 * mh + mr;            // A[i = mj][k = mr] = T[4h + i][4h + k]
-        gO = (4 * mh + mj) * 8 + 4 * (1 - mh) + mr;      //                    T[4h + i][4h' + k]
-        gDT = (4 * mh + mr) * 8 + 4 * mh + mj;           // the same of T'
-        gOT = (4 * (1 - mh) + mr) * 8 + 4 * mh + mj;
-        mD = mO = tD = tO = 0.0;
+        {   // lane (r, b = 2I + J, c) of an A operand: type A step T[4J + c][4I + r], type B step T[4I + c][4J + r]
+            const int r_ = lane >> 4, I_ = (lane >> 3) & 1, J_ = (lane >> 2) & 1, c_ = lane & 3;
+            gA = (4 * J_ + c_) * 8 + 4 * I_ + r_;
+            gB = (4 * I_ + c_) * 8 + 4 * J_ + r_;
+        }
+        mS = tT = 0.0;
         li = 4 * ((lane >> 3) & 1) + (lane >> 4); lj = lane & 7;
         tlane = 8 * dgroup(lj) + li;
     }
@@ -501,18 +501,15 @@ struct Solver {
 #undef LPVMPC_CHOL_STEP_D
         return w;
     }
-    // operand registers of the MFMA sweeps from D forms: x = D form of the TRANSPOSE of the chain tile (blocks 0, 1 of the pair),
-    // s2 = D form of the transpose of the second tile (blocks 2, 3).  Diagonal register: quads (x0, x3, s0, s3); off-diagonal
-    // register: quads (x2, x1, s2, s1)  (quad q = block (I, J) = (q >> 1, q & 1) of the D form).
-    struct MfPair { double d, o; };
-    __device__ __forceinline__ static MfPair sweep_pair(double x, double s2) {
-        double d = dpp_into<0x108, 0x2>(x, x);          // quad 1 <- x quad 3
-        d = dpp_into<0x118, 0x4>(d, s2);                // quad 2 <- s2 quad 0
-        d = dpp_into<0xE4, 0x8>(d, s2);                 // quad 3 <- s2 quad 3
-        double o = dpp_into<0x108, 0x1>(x, x);          // quad 0 <- x quad 2
-        o = dpp_into<0xE4, 0x4>(o, s2);                 // quad 2 <- s2 quad 2
-        o = dpp_into<0x118, 0x8>(o, s2);                // quad 3 <- s2 quad 1
-        return MfPair{d, o};
+    // D form with the two off-diagonal 4x4 blocks exchanged (quads 1 <-> 2 of every 16-lane row): turns the A operand of a
+    // type A sweep step into the one of a type B step (see mf_forward)
+    __device__ __forceinline__ static double qswap(double v) {
+#ifdef LPVMPC_USE_SHFL
+        const int l = threadIdx.x & 63, q = (l >> 2) & 3;
+        return __shfl(v, (q == 1 || q == 2) ? (l ^ 12) : l);
+#else
+        return dpp_into<0x114, 0x4>(dpp_into<0x104, 0x2>(v, v), v);     // row_shl:4 into quad 1, row_shr:4 into quad 2
+#endif
     }
     // diagonal block K_kk in D form; WDv / WBv: row weights of the dynamics / box rows (filled by factor())
     __device__ __forceinline__ double kd_d(int k, double sig, const double *WDv, const double *WBv) const {
@@ -577,11 +574,14 @@ struct Solver {
                     sk = mm8(-gt, gt, kd);                         // S = Kd - G G'
                     const double ltn = -mm8(wd, gt, 0.0);          // -L' = -W' G'
                     const double ln = -mm8(gt, wd, 0.0);           // -L  = -G W
-                    // forward step p: {-L_p | S_{p-1}^-1}; backward step p - 1: {-L_p' | [A|B] of the operand stage k}
-                    const MfPair f = sweep_pair(ltn, sinv), b = sweep_pair(ln, ln);
-                    const double b0 = mw ? ab_entry(k, gD) : b.d, b1 = mw ? ab_entry(k, gO) : b.o;
+                    // forward step p consumes y_{p-1} (layout A for odd p): tiles -L_p and S_{p-1}^-1; backward step p - 1
+                    // consumes x at chain position p (layout B when P - p is even): tiles -L_p' and [A|B] of stage k.
+                    // A type A operand is the D form of the tile's transpose, a type B operand the same with quads 1, 2 swapped.
+                    const bool fa = (p & 1) != 0, bb = ((P - p) & 1) == 0;
+                    const double fc = fa ? ltn : qswap(ltn), fv = fa ? sinv : qswap(sinv);
+                    const double bc = bb ? qswap(ln) : ln, ba = ab_entry(k, bb ? gB : gA);
 #pragma unroll
-                    for (int pp = 0; pp < kMP; ++pp) if (pp == p - 1) { fD[pp] = f.d; fO[pp] = f.o; bD[pp] = b0; bO[pp] = b1; }
+                    for (int pp = 0; pp < kMP; ++pp) if (pp == p - 1) { fC[pp] = fc; fV[pp] = fv; bC[pp] = bc; bA[pp] = ba; }
                 }
                 STAMP(5);
                 wd = chol_inverse_d(sk);
@@ -608,12 +608,13 @@ struct Solver {
             }
             sync();
             if (wv == 1) { ltn = PUB[128 + lane]; ln = PUB[192 + lane]; sm = PUB[256 + lane]; }
-            {
-                const MfPair f = sweep_pair(ltn, sinv), b = sweep_pair(ln, ln), m = sweep_pair(sm, sm);
-                fD[P - 1] = f.d; fO[P - 1] = f.o;
-                bD[P - 1] = mw ? ab_entry(kMid, gD) : b.d; bO[P - 1] = mw ? ab_entry(kMid, gO) : b.o;
-                mD = m.d; mO = m.o;
-                tD = mw ? ab_entry(0, gD) : 0.0; tO = mw ? ab_entry(0, gO) : 0.0;
+            {   // link to the middle stage (forward step P, backward step P - 1: its operand x_m is in layout B), the middle
+                // pivot (type A) and wave 0's closing product [A|B]_0 x_0 (x_0 leaves the last backward step in layout B iff P is even)
+                constexpr bool fa = (P & 1) != 0, tb = (P & 1) == 0;
+                fC[P - 1] = fa ? ltn : qswap(ltn); fV[P - 1] = fa ? sinv : qswap(sinv);
+                bC[P - 1] = qswap(ln); bA[P - 1] = ab_entry(kMid, gB);
+                mS = sm;
+                tT = ab_entry(0, tb ? gB : gA);
             }
             sync();
             return;
@@ -768,83 +769,124 @@ struct Solver {
     }
 
     // ---- the two sweeps on the matrix cores -------------------------------------------------------------------------
-    // One v_mfma_f64_4x4x4_4b_f64 pair per chain step: blocks 0, 1 advance the chain (y_p = b_p - L_p y_{p-1}, or
-    // x_p = v_p - L_{p+1}' x_{p+1}), blocks 2, 3 multiply the same operand by a second tile -- the pivot product
-    // v_{p-1} = S_{p-1}^-1 y_{p-1} on the way up, the dynamics-row product [A|B]_k x_k (the z~ = A x~ of the ADMM update)
-    // on the way down.  The chain value comes out in the layout the next step reads it in; per step only the block-pair
-    // replication (2 DPP moves) and the half swap for the off-diagonal blocks (4 DPP moves, off the chain) are vector work.
+    // v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4x4 blocks; lane = 16 r + 4 b + c.  A stage vector v[0..7] is kept
+    // replicated over c in one of two layouts:  layout A: lane (r, b, c) holds v[4 (b >> 1) + r],  layout B: v[4 (b & 1) + r].
+    // With the tile T cut into 4x4 blocks T_IJ, a "type A" step (operand in layout A) gives the blocks (T00, T10, T01, T11) to
+    // b = 0..3: b and b ^ 2 then hold the two halves of one dot product, one row_ror:8 move and one add complete it, and the
+    // result stands in layout B.  A "type B" step (operand in layout B) uses (T00, T01, T10, T11), completes with
+    // row_half_mirror (b ^ 1; the values are uniform over c) and delivers layout A.  So one chain step
+    //     y_p = b_p - L_p y_{p-1}      or      x_p = v_p - L_{p+1}' x_{p+1}
+    // is ONE MFMA, two DPP moves and one add on the dependent path (~50 cycles measured, against ~150 for the two-MFMA step
+    // with half swaps it replaces); the right-hand side enters as the C operand of the block that owns the result.  A second,
+    // independent MFMA per step multiplies the same operand by another tile: the pivot product v_{p-1} = S_{p-1}^-1 y_{p-1}
+    // on the way up, the dynamics-row product [A|B]_k x_k (z~ = A x~ of the ADMM update) on the way down.
+    struct MfLane {
+        int ln, eA, eB;         // lane (opaque to the optimiser), element held in layout A / B
+        bool stA, stB;          // this lane stores / carries the C operand of a result in layout A / B (one lane per element)
+    };
+    __device__ __forceinline__ MfLane mf_lane() const {
+        MfLane m;
+        m.ln = opaque(lane);
+        const int r = m.ln >> 4, b = (m.ln >> 2) & 3;
+        m.eA = 4 * (b >> 1) + r; m.eB = 4 * (b & 1) + r;
+        m.stA = (b & 1) == 0; m.stB = b < 2;
+        return m;
+    }
+    template <bool TYPE_A>
+    __device__ __forceinline__ static double mf_close(double d) { return d + dpp_mov<TYPE_A ? 0x128 : 0x141>(d); }
     template <bool BOT>
     __device__ __forceinline__ void mf_forward() {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
-        const int ln = opaque(lane), elem = ((ln >> 2) & 1) * 4 + (ln >> 4);
-        const bool second = (ln >> 3) & 1, col0 = (ln & 3) == 0;          // blocks 2, 3; column j = 0 of a block (the lanes that store)
-        const double *const bsrc = XT + elem;
-        double *const vst = (col0 && second) ? VT + elem : SINK + ln;
-        if (!BOT && ln < 8) RED[48 + ln] = XT[kMid * 8 + ln];             // the middle right-hand side survives x_m (see twisted_forward)
-        double Y = bsrc[stage(0) * 8], Dlate = 0.0;
+        const MfLane m = mf_lane();
+        const bool c0 = (m.ln & 3) == 0;
+        if (!BOT && m.ln < 8) RED[48 + m.ln] = XT[kMid * 8 + m.ln];        // the middle right-hand side survives x_m (see twisted_forward)
+        // a type A step delivers layout B: right-hand side element eB in the blocks stB, results stored by the lanes c = 0 of them
+        const double *const csA = XT + m.eB, *const csB = XT + m.eA;
+        double *const vsA = (c0 && m.stB) ? VT + m.eB : SINK + m.ln;
+        double *const vsB = (c0 && m.stA) ? VT + m.eA : SINK + m.ln;
+        double Y = XT[stage(0) * 8 + m.eA];
         double bq[3];                                                       // right-hand sides are fetched two steps ahead
-        bq[1] = bsrc[stage(1) * 8];
-        bq[2] = (P > 2) ? bsrc[stage(2) * 8] : 0.0;
+        bq[1] = csA[stage(1) * 8];
+        bq[2] = (P > 2) ? csB[stage(2) * 8] : 0.0;
+        double dvl = 0.0;                                                   // pivot product of the previous step, not yet closed
 #pragma unroll
         for (int p = 1; p < P; ++p) {
             const double bl = bq[p % 3];
-            if (p + 2 < P) bq[(p + 2) % 3] = bsrc[stage(p + 2) * 8];
+            if (p + 2 < P) bq[(p + 2) % 3] = ((p + 2) & 1) ? csA[stage(p + 2) * 8] : csB[stage(p + 2) * 8];
             __builtin_amdgcn_sched_barrier(0);          // keep the fetch up here: sunk to its use, every step waits for LDS
-            const double bp = second ? 0.0 : bl;
-            const double Ysw = swap_half(Y);
-            const double t = mfma4(fD[p - 1], Y, bp);
-            // the previous step's pivot product v_{p-2} (blocks 2, 3) is stored here, in the shadow of this step's first
-            // MFMA: a store of a fresh MFMA result sits ~45 cycles of result latency in front of the chain's next move
-            if (p >= 2) vst[stage(p - 2) * 8] = Dlate;
-            __builtin_amdgcn_sched_barrier(0);
-            const double D = mfma4(fO[p - 1], Ysw, t);
-            Dlate = D;
-            Y = dup01(D);
+            // the previous step's pivot product is closed and stored in the shadow of this step's MFMAs
+            if (p & 1) {
+                const double dc = mfma4(fC[p - 1], Y, m.stB ? bl : 0.0), dv = mfma4(fV[p - 1], Y, 0.0);
+                if (p >= 2) vsB[stage(p - 2) * 8] = mf_close<false>(dvl);
+                Y = mf_close<true>(dc);
+                dvl = dv;
+            } else {
+                const double dc = mfma4(fC[p - 1], Y, m.stA ? bl : 0.0), dv = mfma4(fV[p - 1], Y, 0.0);
+                vsA[stage(p - 2) * 8] = mf_close<true>(dvl);
+                Y = mf_close<false>(dc);
+                dvl = dv;
+            }
         }
-        if (P >= 2) vst[stage(P - 2) * 8] = Dlate;
+        if (P >= 2) { if ((P - 1) & 1) vsA[stage(P - 2) * 8] = mf_close<true>(dvl); else vsB[stage(P - 2) * 8] = mf_close<false>(dvl); }
         // last chain stage: its pivot product and this chain's contribution -L_link y_last to the middle right-hand side
-        double *const cst = col0 ? (second ? VT + stage(P - 1) * 8 + elem : RED + 32 + (BOT ? 8 : 0) + elem) : SINK + ln;
-        const double Ysw = swap_half(Y);
-        *cst = mfma4(fO[P - 1], Ysw, mfma4(fD[P - 1], Y, 0.0));
+        constexpr bool la = (P & 1) != 0;
+        const double dl = mfma4(fC[P - 1], Y, 0.0), dv = mfma4(fV[P - 1], Y, 0.0);
+        (la ? vsA : vsB)[stage(P - 1) * 8] = mf_close<la>(dv);
+        double *const cst = (c0 && (la ? m.stB : m.stA)) ? RED + 32 + (BOT ? 8 : 0) + (la ? m.eB : m.eA) : SINK + m.ln;
+        *cst = mf_close<la>(dl);
     }
     template <bool BOT>
     __device__ __forceinline__ void mf_backward() {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
-        const int ln = opaque(lane), elem = ((ln >> 2) & 1) * 4 + (ln >> 4);
-        const bool second = (ln >> 3) & 1, col0 = (ln & 3) == 0;
-        const double *const vsrc = VT + elem;
-        double Dlate = 0.0;
+        const MfLane m = mf_lane();
+        const bool c0 = (m.ln & 3) == 0;
+        // backward step p consumes x at chain position p + 1; x_m arrives in layout B, so step p is of type B iff P - 1 - p is even
+        const double *const vsA = VT + m.eB, *const vsB = VT + m.eA;         // v_p enters as C of the owner blocks of the OUTPUT layout
+        double *const xsA = (c0 && m.stB) ? XT + m.eB : SINK + m.ln;         // results of a type A step (layout B)
+        double *const xsB = (c0 && m.stA) ? XT + m.eA : SINK + m.ln;
+        double *const asA = (c0 && m.stB) ? AT + (BOT ? 0 : 16) + m.eB : SINK + m.ln;   // [A|B]_k x_k, filed under the dynamics rows of stage k + 1
+        double *const asB = (c0 && m.stA) ? AT + (BOT ? 0 : 16) + m.eA : SINK + m.ln;
+        auto typeB = [](int p) constexpr { return ((P - 1 - p) & 1) == 0; };
         double vq[3];                                                       // pivot products are fetched two steps ahead
-        vq[(P - 1) % 3] = vsrc[stage(P - 1) * 8];
-        if (P >= 2) vq[(P - 2) % 3] = vsrc[stage(P - 2) * 8];
-        const double ym = RED[48 + elem] + (RED[32 + elem] + RED[40 + elem]);
-        double X = mfma4(mO, swap_half(ym), mfma4(mD, ym, 0.0));        // x_m, identical in all four blocks and on both waves
-        *((!BOT && col0 && !second) ? XT + kMid * 8 + elem : SINK + ln) = X;
-        // blocks 0, 1 -> x_p; blocks 2, 3 -> [A|B]_k x_k of the operand stage k, filed under the dynamics rows of stage k + 1
-        double *const xonly = (col0 && !second) ? XT + elem : SINK + ln;
-        double *const xst = col0 ? (second ? AT + (BOT ? 0 : 16) + elem : XT + elem) : SINK + ln;
+        vq[(P - 1) % 3] = vsB[stage(P - 1) * 8];
+        if (P >= 2) vq[(P - 2) % 3] = vsA[stage(P - 2) * 8];
+        // middle stage, on both waves: x_m = S_m^-1 (b_m - L_t y_{m-1} - L_b y_{m+1}); type A step, x_m in layout B
+        const double ym = RED[48 + m.eA] + (RED[32 + m.eA] + RED[40 + m.eA]);
+        double X = mf_close<true>(mfma4(mS, ym, 0.0));
+        *((!BOT && c0 && m.stB) ? XT + kMid * 8 + m.eB : SINK + m.ln) = X;
+        double dal = 0.0;                                                   // dynamics-row product of the previous step, not yet closed
 #pragma unroll
         for (int p = P - 1; p >= 0; --p) {
             const double vl = vq[p % 3];
-            if (p - 2 >= 0) vq[(p - 2) % 3] = vsrc[stage(p - 2) * 8];
+            if (p - 2 >= 0) vq[(p - 2) % 3] = typeB(p - 2) ? vsB[stage(p - 2) * 8] : vsA[stage(p - 2) * 8];
             __builtin_amdgcn_sched_barrier(0);
-            const double vp = second ? 0.0 : vl;
-            const double Xsw = swap_half(X);
-            const double t = mfma4(bD[p], X, vp);
-            // the previous step's results are stored in the shadow of this step's first MFMA (see mf_forward); both waves'
-            // first step multiplies [A|B]_kMid x_m: wave 1 files it, wave 0 drops it
-            if (p <= P - 2) ((!BOT && p == P - 2) ? xonly : xst)[stage(p + 1) * 8] = Dlate;
-            __builtin_amdgcn_sched_barrier(0);
-            const double D = mfma4(bO[p], Xsw, t);
-            Dlate = D;
-            X = dup01(D);
+            // the previous step's [A|B] product is closed and filed in the shadow of this step's MFMAs; both waves' first
+            // step multiplies [A|B]_kMid x_m: wave 1 files it, wave 0 drops it
+            const bool keep = BOT || p + 1 != P - 1;
+            if (typeB(p)) {
+                const double dc = mfma4(bC[p], X, m.stA ? vl : 0.0), da = mfma4(bA[p], X, 0.0);
+                if (p <= P - 2) (keep ? asA : SINK + m.ln)[keep ? stage(p + 1) * 8 : 0] = mf_close<true>(dal);
+                X = mf_close<false>(dc);
+                xsB[stage(p) * 8] = X;
+                dal = da;
+            } else {
+                const double dc = mfma4(bC[p], X, m.stB ? vl : 0.0), da = mfma4(bA[p], X, 0.0);
+                if (p <= P - 2) (keep ? asB : SINK + m.ln)[keep ? stage(p + 1) * 8 : 0] = mf_close<false>(dal);
+                X = mf_close<true>(dc);
+                xsA[stage(p) * 8] = X;
+                dal = da;
+            }
         }
-        ((!BOT && P == 1) ? xonly : xst)[stage(0) * 8] = Dlate;
-        if (!BOT) {     // [A|B]_0 x_0 -> dynamics rows of stage 1
-            const double Xsw = swap_half(X);
-            *((col0 && second) ? AT + 8 + elem : SINK + ln) = mfma4(tO, Xsw, mfma4(tD, X, 0.0));
+        {   // product of step 0 (type B iff P - 1 is even)
+            constexpr bool keep = BOT || 0 != P - 1;
+            if (typeB(0)) (keep ? asB : SINK + m.ln)[keep ? stage(0) * 8 : 0] = mf_close<false>(dal);
+            else          (keep ? asA : SINK + m.ln)[keep ? stage(0) * 8 : 0] = mf_close<true>(dal);
+        }
+        if (!BOT) {     // [A|B]_0 x_0 -> dynamics rows of stage 1; x_0 is in layout B iff P is even
+            constexpr bool tb = (P & 1) == 0;
+            *((c0 && (tb ? m.stA : m.stB)) ? AT + 8 + (tb ? m.eA : m.eB) : SINK + m.ln) = mf_close<!tb>(mfma4(tT, X, 0.0));
         }
     }
 

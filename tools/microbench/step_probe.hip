@@ -55,6 +55,22 @@ __global__ void k(double *out, unsigned long long *cyc, int reps) {
                 dst[p * 64] = Dl;
                 __builtin_amdgcn_sched_barrier(0);
                 Y = mfma4(a1, Ysw, t); Dl = Y;
+            } else if (MODE == 10) {    // four-block chain: one MFMA + cross-block add (row_ror:8), C from LDS
+                const double bl = src[p * 8]; const double bp = second ? 0.0 : bl;
+                const double D = mfma4(a0, Y, bp);
+                Y = D + dpp_mov<0x128>(D);
+            } else if (MODE == 11) {    // four-block chain, alternating row_ror:8 / row_half_mirror, + independent pivot MFMA, add and store
+                const double bl = src[p * 8]; const double bp = second ? 0.0 : bl;
+                const double D = mfma4(a0, Y, bp);
+                const double V = mfma4(a1, Y, 0.0);
+                if (p & 1) { Y = D + dpp_mov<0x141>(D); dst[p * 64] = V + dpp_mov<0x141>(V); }
+                else       { Y = D + dpp_mov<0x128>(D); dst[p * 64] = V + dpp_mov<0x128>(V); }
+            } else if (MODE == 12) {    // as 11, the pivot product's add and store delayed by one step
+                const double bl = src[p * 8]; const double bp = second ? 0.0 : bl;
+                const double D = mfma4(a0, Y, bp);
+                if (p & 1) dst[p * 64] = Dl + dpp_mov<0x128>(Dl); else dst[p * 64] = Dl + dpp_mov<0x141>(Dl);
+                Dl = mfma4(a1, Y, 0.0);
+                if (p & 1) Y = D + dpp_mov<0x141>(D); else Y = D + dpp_mov<0x128>(D);
             } else if (MODE == 7) {     // split accumulation: two independent MFMAs + f64 add
                 const double bl = src[p * 8];
                 const double Ysw = swap_half(Y); const double t = mfma4(a0, Y, bl); const double u = mfma4(a1, Ysw, 0.0);
@@ -91,5 +107,8 @@ int main() {
     run<7>("two independent MFMAs + f64 add", dout, dcyc);
     run<8>("as built, store delayed one step", dout, dcyc);
     run<9>("natural layout, store delayed one step", dout, dcyc);
+    run<10>("four-block chain: 1 MFMA + ror8 add, C from LDS", dout, dcyc);
+    run<11>("four-block chain + pivot MFMA + add + store", dout, dcyc);
+    run<12>("four-block chain + pivot MFMA, its add/store one step late", dout, dcyc);
     return 0;
 }
