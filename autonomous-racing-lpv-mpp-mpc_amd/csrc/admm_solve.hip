@@ -81,9 +81,20 @@ struct Solver {
     // row weights: ADMM rho classes (OSQP set_rho_vec) or, while polishing, |flag| = 1/delta on active rows
     bool pol;
     double rho, rho_eq, rinv, rinv_eq;
-    // per-lane constants of the compact layout (component = lane & 7 in every 64-element round)
-    int r0, r1, r2, bvar; // box rows acting on variable tj (7 = none, its coefficient is 0; r2 = the delay row on delta); variable of box row tj
-    double rmask;         // 1 if tj is a real dynamics row
+    // per-lane constants of the compact layout (component = lane & 7 in every 64-element round): recomputed from the lane
+    // number where they are used (a handful of integer instructions) instead of living in registers for the whole solve
+    struct LaneC {
+        int r0, r1, r2, bvar; // box rows acting on variable tj (7 = none, its coefficient is 0; r2 = the delay row on delta); variable of box row tj
+        double rmask;         // 1 if tj is a real dynamics row
+    };
+    int lpack;                // r0 | r1 << 4 | r2 << 8 | bvar << 12 | (tj < NX) << 16: one register for the whole solve, unpacked where used
+    __device__ __forceinline__ LaneC lane_consts() const {
+        LaneC l;
+        const int lp = opaque(lpack);          // unpacked here, not hoisted into five live registers
+        l.r0 = lp & 15; l.r1 = (lp >> 4) & 15; l.r2 = (lp >> 8) & 15; l.bvar = (lp >> 12) & 15;
+        l.rmask = (lp >> 16) ? 1.0 : 0.0;
+        return l;
+    }
 
     __device__ __forceinline__ Solver(const DevCfg &cf, double *smem)
         : cfg(cf), N(kReg ? NT : cf.N), NS((kReg ? NT : cf.N) + 1), tid(threadIdx.x), wv(threadIdx.x >> 6), lane(threadIdx.x & 63),
@@ -98,9 +109,11 @@ struct Solver {
         Zb = p; p += V; Yb = p; p += V; Eb = p; p += V; ZTb = p; p += V; DYb = p; p += V;
         Lo = p; p += V; Hi = p; p += V;
         beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; RED = p; p += 80; SINK = p; p += 64 + 8 * NS;
-        { int first, cnt; rows_on(tj, first, cnt); r0 = cnt >= 1 ? first : 7; r1 = cnt >= 2 ? first + 1 : 7; }
-        r2 = (kCtrl && tj == 6) ? 6 : 7;
-        bvar = box_var(tj); rmask = tj < NX ? 1.0 : 0.0;
+        {
+            int first, cnt; rows_on(tj, first, cnt);
+            const int r0 = cnt >= 1 ? first : 7, r1 = cnt >= 2 ? first + 1 : 7, r2 = (kCtrl && tj == 6) ? 6 : 7;
+            lpack = r0 | (r1 << 4) | (r2 << 8) | (box_var(tj) << 12) | ((tj < NX ? 1 : 0) << 16);
+        }
         c = 1.0; cinv = 1.0; pol = false; rho = rho_eq = rinv = rinv_eq = 0.0; rSm = rLt = rLb = 0.0;
         {   // lane (r, b = 2I + J, c) of an A operand: type A step T[4J + c][4I + r], type B step T[4I + c][4J + r]
             const int r_ = lane >> 4, I_ = (lane >> 3) & 1, J_ = (lane >> 2) & 1, c_ = lane & 3;
@@ -193,7 +206,7 @@ struct Solver {
     __device__ __forceinline__ double &Eid(int k, int r) const { return tA[k * kTS + 48 + r]; }
     __device__ __forceinline__ double &Sb(int k, int r) const { return tA[k * kTS + 56 + r]; }
     __device__ __forceinline__ void cache_row_coefficients() {
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             const int k = e >> 3, r = e & 7;
             Eid(k, r) = r < NX ? Ed[e] * D[e] : 0.0;
             Sb(k, r) = r < nbox(k) ? box_sign(r) * Eb[e] * D[k * 8 + box_var(r)] : 0.0;
@@ -212,30 +225,32 @@ struct Solver {
     }
     // (dstD, dstB) = A * src
     __device__ __forceinline__ void A_mul(const double *src, double *dstD, double *dstB) const {
-        for (int e = tid; e < NS * 8; e += kStride) {
+        const LaneC lc = lane_consts();
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             const int k = e >> 3;
-            dstD[e] = rmask * (Eid(k, tj) * src[e] - prev_stage_dot(k, src));
-            dstB[e] = Sb(k, tj) * src[k * 8 + bvar];
+            dstD[e] = lc.rmask * (Eid(k, tj) * src[e] - prev_stage_dot(k, src));
+            dstB[e] = Sb(k, tj) * src[k * 8 + lc.bvar];
         }
     }
     // value of (A' (srcD, srcB))[e]
-    __device__ __forceinline__ double At_elem(int e, const double *srcD, const double *srcB) const {
+    __device__ __forceinline__ double At_elem(int e, const double *srcD, const double *srcB, const LaneC &lc) const {
         const int k = e >> 3, kn = k < N ? k + 1 : N;         // the stage-N tile is all zero
         const double *col = tA + k * kTS + tj, *sd = srcD + kn * 8;
         double c_[NX], d_[NX];
 #pragma unroll
         for (int r = 0; r < NX; ++r) { c_[r] = col[r * 8]; d_[r] = sd[r]; }
-        const double sb0 = Sb(k, r0), sb1 = Sb(k, r1), w0 = srcB[k * 8 + r0], w1 = srcB[k * 8 + r1], ei = Eid(k, tj), wd = srcD[e];
+        const double sb0 = Sb(k, lc.r0), sb1 = Sb(k, lc.r1), w0 = srcB[k * 8 + lc.r0], w1 = srcB[k * 8 + lc.r1], ei = Eid(k, tj), wd = srcD[e];
         double acc0 = c_[0] * d_[0] + c_[1] * d_[1], acc1 = c_[2] * d_[2] + c_[3] * d_[3];
 #pragma unroll
         for (int r = 4; r < NX; ++r) acc0 += c_[r] * d_[r];
         double boxes = sb0 * w0 + sb1 * w1;
-        if (kCtrl && delay > 0) boxes += Sb(k, r2) * srcB[k * 8 + r2];        // pinned-steering row (uniform branch)
+        if (kCtrl && delay > 0) boxes += Sb(k, lc.r2) * srcB[k * 8 + lc.r2];        // pinned-steering row (uniform branch)
         return boxes + (ei * wd - (acc0 + acc1));
     }
     // dst = A' * (srcD, srcB)
     __device__ __forceinline__ void At_mul(const double *srcD, const double *srcB, double *dst) const {
-        for (int e = tid; e < NS * 8; e += kStride) dst[e] = At_elem(e, srcD, srcB);
+        const LaneC lc = lane_consts();
+        for (int e = opaque(tid); e < NS * 8; e += kStride) dst[e] = At_elem(e, srcD, srcB, lc);
     }
     // row a of the stage-k Hessian block times (D_k .* v_k), plus the slew-rate coupling to the neighbouring
     // stages; ABS = true gives the infinity norm of the (scaled) column instead.  Branch-free: the Pm row is
@@ -269,7 +284,7 @@ struct Solver {
     }
     // dst = P * src   (P = c D P0 D)
     __device__ __forceinline__ void P_mul(const double *src, double *dst) const {
-        for (int e = tid; e < NS * 8; e += kStride) dst[e] = P_row<false>(e >> 3, src);
+        for (int e = opaque(tid); e < NS * 8; e += kStride) dst[e] = P_row<false>(e >> 3, src);
     }
     // infinity norm of column (k, tj) of the scaled Hessian
     __device__ __forceinline__ double P_colnorm(int k, int) const { return P_row<true>(k, D); }
@@ -285,6 +300,8 @@ struct Solver {
         // normalisation are kept for the next iteration's column norms (D does not change in between): one pass less
         constexpr int kRounds = kReg ? ((NT + 1) * 8 + kStride - 1) / kStride : 1;
         double pacc[kRounds];
+        const LaneC lc = lane_consts();
+        const int r0 = lc.r0, r1 = lc.r1, r2 = lc.r2, bvar = lc.bvar;
         for (int it = 0; it < cfg.scaling; ++it) {
             // infinity norms of the columns of [P A'; A 0] -> step factors in XT (variables), ZTd / ZTb (rows)
             auto norms = [&](int e, double pcol) {
@@ -319,10 +336,10 @@ struct Solver {
                     if (e < NS * 8) norms(e, it == 0 ? P_colnorm(e >> 3, tj) : pacc[r] * c * D[e]);
                 }
             } else {
-                for (int e = tid; e < NS * 8; e += kStride) norms(e, P_colnorm(e >> 3, tj));
+                for (int e = opaque(tid); e < NS * 8; e += kStride) norms(e, P_colnorm(e >> 3, tj));
             }
             sync();
-            for (int e = tid; e < NS * 8; e += kStride) { D[e] *= XT[e]; Ed[e] *= ZTd[e]; Eb[e] *= ZTb[e]; }
+            for (int e = opaque(tid); e < NS * 8; e += kStride) { D[e] *= XT[e]; Ed[e] *= ZTd[e]; Eb[e] *= ZTb[e]; }
             sync();
             // cost normalisation
             double psum = 0.0, qmax = 0.0;
@@ -337,7 +354,7 @@ struct Solver {
                     }
                 }
             } else {
-                for (int e = tid; e < NS * 8; e += kStride) {
+                for (int e = opaque(tid); e < NS * 8; e += kStride) {
                     psum += P_colnorm(e >> 3, tj);
                     qmax = fmax(qmax, fabs(c * D[e] * Qv[e]));
                 }
@@ -518,6 +535,8 @@ struct Solver {
         const int a = inside ? li : 0, b = inside ? lj : 0;
         double kd = Pc(k, a, b) * c * D[k * 8 + a] * D[k * 8 + b];
         // diagonal: sigma + the box rows acting on the variable + the identity part of its dynamics row (lj = tj: r0, r1, r2 apply)
+        const LaneC lc = lane_consts();
+        const int r0 = lc.r0, r1 = lc.r1, r2 = lc.r2;
         const double sb0 = Sb(k, r0), sb1 = Sb(k, r1), sb2 = Sb(k, r2), ei = Eid(k, lj);
         double dd = sig + WBv[k * 8 + r0] * sb0 * sb0 + WBv[k * 8 + r1] * sb1 * sb1 + WDv[k * 8 + lj] * ei * ei;
         if (kCtrl && delay > 0) dd += WBv[k * 8 + r2] * sb2 * sb2;
@@ -556,7 +575,7 @@ struct Solver {
             // through LDS.  Per stage: G' = W Ko' (W = C_pred^-1), S = Kd - G G', L' = W' G', L = G W, C C' = S, W <- C^-1,
             // S^-1 = W' W; the finished step leaves its tiles in the operand registers of the MFMA sweeps.
             double *const WDv = XT, *const WBv = DX, *const PUB = VT;       // free vectors: row weights, hand-over area (VT + AT)
-            for (int e = tid; e < NS * 8; e += kStride) { WDv[e] = w_dyn(e); WBv[e] = w_box(e); }
+            for (int e = opaque(tid); e < NS * 8; e += kStride) { WDv[e] = w_dyn(e); WBv[e] = w_box(e); }
             sync();
             constexpr int P = kMid;
             double wd = 0.0, wtd = 0.0, sinv = 0.0;       // D forms of W, W' and S^-1 of the stage eliminated last
@@ -689,7 +708,7 @@ struct Solver {
     // Chain position p of wave w is stage p (w = 0) or N - p (w = 1); even positions use column form, odd ones
     // row form, L of odd positions is stored transposed -- exactly the single-chain scheme below, run on two
     // half-length chains at once.  The chains meet at stage kMid (wave 0), then both sweep outwards again.
-    template <bool BOT>
+    template <bool BOT, bool STASHED>
     __device__ __forceinline__ void twisted_forward() {
         constexpr int P = BOT ? kP1 : kP0;
         double *const vrow = (ti == 0) ? VT + tj : SINK + lane;
@@ -697,7 +716,7 @@ struct Solver {
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         // The right-hand side of the middle stage is read by BOTH waves in the backward sweep while wave 0 stores x_m
         // over it: keep a copy where nobody writes (RED[48..55]) so that a late wave 1 cannot pick up x_m instead.
-        if (!BOT && lane < 8) RED[48 + lane] = XT[kMid * 8 + lane];
+        if (!STASHED && !BOT && lane < 8) RED[48 + lane] = XT[kMid * 8 + lane];
         double yc = XT[stage(0) * 8 + ti], yr = 0.0;
         double bq[3];
         bq[1] = XT[stage(1) * 8 + tj];
@@ -794,13 +813,13 @@ struct Solver {
     }
     template <bool TYPE_A>
     __device__ __forceinline__ static double mf_close(double d) { return d + dpp_mov<TYPE_A ? 0x128 : 0x141>(d); }
-    template <bool BOT>
+    template <bool BOT, bool STASHED>
     __device__ __forceinline__ void mf_forward() {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         const MfLane m = mf_lane();
         const bool c0 = (m.ln & 3) == 0;
-        if (!BOT && m.ln < 8) RED[48 + m.ln] = XT[kMid * 8 + m.ln];        // the middle right-hand side survives x_m (see twisted_forward)
+        if (!STASHED && !BOT && m.ln < 8) RED[48 + m.ln] = XT[kMid * 8 + m.ln];   // the middle right-hand side survives x_m (see twisted_forward)
         // a type A step delivers layout B: right-hand side element eB in the blocks stB, results stored by the lanes c = 0 of them
         const double *const csA = XT + m.eB, *const csB = XT + m.eA;
         double *const vsA = (c0 && m.stB) ? VT + m.eB : SINK + m.ln;
@@ -890,9 +909,11 @@ struct Solver {
         }
     }
 
+    // STASHED: the caller has already copied the middle stage's right-hand side to RED[48..55]
+    template <bool STASHED = false>
     __device__ __forceinline__ void kkt_solve() {
         if constexpr (kMf) {
-            if (wv == 0) mf_forward<false>(); else mf_forward<true>();
+            if (wv == 0) mf_forward<false, STASHED>(); else mf_forward<true, STASHED>();
             sync();
             STAMP(1);
             if (wv == 0) mf_backward<false>(); else mf_backward<true>();
@@ -900,7 +921,7 @@ struct Solver {
             STAMP(2);
             return;
         } else if constexpr (kTwo) {
-            if (wv == 0) twisted_forward<false>(); else twisted_forward<true>();
+            if (wv == 0) twisted_forward<false, STASHED>(); else twisted_forward<true, STASHED>();
             sync();
             STAMP(1);
             if (wv == 0) twisted_backward<false>(); else twisted_backward<true>();
@@ -1004,7 +1025,7 @@ struct Solver {
         At_mul(yd, yb, AT);
         sync();
         Res r = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             const double eid = 1.0 / Ed[e], eib = 1.0 / Eb[e], di = 1.0 / D[e];
             const double rd = ZTd[e] - zd[e], rb = ZTb[e] - zb[e];
             r.s_pri = fmax(r.s_pri, fmax(fabs(rd), fabs(rb)));
@@ -1037,7 +1058,7 @@ struct Solver {
         P_mul(xv, VT);
         sync();
         double v = 0.0;
-        for (int e = tid; e < NS * 8; e += kStride) v += xv[e] * (0.5 * VT[e] + Qv[e]);
+        for (int e = opaque(tid); e < NS * 8; e += kStride) v += xv[e] * (0.5 * VT[e] + Qv[e]);
         v = bsum<1>(v) * cinv;
         sync();
         return v;
@@ -1049,7 +1070,7 @@ struct Solver {
     // ---- infeasibility certificates (OSQP is_primal_infeasible / is_dual_infeasible) ----------------
     __device__ __forceinline__ bool primal_infeasible(double eps) {
         double nd = 0.0;
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             // dynamics rows have finite bounds: no projection.  box rows: project on the polar recession cone
             double dy = DYb[e];
             const double lo = Lo[e], hi = Hi[e];
@@ -1063,7 +1084,7 @@ struct Solver {
         bool res = false;
         if (nd > eps) {
             double lhs = 0.0;
-            for (int e = tid; e < NS * 8; e += kStride) {
+            for (int e = opaque(tid); e < NS * 8; e += kStride) {
                 const double b = dyn_bound(e), dyd = DYd[e], dyb = DYb[e];
                 lhs += b * fmax(dyd, 0.0) + b * fmin(dyd, 0.0);
                 lhs += Hi[e] * fmax(dyb, 0.0) + Lo[e] * fmin(dyb, 0.0);
@@ -1073,7 +1094,7 @@ struct Solver {
                 At_mul(DYd, DYb, AT);
                 sync();
                 double na = 0.0;
-                for (int e = tid; e < NS * 8; e += kStride) na = fmax(na, fabs(AT[e] / D[e]));
+                for (int e = opaque(tid); e < NS * 8; e += kStride) na = fmax(na, fabs(AT[e] / D[e]));
                 na = bmax<2>(na);
                 res = na < eps * nd;
                 sync();
@@ -1083,21 +1104,21 @@ struct Solver {
     }
     __device__ __forceinline__ bool dual_infeasible(double eps) {
         double nd = 0.0, qdx = 0.0;
-        for (int e = tid; e < NS * 8; e += kStride) { nd = fmax(nd, fabs(D[e] * DX[e])); qdx += Qv[e] * DX[e]; }
+        for (int e = opaque(tid); e < NS * 8; e += kStride) { nd = fmax(nd, fabs(D[e] * DX[e])); qdx += Qv[e] * DX[e]; }
         { const SumMax qn = bsum_bmax<3>(qdx, nd); qdx = qn.s; nd = qn.m; }
         bool res = false;
         if (nd > eps && qdx < -c * eps * nd) {
             P_mul(DX, VT);
             sync();
             double np = 0.0;
-            for (int e = tid; e < NS * 8; e += kStride) np = fmax(np, fabs(VT[e] / D[e]));
+            for (int e = opaque(tid); e < NS * 8; e += kStride) np = fmax(np, fabs(VT[e] / D[e]));
             np = bmax<0>(np);
             sync();
             if (np < c * eps * nd) {
                 A_mul(DX, ZTd, ZTb);
                 sync();
                 double bad = 0.0;
-                for (int e = tid; e < NS * 8; e += kStride) {
+                for (int e = opaque(tid); e < NS * 8; e += kStride) {
                     const int k = e >> 3, r = e & 7;
                     if (r < NX) { const double v = ZTd[e] / Ed[e]; if (v > eps * nd || v < -eps * nd) bad = 1.0; }
                     if (r < nbox(k)) {
@@ -1114,7 +1135,7 @@ struct Solver {
 
     // w rows for the next right-hand side: ZT = rho z - y   (kept in ZT* between iterations)
     __device__ __forceinline__ void recompute_w() {
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             ZTd[e] = rho_eq * Zd[e] - Yd[e];
             ZTb[e] = rho_of(Lo[e], Hi[e], rho) * Zb[e] - Yb[e];
         }
@@ -1122,13 +1143,17 @@ struct Solver {
     }
     // XT = sigma x - q + A' (rho z - y)        (OSQP compute_rhs, x part, reduced form)
     __device__ __forceinline__ void build_rhs(double sigma) {
-        for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] = At_elem(e, ZTd, ZTb) + (sigma * X[e] - Qv[e]);
+        const LaneC lc = lane_consts();
+        for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
         sync();
     }
     // z~ = A x~ fused with OSQP update_x / update_z / update_y; leaves rho z - y in ZT*.
     // All LDS reads of a round are issued before any of its writes.
     __device__ __forceinline__ void update(double alpha, bool want_delta) {
         const double oma = 1.0 - alpha;
+        const LaneC lc = lane_consts();
+        const int bvar = lc.bvar;
+        const double rmask = lc.rmask;
         for (int e = opaque(tid); e < NS * 8; e += kStride) {
             const int k = e >> 3;
             const double xt = XT[e], xo = X[e];
@@ -1161,7 +1186,7 @@ struct Solver {
     // previous solution's stage k+1 (the last stage that exists for that row / variable is kept).
     __device__ __forceinline__ void warm_start(const double *st, bool shift) {
         const double *sx = st, *syd = st + NS * 8, *syb = st + 2 * NS * 8;
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             const int k = e >> 3, r = e & 7;
             const int kx = shift ? (r < NX ? (k < N ? k + 1 : N) : (k < N - 1 ? k + 1 : (k < N ? N - 1 : k))) : k;
             const int kd = shift ? (k < N ? k + 1 : N) : k;
@@ -1177,7 +1202,7 @@ struct Solver {
     }
     __device__ __forceinline__ void save_duals(double *st) const {
         double *syd = st + NS * 8, *syb = st + 2 * NS * 8;
-        for (int e = tid; e < NS * 8; e += kStride) { syd[e] = cinv * Ed[e] * Yd[e]; syb[e] = cinv * Eb[e] * Yb[e]; }
+        for (int e = opaque(tid); e < NS * 8; e += kStride) { syd[e] = cinv * Ed[e] * Yd[e]; syb[e] = cinv * Eb[e] * Yb[e]; }
     }
 
     // ---- the whole solve --------------------------------------------------------------------------
@@ -1195,7 +1220,7 @@ struct Solver {
             if (tid < 8) dRl[tid] = tid < 2 ? cfg.dR[tid] : 0.0;
         }
         for (int e = tid; e < NS * kTS; e += kStride) { tA[e] = 0.0; }
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             X[e] = 0; D[e] = 1.0; DX[e] = 0; Zd[e] = 0; Yd[e] = 0; Ed[e] = 1.0; DYd[e] = 0; ZTd[e] = 0;
             Zb[e] = 0; Yb[e] = 0; Eb[e] = 1.0; DYb[e] = 0; Lo[e] = 0; Hi[e] = 0; Qv[e] = 0; ZTb[e] = 0;
         }
@@ -1213,7 +1238,7 @@ struct Solver {
         const double uo0 = a.u_old ? a.u_old[(size_t)inst * uos + 0] : 0.0, uo1 = a.u_old ? a.u_old[(size_t)inst * uos + 1] : 0.0;
         const double mey = (!kCtrl && a.max_ey) ? a.max_ey[inst] : 0.0;
         bad |= !__builtin_isfinite(uo0) || !__builtin_isfinite(uo1) || !__builtin_isfinite(mey);
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             const int k = e >> 3, r = e & 7;
             // linear cost: controller q = -2 xtrack' M0 (CTRL:434-447); planner q = L_cf (PLAN:163)
             double q = 0.0;
@@ -1240,7 +1265,7 @@ struct Solver {
         sync();
         if (beq[15] != 0.0) {
             const double nanv = __builtin_nan("");
-            for (int e = tid; e < NS * 8; e += kStride) {
+            for (int e = opaque(tid); e < NS * 8; e += kStride) {
                 const int k = e >> 3, r = e & 7;
                 if (r < NX) a.xPred[((size_t)inst * NS + k) * NX + r] = nanv;
                 else if (r < NB && k < N) a.uPred[((size_t)inst * N + k) * 2 + (r - NX)] = nanv;
@@ -1257,7 +1282,7 @@ struct Solver {
 
         // ---------- setup: scaling, rho, factorisation ----------
         if (cfg.scaling > 0) scale_data();
-        for (int e = tid; e < NS * 8; e += kStride) { Qv[e] *= c * D[e]; Lo[e] *= Eb[e]; Hi[e] *= Eb[e]; }
+        for (int e = opaque(tid); e < NS * 8; e += kStride) { Qv[e] *= c * D[e]; Lo[e] *= Eb[e]; Hi[e] *= Eb[e]; }
         if (tid < 8) beq[tid] *= Ed[tid];
         sync();
         cache_row_coefficients();
@@ -1333,7 +1358,7 @@ struct Solver {
                            status == LPVMPC_DUAL_INFEASIBLE_ || status == LPVMPC_DUAL_INFEASIBLE_INACC_ ||
                            status == LPVMPC_NON_CVX_);
         const double nan = __builtin_nan("");
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             const int k = e >> 3, r = e & 7;
             const double v = sol ? D[e] * X[e] : nan;
             if (r < NX) a.xPred[((size_t)inst * NS + k) * NX + r] = v;
@@ -1341,7 +1366,7 @@ struct Solver {
             if (st_out) st_out[e] = sol ? v : 0.0;
         }
         if (st_out && !sol) {      // no solution: do not seed the next solve with garbage
-            for (int e = tid; e < NS * 8; e += kStride) { st_out[NS * 8 + e] = 0.0; st_out[2 * NS * 8 + e] = 0.0; }
+            for (int e = opaque(tid); e < NS * 8; e += kStride) { st_out[NS * 8 + e] = 0.0; st_out[2 * NS * 8 + e] = 0.0; }
         }
 #ifdef LPVMPC_STAMPS
         if (tid == 0 && a.resid) {     // diagnostic build: resid carries per-iteration cycle counts instead
@@ -1400,7 +1425,7 @@ struct Solver {
     struct PolishOut { int flag; double pri, dua, obj; };
     __device__ __forceinline__ PolishOut polish(double pri_res, double dua_res, double obj) {
         const double delta = cfg.delta, dinv = 1.0 / cfg.delta;
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             const int k = e >> 3, r = e & 7;
             double wd = 0.0, wb = 0.0;
             if (r < NX) {
@@ -1417,21 +1442,21 @@ struct Solver {
         factor(delta);
         // px (DX), py (Yd/Yb are overwritten: ADMM duals are no longer needed)
         // initial solve: rhs = -q + A'(W b)
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             ZTd[e] = fabs(DYd[e]) * dyn_bound(e);
             ZTb[e] = fabs(DYb[e]) * (DYb[e] > 0 ? Hi[e] : (DYb[e] < 0 ? Lo[e] : 0.0));
         }
         sync();
         At_mul(ZTd, ZTb, XT);
         sync();
-        for (int e = tid; e < NS * 8; e += kStride) XT[e] -= Qv[e];
+        for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] -= Qv[e];
         sync();
         kkt_solve();
-        for (int e = tid; e < NS * 8; e += kStride) DX[e] = XT[e];
+        for (int e = opaque(tid); e < NS * 8; e += kStride) DX[e] = XT[e];
         sync();
         A_mul(DX, ZTd, ZTb);
         sync();
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             Yd[e] = fabs(DYd[e]) * (ZTd[e] - dyn_bound(e));
             Yb[e] = fabs(DYb[e]) * (ZTb[e] - (DYb[e] > 0 ? Hi[e] : (DYb[e] < 0 ? Lo[e] : 0.0)));
         }
@@ -1442,7 +1467,7 @@ struct Solver {
             At_mul(Yd, Yb, AT);
             A_mul(DX, ZTd, ZTb);
             sync();
-            for (int e = tid; e < NS * 8; e += kStride) {
+            for (int e = opaque(tid); e < NS * 8; e += kStride) {
                 const double r2d = (DYd[e] != 0.0) ? dyn_bound(e) - ZTd[e] : 0.0;
                 const double r2b = (DYb[e] != 0.0) ? (DYb[e] > 0 ? Hi[e] : Lo[e]) - ZTb[e] : 0.0;
                 ZTd[e] = r2d; ZTb[e] = r2b;
@@ -1451,12 +1476,12 @@ struct Solver {
             sync();
             At_mul(Zd, Zb, XT);
             sync();
-            for (int e = tid; e < NS * 8; e += kStride) XT[e] += -Qv[e] - VT[e] - AT[e];
+            for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] += -Qv[e] - VT[e] - AT[e];
             sync();
             kkt_solve();
             A_mul(XT, Zd, Zb);
             sync();
-            for (int e = tid; e < NS * 8; e += kStride) {
+            for (int e = opaque(tid); e < NS * 8; e += kStride) {
                 DX[e] += XT[e];
                 Yd[e] += fabs(DYd[e]) * (Zd[e] - ZTd[e]);
                 Yb[e] += fabs(DYb[e]) * (Zb[e] - ZTb[e]);
@@ -1466,7 +1491,7 @@ struct Solver {
         // pol_z = A px, project (z, y) on the normal cone
         A_mul(DX, Zd, Zb);
         sync();
-        for (int e = tid; e < NS * 8; e += kStride) {
+        for (int e = opaque(tid); e < NS * 8; e += kStride) {
             { const double b = dyn_bound(e), t = Zd[e] + Yd[e], z = clipd(t, b, b); Zd[e] = z; Yd[e] = t - z; }
             { const double t = Zb[e] + Yb[e], z = clipd(t, Lo[e], Hi[e]); Zb[e] = z; Yb[e] = t - z; }
         }
@@ -1476,7 +1501,7 @@ struct Solver {
         const bool good = (R.pri < pri_res && R.dua < dua_res) || (R.pri < pri_res && dua_res < 1e-10) ||
                           (R.dua < dua_res && pri_res < 1e-10);
         if (good) {
-            for (int e = tid; e < NS * 8; e += kStride) X[e] = DX[e];
+            for (int e = opaque(tid); e < NS * 8; e += kStride) X[e] = DX[e];
             sync();
             return PolishOut{1, R.pri, R.dua, pobj};
         }

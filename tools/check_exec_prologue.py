@@ -10,6 +10,33 @@ import re
 import sys
 
 
+def dest_regs(instr):
+    """VGPR numbers written by a plain copy (first operand)."""
+    m = re.match(r"\S+\s+v(\d+),", instr)
+    if m:
+        return [int(m.group(1))]
+    m = re.match(r"\S+\s+v\[(\d+):(\d+)\],", instr)
+    if m:
+        return list(range(int(m.group(1)), int(m.group(2)) + 1))
+    return []
+
+
+def reads(instrs, reg):
+    """True if register v<reg> appears as a SOURCE operand of one of the instructions."""
+    for t in instrs:
+        ops = t.split(None, 1)[1] if " " in t else ""
+        srcs = ops.split(",", 1)[1] if "," in ops else ""
+        if t.startswith(("global_store", "ds_write", "scratch_store", "buffer_store", "flat_store")):
+            srcs = ops                                   # stores only read
+        for m in re.finditer(r"v\[(\d+):(\d+)\]|v(\d+)", srcs):
+            if m.group(3) is not None:
+                if int(m.group(3)) == reg:
+                    return True
+            elif int(m.group(1)) <= reg <= int(m.group(2)):
+                return True
+    return False
+
+
 def scan(path, window=8):
     suspects = []
     kernel = None
@@ -37,7 +64,16 @@ def scan(path, window=8):
                     # plain whole-register copies are what the register allocator / machine-sink insert; computations,
                     # stores and v_writelane (exec-independent SGPR spills) in front of the mask restore are normally the
                     # legitimate tail of the branch that falls through into the join block
-                    pre = [b for b in body[:k] if re.match(r"(v_mov_b32_e32\s+v\d+,\s*v\d+$|v_mov_b64_e32\s+v\[[\d:]+\],\s*v\[|v_accvgpr_(read|write)_b32)", b)]
+                    pre = []
+                    for idx, b in enumerate(body[:k]):
+                        if not re.match(r"(v_mov_b32_e32\s+v\d+,\s*v\d+$|v_mov_b64_e32\s+v\[[\d:]+\],\s*v\[|v_accvgpr_(read|write)_b32)", b):
+                            continue
+                        # a copy whose destination is consumed again before the mask restore is a temporary of the branch
+                        # that falls through into the join (e.g. the halves of a 64-bit address product feeding a store
+                        # of that branch), not a value handed to the lanes behind the join
+                        if all(reads(later, d) for d in dest_regs(b) for later in [body[idx + 1:k]]):
+                            continue
+                        pre.append(b)
                     if pre:
                         suspects.append((kernel, label, pre, t))
                     break
