@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU (default: configs[1] = 1024)")
-    ap.add_argument("--streams", type=int, default=32,
+    ap.add_argument("--streams", type=int, default=64,
                     help="HIP streams the K steps are issued on round-robin (independent batches overlap, so the few "
                          "slow instances of one batch do not leave the GPU idle); 1 = strictly back-to-back steps")
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
@@ -57,6 +57,9 @@ def main():
                          "planner, N=20; cfg5 = configs[4]: planner + controller + plant cascade, a step is one 30 Hz "
                          "controller tick of --batch vehicles per GPU (default 8192 / gpus) -- extra measurements, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs outside the timed region (serial steps, batch latencies, one launch of all distinct "
+                         "instances, single-solve latency): what the profiling passes use")
     ap.add_argument("--kernel-variant", type=int, default=0,
                     help="diagnostic: lpvmpc_set_option(kernel_variant) on every engine (0 = default; 3 = the DPP two-wavefront kernel)")
     ap.add_argument("--dry-run", action="store_true",
@@ -72,7 +75,9 @@ def main():
         return dry_run(args)
 
     # independent batches are pipelined over several HIP streams; give the runtime as many hardware queues
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(8, args.streams))))
+    # (16 hardware queues: with 8, the streams that share a queue with a launch holding a many-thousand-iteration instance wait
+    # behind it; beyond ~20 the queues are time-sliced and every launch slows down -- tools/queue_sweep.sh)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(16, args.streams))))
     import numpy as np
     import torch                      # first: liblpvmpc then binds to the HIP runtime torch loaded
     import torch.distributed as dist
@@ -101,40 +106,47 @@ def main():
     planner = args.workload == "cfg3"
     B, N = args.batch, (30 if planner else HORIZON)
     nx = 5 if planner else 6
-    if planner:
-        w = workloads.planner_batch(B, N=N, seed=1 + 1000 * rank)
-    else:
-        w = workloads.controller_batch(B, N=N, seed=1000 * rank)  # rank 0 == seed 0 of SURVEY section 8d
-    eng = workloads.make_solver(w, device=local_rank)
-    eng.reserve(B)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    x0, u_prev, curv, u_old = t(w["x0"]), t(w["u_prev"]), t(w["curv_s"]), t(w["u_old"])
-    vel_ref = None if planner else t(w["vel_ref"])
-    max_ey = t(w["max_ey"]) if planner else None
-    # one engine (workspace + output buffers) per stream: steps issued on different streams are independent
+    # One engine (workspace + output buffers), one HIP stream and one DISTINCT batch per in-flight slot: slot i solves the
+    # instances of seed i (+ 1000 rank; rank 0 / slot 0 == seed 0 of SURVEY section 8d), so the pipelined steps never
+    # re-solve the same 1024 instances and the rare many-thousand-iteration instances of the distribution are part of the
+    # measurement.  Steps issued on different streams are independent.
     S = max(1, args.streams)
-    engines = [eng] + [workloads.make_solver(w, device=local_rank) for _ in range(S - 1)]
+    make = workloads.planner_batch if planner else workloads.controller_batch
+    ws = [make(B, N=N, seed=(1 if planner else 0) + i + 1000 * rank) for i in range(S)]
+    w = ws[0]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ins = [dict(x0=t(wi["x0"]), u_prev=t(wi["u_prev"]), curv=t(wi["curv_s"]), u_old=t(wi["u_old"]),
+                vel_ref=None if planner else t(wi["vel_ref"]), max_ey=t(wi["max_ey"]) if planner else None) for wi in ws]
+    engines = [workloads.make_solver(w, device=local_rank) for _ in range(S)]
     for e in engines:
         e.set_option("kernel_variant", args.kernel_variant)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+
+    def new_outs(n):
+        return dict(xPred=torch.empty((n, N + 1, nx), dtype=torch.float64, device=dev),
+                    uPred=torch.empty((n, N, 2), dtype=torch.float64, device=dev),
+                    status=torch.empty(n, dtype=torch.int32, device=dev), iters=torch.empty(n, dtype=torch.int32, device=dev),
+                    resid=torch.empty((n, 4), dtype=torch.float64, device=dev), polish=torch.empty(n, dtype=torch.int32, device=dev))
     outs = []
     for e in engines:
         e.reserve(B)
-        outs.append(dict(xPred=torch.empty((B, N + 1, nx), dtype=torch.float64, device=dev),
-                         uPred=torch.empty((B, N, 2), dtype=torch.float64, device=dev),
-                         status=torch.empty(B, dtype=torch.int32, device=dev),
-                         iters=torch.empty(B, dtype=torch.int32, device=dev),
-                         resid=torch.empty((B, 4), dtype=torch.float64, device=dev),
-                         polish=torch.empty(B, dtype=torch.int32, device=dev)))
-    iters, status = outs[0]["iters"], outs[0]["status"]
+        outs.append(new_outs(B))
     counter = [0]
+    ran = [False] * S                                   # slot i has solved its whole batch at least once (its outputs are valid)
+
+    def solve_slot(i, n=B):
+        o, d = outs[i], ins[i]
+        engines[i].solve_dev(n, d["x0"], d["u_prev"], d["vel_ref"], d["curv"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"],
+                             o["status"], o["iters"], o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"],
+                             stream=streams[i].cuda_stream)
+        if n == B:
+            ran[i] = True
 
     def step():
         i = counter[0] % S
         counter[0] += 1
-        o = outs[i]
-        engines[i].solve_dev(B, x0, u_prev, vel_ref, curv, u_old, max_ey, o["xPred"], o["uPred"], o["status"], o["iters"],
-                             o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"], stream=streams[i].cuda_stream)
+        solve_slot(i)
+        return i
 
     def fence():
         torch.cuda.synchronize()
@@ -146,9 +158,7 @@ def main():
     # launch attributes exist before the first step (otherwise each of the S streams pays them inside the timed region when
     # the driver asks for fewer warm-up steps than there are streams)
     for i in range(S):
-        o = outs[i]
-        engines[i].solve_dev(1, x0, u_prev, vel_ref, curv, u_old, max_ey, o["xPred"], o["uPred"], o["status"], o["iters"],
-                             o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"], stream=streams[i].cuda_stream)
+        solve_slot(i, 1)
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -156,8 +166,7 @@ def main():
         e.set_timing(True)            # HIP events on the launch stream around every solve-kernel launch
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    timed_slots = [step() for _ in range(args.steps)]
     fence()
     elapsed = time.perf_counter() - t0
     k_ms = k_n = 0
@@ -165,56 +174,105 @@ def main():
         ms_, n_ = e.kernel_time_stats()
         k_ms += ms_; k_n += n_
         e.set_timing(False)
+    used = sorted(set(timed_slots))
+    it_slot = {i: outs[i]["iters"].cpu().numpy().astype(np.int64) for i in used}
+    st_slot = {i: outs[i]["status"].cpu().numpy() for i in used}
+    m_rows = ((N + 1) * nx + (N + 1) * nx + N * 2) if planner else None
+    bytes_slot = {i: algorithmic_bytes(it_slot[i], N=N, nx=nx, m_rows=m_rows)[0] for i in used}
+    bytes_iter = algorithmic_bytes(it_slot[used[0]], N=N, nx=nx, m_rows=m_rows)[1]
+    bytes_timed = float(sum(bytes_slot[i] for i in timed_slots))            # algorithmic bytes of exactly the K timed launches
+    iters_timed = float(sum(it_slot[i].sum() for i in timed_slots))
+    solved_timed = float(sum((st_slot[i] == 1).sum() for i in timed_slots))
 
-    # strictly serial steps on one stream (outside the timed region), for reference next to the pipelined value
-    counter[0] = 0
-    n_serial = min(args.steps, 20)
-    torch.cuda.synchronize(); t1 = time.perf_counter()
-    for _ in range(n_serial):
-        counter[0] = 0
-        step()
-    torch.cuda.synchronize()
-    serial_rate = B * n_serial / (time.perf_counter() - t1)
+    extras = {}
+    if not args.no_extras:
+        # round 1's protocol for continuity: the same K steps with EVERY slot solving the seed-0 batch (no instance beyond 700
+        # iterations), same streams and engines -- kernel progress separated from the change of protocol
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for j in range(args.steps):
+            i = j % S
+            o, d = outs[i], ins[0]
+            engines[i].solve_dev(B, d["x0"], d["u_prev"], d["vel_ref"], d["curv"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"],
+                                 o["status"], o["iters"], o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"],
+                                 stream=streams[i].cuda_stream)
+        torch.cuda.synchronize()
+        extras["seed0_replicated_solves_per_s"] = B * args.steps / (time.perf_counter() - t1)
+        # strictly serial steps on ONE stream (every step waits for its predecessor's slowest instance), batches of slots 0, 1, ...
+        n_serial = min(args.steps, 20)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for j in range(n_serial):
+            o, d = outs[j % S], ins[j % S]
+            engines[0].solve_dev(B, d["x0"], d["u_prev"], d["vel_ref"], d["curv"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"],
+                                 o["status"], o["iters"], o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"],
+                                 stream=streams[0].cuda_stream)
+        torch.cuda.synchronize()
+        extras["single_stream_solves_per_s_per_gpu"] = B * n_serial / (time.perf_counter() - t1)
+        # latency of one synchronous batch: every distinct batch once (p50 over batches), and the seed-0 batch alone
+        lat = []
+        for i in range(S):
+            torch.cuda.synchronize(); t1 = time.perf_counter(); solve_slot(i); torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        extras["p50_batch_latency_ms"] = float(np.median(lat))
+        extras["max_batch_latency_ms"] = float(np.max(lat))
+        l0 = []
+        for _ in range(7):
+            torch.cuda.synchronize(); t1 = time.perf_counter(); solve_slot(0); torch.cuda.synchronize()
+            l0.append((time.perf_counter() - t1) * 1e3)
+        extras["seed0_batch_latency_ms"] = float(np.median(l0))
+        # isolated launches of the seed-0 batch (nothing else on the GPU): the per-launch kernel time without neighbours
+        engines[0].set_timing(True)
+        for _ in range(5):
+            solve_slot(0); torch.cuda.synchronize()
+        ms_, n_ = engines[0].kernel_time_stats(); engines[0].set_timing(False)
+        iso_ms = ms_ / max(n_, 1)
+        it0 = outs[0]["iters"].cpu().numpy().astype(np.int64)
+        extras["isolated_seed0_launch"] = {"kernel_avg_ms": iso_ms, "launches": n_,
+                                           "frac": algorithmic_bytes(it0, N=N, nx=nx, m_rows=m_rows)[0] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "max_admm_iters": int(it0.max())}
+        # ONE launch of all the distinct instances of this rank (S x B; 32768 at the defaults): one workspace, one stream
+        if not planner and S * B <= 65536:
+            cat = lambda k: None if ins[0][k] is None else torch.cat([d[k] for d in ins], dim=0)
+            big_in = {k: cat(k) for k in ("x0", "u_prev", "vel_ref", "curv", "u_old", "max_ey")}
+            big = workloads.make_solver(w, device=local_rank); big.set_option("kernel_variant", args.kernel_variant)
+            big.reserve(S * B); bo = new_outs(S * B)
 
-    # p50 latency of one synchronous batch (outside the timed region)
-    lat = []
-    for _ in range(min(20, max(5, args.steps))):
-        counter[0] = 0
-        torch.cuda.synchronize(); t1 = time.perf_counter(); step(); torch.cuda.synchronize()
-        lat.append((time.perf_counter() - t1) * 1e3)
-    p50 = float(np.median(lat))
+            def big_launch():
+                big.solve_dev(S * B, big_in["x0"], big_in["u_prev"], big_in["vel_ref"], big_in["curv"], big_in["u_old"], big_in["max_ey"],
+                              bo["xPred"], bo["uPred"], bo["status"], bo["iters"], bo["resid"], bo["polish"], cf_new=w["cf_new"],
+                              lap=w["lap"], stream=streams[0].cuda_stream)
+            big_launch(); torch.cuda.synchronize()
+            tb = []
+            for _ in range(3):
+                t1 = time.perf_counter(); big_launch(); torch.cuda.synchronize(); tb.append(time.perf_counter() - t1)
+            bi = bo["iters"].cpu().numpy().astype(np.int64)
+            extras["single_launch"] = {"instances": S * B, "solves_per_s": S * B / float(np.median(tb)), "ms": float(np.median(tb)) * 1e3,
+                                       "max_admm_iters": int(bi.max()),
+                                       "frac": algorithmic_bytes(bi, N=N, nx=nx)[0] / float(np.median(tb)) / 1e9 / HBM_PEAK_GBS}
+            big.close()
+        # p50 latency of ONE solve through the host-array entry point (what a 30 Hz control loop calls once per tick: PCIe
+        # copies in and out included)
+        one = {k: (v[:1] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == B and k != "track" else v) for k, v in w.items()}
+        lat1 = []
+        for _ in range(30):
+            t1 = time.perf_counter()
+            engines[0].solve(one["x0"], one["u_prev"], one["vel_ref"], one["curv_s"], one["u_old"], one["max_ey"], one["cf_new"], one["lap"])
+            lat1.append((time.perf_counter() - t1) * 1e3)
+        extras["p50_single_solve_latency_ms"] = float(np.median(lat1[5:]))
 
-    # p50 latency of ONE solve through the host-array entry point (what a 30 Hz control loop calls once per tick: PCIe
-    # copies in and out included), outside the timed region
-    one = {k: (v[:1] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == B and k != "track" else v) for k, v in w.items()}
-    lat1 = []
-    for _ in range(30):
-        t1 = time.perf_counter()
-        engines[0].solve(one["x0"], one["u_prev"], one["vel_ref"], one["curv_s"], one["u_old"], one["max_ey"], one["cf_new"], one["lap"])
-        lat1.append((time.perf_counter() - t1) * 1e3)
-    p50_one = float(np.median(lat1[5:]))
-
-    it_host = iters.cpu().numpy().astype(np.int64)
-    st_host = status.cpu().numpy()
     from lpvmpc.distributed import reduce_stats, gather_results
-    elapsed, agg = reduce_stats(elapsed, [float(it_host.sum()), float((st_host == 1).sum())], device=dev)
+    elapsed, agg = reduce_stats(elapsed, [iters_timed, solved_timed, bytes_timed], device=dev)
     # the one collective of the path, after the timed region: first input, status and iteration count of every
-    # instance of the job on every rank (B x 4 words per rank over RCCL)
-    g_u0, g_status, g_iters = gather_results(outs[0]["uPred"][:, 0, :].cpu().numpy(), st_host, it_host, B * world, device=dev)
-    assert g_u0.shape == (B * world, 2) and int(g_iters.astype(np.int64).sum()) == int(agg[0])
+    # instance of one batch per rank (B x 4 words per rank over RCCL)
+    last = timed_slots[-1] if timed_slots else 0
+    g_u0, g_status, g_iters = gather_results(outs[last]["uPred"][:, 0, :].cpu().numpy(), st_slot[last], it_slot[last], B * world, device=dev)
+    assert g_u0.shape == (B * world, 2) and g_iters.shape == (B * world,)
 
     if rank == 0:
         total = B * world * args.steps
-        bytes_launch, bytes_iter = algorithmic_bytes(it_host, N=N, nx=nx, m_rows=((N + 1) * nx + (N + 1) * nx + N * 2) if planner else None)
         k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
+        bytes_launch = bytes_timed / max(args.steps, 1)         # mean algorithmic bytes of a timed launch (rank 0)
         achieved = bytes_launch / k_avg_s / 1e9 if k_n else float("nan")
-        traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside bench.py)
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pm.get("batch") == B and not planner:
-                traffic = pm["traffic_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
+        pmc = load_pmc(B, planner)
         out = {
             "metric": "MPC solves/sec (N=20, nx=6, nu=2)" if not planner else "LPV-MPP planner solves/sec (N=30, nx=5, nu=2)",
             "value": total / elapsed,
@@ -228,26 +286,29 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": ("configs[1]: batch=%d LPV-MPC controller solves per GPU, N=20, random x0 along "
-                                    "oval, racing tuning, OSQP defaults + polish, cold start" % B) if not planner else
-                                   ("configs[2]: batch=%d LPV-MPP planner solves per GPU (velocity-max cost), N=30, "
-                                    "L-shape track, OSQP defaults + polish, cold start" % B),
-                       "batch_per_gpu": B, "horizon": N, "nx": nx, "nu": 2,
-                       "mean_admm_iters": agg[0] / (B * world),
-                       "max_admm_iters_rank0": int(it_host.max()),
-                       "solved_fraction": agg[1] / (B * world),
-                       "p50_batch_latency_ms": p50, "p50_single_solve_latency_ms": p50_one, "streams": S,
-                       "single_stream_solves_per_s_per_gpu": serial_rate},
+            "config": dict({"workload": ("configs[1]: batch=%d LPV-MPC controller solves per GPU, N=20, random x0 along "
+                                         "oval, racing tuning, OSQP defaults + polish, cold start" % B) if not planner else
+                                        ("configs[2]: batch=%d LPV-MPP planner solves per GPU (velocity-max cost), N=30, "
+                                         "L-shape track, OSQP defaults + polish, cold start" % B),
+                            "batch_per_gpu": B, "horizon": N, "nx": nx, "nu": 2, "streams": S,
+                            "distinct_batches_timed": len(used), "batch_seeds": "slot i = seed %d + i + 1000 rank" % (1 if planner else 0),
+                            "mean_admm_iters": agg[0] / total,
+                            "max_admm_iters_rank0": int(max(it_slot[i].max() for i in used)),
+                            "solved_fraction": agg[1] / total}, **extras),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "admm_solve_kernel<%d, %d, 2>" % (nx, N), "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc.get("traffic_bytes_per_launch"), "traffic_source": pmc.get("source"),
+                         "valu": pmc.get("valu"), "valu_source": pmc.get("source") if pmc.get("valu") else None,
+                         "kernel": "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, "" if planner or args.kernel_variant == 3 else ", MFMA sweeps"),
+                         "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
                          "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_admm_iteration": bytes_iter,
-                         "aggregate_algorithmic_GBps": bytes_launch * args.steps * world / elapsed / 1e9,
-                         "aggregate_frac_per_gpu": bytes_launch * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                         "aggregate_algorithmic_GBps": agg[2] / elapsed / 1e9,
+                         "aggregate_frac_per_gpu": bytes_timed / elapsed / 1e9 / HBM_PEAK_GBS,
                          "note": "algorithmic bytes per SURVEY 8(d) (factor + vectors streamed once per ADMM "
                                  "iteration); the kernel keeps them in LDS/registers, so real HBM traffic is far lower. "
-                                 "With --streams > 1 launches overlap, so the per-launch duration includes time "
-                                 "spent sharing the GPU with the neighbouring batches"},
+                                 "frac is per launch, measured while the launches of the other streams share the GPU "
+                                 "(a launch lasts as long as its slowest instance); aggregate_frac_per_gpu = all timed "
+                                 "launches' bytes / wall time; config.isolated_seed0_launch is one launch alone on the GPU"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, planner=planner)
@@ -257,6 +318,23 @@ def main():
         e.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def load_pmc(B, planner):
+    """HBM traffic and VALU counters of the solve kernel from the rocprofv3 --pmc passes committed under profiles/ (rocprofv3
+    cannot run inside bench.py): they describe one isolated launch of the seed-0 batch, NOT this run -- the file is named in
+    the output next to the numbers."""
+    if planner or B != BATCH:
+        return {}
+    for name in ("r02_pmc.json",):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if pm.get("batch") == B:
+            pm["source"] = "profiles/%s (%s); collected separately, not measured in this run" % (name, pm.get("command", "rocprofv3 --pmc"))
+            return pm
+    return {}
 
 
 def launch_ranks(n):
