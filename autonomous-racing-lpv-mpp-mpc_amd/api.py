@@ -260,6 +260,13 @@ class BatchedSolver:
         return out
 
     # -- planner + controller + plant cascade (configs[4]) ------------------------------------------------
+    def cl_release(self):
+        """End the closed-loop fleet / cascade of this engine: batch calls are accepted again (they are refused while a fleet
+        runs, because the fleet's state lives in the engine's workspace)."""
+        self._chk(self._lib.lpvmpc_cl_release(self._h))
+        self._cas = None
+        self._cas_planner = None
+
     def cascade_init(self, planner, plant0, cmd0, uPred0, lap0=1, half_width=0.3, slack=0.15, plan_max_ey=0.2, q9_swap=True,
                      n_sub=(7, 7, 6), dt_sim=0.005, mu_sim=0.05):
         p0 = f64(plant0).reshape(-1, 8)

@@ -80,7 +80,7 @@ extern "C" int lpvmpc_handoff_setup(lpvmpc_handle *h, const lpvmpc_handoff_confi
 
 extern "C" int lpvmpc_handoff_batch(lpvmpc_handle *h, int32_t B, const double *xPred, double *SS, double *pose, double *sig, double *refs) {
     if (h && B == 0) return LPVMPC_OK;
-    int rc = lpvmpc_check_common(h, B, "lpvmpc_handoff_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_batch(h, B, "lpvmpc_handoff_batch"); if (rc) return rc;
     if (!h->d_Wop) return fail(h, LPVMPC_E_ARG, "lpvmpc_handoff_batch: call lpvmpc_handoff_setup first");
     if (!xPred || !SS || !pose || !refs) return fail(h, LPVMPC_E_ARG, "lpvmpc_handoff_batch: NULL argument");
     const size_t N = h->cfg.N, M = h->ho_M, b = B;
@@ -115,6 +115,7 @@ void lpvmpc_cascade_free(lpvmpc_handle *h) {
     if (c->ev_ctrl) (void)hipEventDestroy(c->ev_ctrl);
     if (c->s_ctrl) (void)hipStreamDestroy(c->s_ctrl);
     if (c->s_plan) (void)hipStreamDestroy(c->s_plan);
+    if (c->plan && c->plan->cascade_owner == h) c->plan->cascade_owner = nullptr;
     delete c;
     h->cascade = nullptr;
 }
@@ -139,6 +140,7 @@ extern "C" int lpvmpc_cascade_init(lpvmpc_handle *h, lpvmpc_handle *plan, int32_
     std::memset(c, 0, sizeof(*c));
     h->cascade = c;
     c->prefetch = h->cascade_prefetch;
+    plan->cascade_owner = h;
     c->plan = plan; c->B = B; c->M = plan->ho_M; c->q9 = q9_swap != 0; c->hw = half_width; c->slack = slack; c->dt_sim = dt_sim; c->mu_sim = mu_sim;
     for (int i = 0; i < 3; ++i) c->n_sub[i] = n_sub[i];
     const size_t b = B, N = h->cfg.N, Np = plan->cfg.N, M = c->M;

@@ -108,7 +108,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->d_xPred = h->d_uPred = h->d_resid = h->d_xlast = h->d_delta = nullptr;
     h->d_status = h->d_iters = h->d_polish = nullptr; h->d_state = nullptr; h->warm_mode = 0; h->state_valid_B = 0;
     h->cl_plant = h->cl_local = h->cl_cmd = nullptr; h->cl_B = 0; h->cl_first_it = 1; h->cl_q9 = 1; h->cl_ticks = 0;
-    h->d_Wop = h->d_FWop = nullptr; h->ho_M = 0; h->cascade = nullptr; h->cascade_prefetch = 1;
+    h->d_Wop = h->d_FWop = nullptr; h->ho_M = 0; h->cascade = nullptr; h->cascade_owner = nullptr; h->cascade_prefetch = 1;
     h->h_pack_in = h->h_pack_out = h->d_pack_in = h->d_pack_out = nullptr;
     DevCfg &d = h->dev;
     std::memset(&d, 0, sizeof(d));
@@ -237,6 +237,16 @@ int lpvmpc_launch_solve_timed(lpvmpc_handle *h, const SolveArgs &a, hipStream_t 
     return LPVMPC_OK;
 }
 
+// The closed-loop fleet (lpvmpc_cl_*) and the cascade keep their state between ticks in the handle's workspace (reference
+// windows, receding-horizon inputs, last commands, statuses): a stand-alone batch call on the same handle would overwrite it
+// -- or, with a larger B, reallocate it -- without any error.  Such calls are refused; use a second handle.
+int lpvmpc_check_batch(lpvmpc_handle *h, int B, const char *who) {
+    if (h && (h->cl_plant || h->cascade || h->cascade_owner))
+        return fail(h, LPVMPC_E_ARG, "%s: this handle runs a %s whose state lives in its workspace; use another handle for batch calls "
+                    "(lpvmpc_cl_release ends the fleet)", who, h->cl_plant ? "closed-loop fleet" : "planner + controller cascade");
+    return lpvmpc_check_common(h, B, who);
+}
+
 int lpvmpc_check_common(lpvmpc_handle *h, int B, const char *who) {
     if (!h) return fail(nullptr, LPVMPC_E_ARG, "%s: handle is NULL", who);
     if (B <= 0) return fail(h, LPVMPC_E_ARG, "%s: B=%d", who, B);
@@ -302,7 +312,7 @@ extern "C" int lpvmpc_lpv_batch(lpvmpc_handle *h, int32_t B, const double *x0, c
                                 const double *vel_ref, const double *curv_s, double cf_new, int32_t lap,
                                 double *states, double *A, double *Bm) {
     if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
-    int rc = lpvmpc_check_common(h, B, "lpvmpc_lpv_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_batch(h, B, "lpvmpc_lpv_batch"); if (rc) return rc;
     const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
     if (!x0 || !u_prev) return fail(h, LPVMPC_E_ARG, "lpvmpc_lpv_batch: x0 / u_prev is NULL");
     if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_lpv_batch: controller needs vel_ref");
@@ -342,7 +352,7 @@ extern "C" int lpvmpc_lpv_batch(lpvmpc_handle *h, int32_t B, const double *x0, c
 extern "C" int lpvmpc_estimate_abc_batch(lpvmpc_handle *h, int32_t B, const double *xlast, const double *delta,
                                          double *A, double *Bm) {
     if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
-    int rc = lpvmpc_check_common(h, B, "lpvmpc_estimate_abc_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_batch(h, B, "lpvmpc_estimate_abc_batch"); if (rc) return rc;
     if (!xlast || !delta) return fail(h, LPVMPC_E_ARG, "lpvmpc_estimate_abc_batch: NULL input");
     rc = lpvmpc_need_track(h, "lpvmpc_estimate_abc_batch"); if (rc) return rc;
     const size_t N = h->cfg.N, nx = h->nx, nb = h->nb, b = B;
@@ -366,7 +376,7 @@ extern "C" int lpvmpc_solve_batch_AB(lpvmpc_handle *h, int32_t B, const double *
                                      double *xPred, double *uPred, int32_t *status, int32_t *iters, double *resid,
                                      int32_t *polish) {
     if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
-    int rc = lpvmpc_check_common(h, B, "lpvmpc_solve_batch_AB"); if (rc) return rc;
+    int rc = lpvmpc_check_batch(h, B, "lpvmpc_solve_batch_AB"); if (rc) return rc;
     const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
     if (!x0 || !A || !Bm) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_AB: x0 / A / B is NULL");
     if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_AB: controller needs vel_ref");
@@ -410,7 +420,7 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
                                       const double *max_ey, double cf_new, int32_t lap, double *xPred, double *uPred,
                                       int32_t *status, int32_t *iters, double *resid, int32_t *polish, void *stream) {
     if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
-    int rc = lpvmpc_check_common(h, B, "lpvmpc_solve_batch_dev"); if (rc) return rc;
+    int rc = lpvmpc_check_batch(h, B, "lpvmpc_solve_batch_dev"); if (rc) return rc;
     const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
     if (!x0 || !u_prev || !xPred || !uPred) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_dev: NULL x0 / u_prev / xPred / uPred");
     if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_dev: controller needs vel_ref");
@@ -431,7 +441,7 @@ extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0,
                                   const double *max_ey, double cf_new, int32_t lap, double *xPred, double *uPred,
                                   int32_t *status, int32_t *iters, double *resid, int32_t *polish) {
     if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
-    int rc = lpvmpc_check_common(h, B, "lpvmpc_solve_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_batch(h, B, "lpvmpc_solve_batch"); if (rc) return rc;
     const bool ctrl = h->cfg.kind == LPVMPC_KIND_CONTROLLER;
     if (!x0 || !u_prev) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch: x0 / u_prev is NULL");
     if (ctrl && !vel_ref) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch: controller needs vel_ref");
@@ -464,7 +474,7 @@ extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0,
 // ------------------------------------------------------------------------------------------------
 extern "C" int lpvmpc_local_position_batch(lpvmpc_handle *h, int32_t B, const double *xy_psi, double half_width, double slack, double *out) {
     if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
-    int rc = lpvmpc_check_common(h, B, "lpvmpc_local_position_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_batch(h, B, "lpvmpc_local_position_batch"); if (rc) return rc;
     if (!xy_psi || !out) return fail(h, LPVMPC_E_ARG, "lpvmpc_local_position_batch: NULL argument");
     rc = lpvmpc_need_track(h, "lpvmpc_local_position_batch"); if (rc) return rc;
     hipStream_t st = h->stream;
@@ -478,7 +488,7 @@ extern "C" int lpvmpc_local_position_batch(lpvmpc_handle *h, int32_t B, const do
 
 extern "C" int lpvmpc_global_position_batch(lpvmpc_handle *h, int32_t B, const double *s_ey, double *out) {
     if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
-    int rc = lpvmpc_check_common(h, B, "lpvmpc_global_position_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_batch(h, B, "lpvmpc_global_position_batch"); if (rc) return rc;
     if (!s_ey || !out) return fail(h, LPVMPC_E_ARG, "lpvmpc_global_position_batch: NULL argument");
     rc = lpvmpc_need_track(h, "lpvmpc_global_position_batch"); if (rc) return rc;
     hipStream_t st = h->stream;
@@ -496,7 +506,7 @@ lpvmpc::PlantCfg lpvmpc_plant_cfg(const lpvmpc_handle *h, int n_sub, double dt_s
 
 extern "C" int lpvmpc_plant_step_batch(lpvmpc_handle *h, int32_t B, double *state, const double *u, int32_t n_sub, double dt_sim, double mu_sim) {
     if (h && B == 0) return LPVMPC_OK;                                   // an empty batch is a no-op
-    int rc = lpvmpc_check_common(h, B, "lpvmpc_plant_step_batch"); if (rc) return rc;
+    int rc = lpvmpc_check_batch(h, B, "lpvmpc_plant_step_batch"); if (rc) return rc;
     if (!state || !u || n_sub < 1 || !(dt_sim > 0)) return fail(h, LPVMPC_E_ARG, "lpvmpc_plant_step_batch: bad argument");
     hipStream_t st = h->stream;
     H2D(h->d_xlast, state, (size_t)B * 8 * 8); H2D(h->d_states, u, (size_t)B * 2 * 8);
@@ -507,6 +517,16 @@ extern "C" int lpvmpc_plant_step_batch(lpvmpc_handle *h, int32_t B, double *stat
 }
 
 // ---- closed-loop fleet: controller in the lap-0 path-tracking branch of controllerMain.py ----------------
+extern "C" int lpvmpc_cl_release(lpvmpc_handle *h) {
+    if (!h) return fail(nullptr, LPVMPC_E_ARG, "lpvmpc_cl_release: handle is NULL");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->cascade) { HIP_TRY(h, hipDeviceSynchronize()); lpvmpc_cascade_free(h); }
+    if (h->cl_plant) { (void)hipFree(h->cl_plant); (void)hipFree(h->cl_local); (void)hipFree(h->cl_cmd); h->cl_plant = h->cl_local = h->cl_cmd = nullptr; }
+    h->cl_B = 0; h->cl_ticks = 0; h->cl_first_it = 1;
+    return LPVMPC_OK;
+}
+
 extern "C" int lpvmpc_cl_init(lpvmpc_handle *h, int32_t B, const double *plant0, double half_width, double slack, int32_t q9_swap,
                               int32_t n_sub, double dt_sim, double mu_sim) {
     int rc = lpvmpc_check_common(h, B, "lpvmpc_cl_init"); if (rc) return rc;

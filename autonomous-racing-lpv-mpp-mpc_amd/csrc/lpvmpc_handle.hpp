@@ -49,6 +49,7 @@ struct lpvmpc_handle {
     int ho_M;
     int cascade_prefetch;               // option "cascade_prefetch" (default 1)
     lpvmpc_cascade *cascade;            // owned by the controller handle of a cascade (lpvmpc_cascade_init)
+    lpvmpc_handle *cascade_owner;       // planner handle: the controller handle whose cascade drives it (its workspace carries the planner recursion)
 };
 
 LPVMPC_HIDDEN int lpvmpc_fail(lpvmpc_handle *h, int code, const char *fmt, ...);
@@ -66,6 +67,7 @@ LPVMPC_HIDDEN int lpvmpc_fail(lpvmpc_handle *h, int code, const char *fmt, ...);
 // helpers defined in lpvmpc_api.hip
 LPVMPC_HIDDEN int lpvmpc_need_track(lpvmpc_handle *h, const char *who);
 LPVMPC_HIDDEN int lpvmpc_check_common(lpvmpc_handle *h, int B, const char *who);       // validates, selects the device, sizes the workspace
+LPVMPC_HIDDEN int lpvmpc_check_batch(lpvmpc_handle *h, int B, const char *who);        // the same for the stand-alone batch calls: refused while the handle runs a fleet
 LPVMPC_HIDDEN int lpvmpc_launch_solve_timed(lpvmpc_handle *h, const lpvmpc::SolveArgs &a, hipStream_t st);
 LPVMPC_HIDDEN lpvmpc::PlantCfg lpvmpc_plant_cfg(const lpvmpc_handle *h, int n_sub, double dt_sim, double mu_sim);
 LPVMPC_HIDDEN void lpvmpc_cascade_free(lpvmpc_handle *h);                               // cascade_api.hip

@@ -554,6 +554,11 @@ def bench_cascade(args, rank, local_rank, world, dev):
                "higher_is_better": True, "scaling": "strong" if args.batch == BATCH else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "configs[4]: %d vehicles per GPU, planner + controller cascade per 30 Hz tick, L-shape track, Monte-Carlo starts "
                                       "around the lap-event state, cold start" % B, "vehicles_per_gpu": B, "alive_fraction": agg[0] / (B * world),
+                          "laps_completed_survivors_rank0": ({"min": int(o["lap"][alive].min()) - 1, "p50": float(np.median(o["lap"][alive])) - 1,
+                                                              "max": int(o["lap"][alive].max()) - 1} if alive.any() else None),
+                          "driving_time_s": (args.steps + args.warmup) / 30.0,
+                          "attrition_note": "losses = planner QPs of the reference's open-loop recursion turning primal infeasible; the CPU oracle "
+                                            "cascade loses the same share (profiles/r02_cascade_attrition_cpu_oracle.txt, tests/test_gpu_cascade.py)",
                           "real_time_factor": (args.steps / 30.0) / elapsed, "planner_ticks": int(o["ticks"][1]),
                           "ctrl_kernel_avg_ms": cms / max(cn, 1)},
                "roofline": {"bound": "hbm", "achieved": bytes_launch / k_avg_s / 1e9 if pn else float("nan"), "peak": HBM_PEAK_GBS, "unit": "GB/s",

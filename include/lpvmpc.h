@@ -224,6 +224,13 @@ int lpvmpc_cl_init(lpvmpc_handle *h, int32_t B, const double *plant0, double hal
                    int32_t n_sub, double dt_sim, double mu_sim);
 int lpvmpc_cl_tick(lpvmpc_handle *h, int32_t n_ticks);
 int lpvmpc_cl_read(lpvmpc_handle *h, double *plant, double *local_state, double *cmd, int32_t *iters, int32_t *status);
+/* A handle that runs a fleet (lpvmpc_cl_init) or a cascade (lpvmpc_cascade_init, the controller handle and its planner
+ * handle) keeps the fleet's receding-horizon state in its workspace between ticks: the stand-alone batch calls
+ * (lpvmpc_solve_batch*, lpvmpc_lpv_batch, lpvmpc_estimate_abc_batch, lpvmpc_*_position_batch, lpvmpc_plant_step_batch,
+ * lpvmpc_handoff_batch) on such a handle fail with LPVMPC_E_ARG instead of overwriting it -- use a second handle.
+ * lpvmpc_cl_release ends the fleet / cascade of the handle (waits for its queued ticks, frees the fleet buffers); the handle
+ * then accepts batch calls again. */
+int lpvmpc_cl_release(lpvmpc_handle *h);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Planner -> controller reference hand-off.  Replaces the post-processing in the planner node

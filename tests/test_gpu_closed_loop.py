@@ -86,3 +86,36 @@ def test_fleet_of_different_vehicles_runs():
     assert np.all(o["local"][:, 4] < 9999) and np.median(ds) > 1.0
     assert np.median(np.abs(o["local"][:, 5])) < 0.1
     eng.close()
+
+
+def test_batch_calls_are_refused_while_a_fleet_runs():
+    """The fleet's receding-horizon state lives in the handle's workspace between ticks: a stand-alone batch call on the same
+    handle would overwrite (or reallocate) it silently.  It is refused with LPVMPC_E_ARG until lpvmpc_cl_release; the fleet
+    is unharmed by the attempt, and a cascade protects its planner handle the same way."""
+    import lpvmpc
+    from lpvmpc import workloads
+    from tests._golden import load
+    g = load("plant_and_transforms")
+    w = workloads.controller_batch(4, N=20, seed=9)
+    mp = lpvmpc.Map("oval", 0.2)
+    Q, R, dR = workloads.CTRL_TUNINGS["path"]
+    eng = lpvmpc.BatchedSolver("controller", 20, 1 / 30.0, Q, R, dR, track=mp.PointAndTangent)
+    ref = lpvmpc.BatchedSolver("controller", 20, 1 / 30.0, Q, R, dR, track=mp.PointAndTangent)
+    plant0 = np.tile(np.asarray(g["cl_plant"][0], float).reshape(1, 8), (4, 1))          # the fixture's start state
+    for e in (eng, ref):
+        e.cl_init(plant0, half_width=mp.halfWidth, slack=mp.slack)
+        e.cl_tick(3)
+    with pytest.raises(lpvmpc.LpvMpcError) as err:
+        eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"])
+    assert err.value.code == lpvmpc._ffi.E_ARG and "fleet" in str(err.value)
+    with pytest.raises(lpvmpc.LpvMpcError):
+        eng.local_position(np.zeros((2000, 3)), mp.halfWidth, mp.slack)          # would have reallocated the workspace
+    for e in (eng, ref):
+        e.cl_tick(3)
+    a, b = eng.cl_read(), ref.cl_read()
+    for k in ("plant", "cmd", "iters", "status"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    eng.cl_release()
+    out = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"])
+    assert np.all(out["status"] == 1)
+    eng.close(); ref.close()

@@ -268,12 +268,17 @@ def test_planner_n40_batch_against_oracle(lpvmpc):
     out = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
     eng.close()
     ref = O.plan_tick_batch(w, nthreads=8)
-    sane = ref["status"] != -10                              # (the oracle gives up on a diverged roll-out: |A| ~ 1e65, 1 in 2048)
-    assert np.array_equal(out["status"][sane], ref["status"][sane]) and np.mean(out["iters"][sane] == ref["iters"][sane]) >= 0.995
+    # the oracle gives up (status -10) on exactly two instances whose roll-out diverged (|A| ~ 1e65); every other instance must
+    # agree exactly: no allowance for "threshold sensitive" instances (tests/diagnostics/n40_sensitive.py lists none)
+    gave_up = np.nonzero(ref["status"] == -10)[0].tolist()
+    assert gave_up == [85, 291], gave_up
+    sane = ref["status"] != -10
+    assert np.array_equal(out["status"][sane], ref["status"][sane])
+    assert np.array_equal(out["iters"][sane], ref["iters"][sane])
     fin = np.isfinite(ref["uPred"]).all(axis=(1, 2)) & sane
     assert np.array_equal(fin, np.isfinite(out["uPred"]).all(axis=(1, 2)) & sane)
     d = np.abs(out["uPred"][fin] - ref["uPred"][fin]).max(axis=(1, 2))
-    assert np.mean(d <= 1e-6) >= 0.99 and np.max(d) <= 2e-3, (np.mean(d <= 1e-6), np.max(d))
+    assert np.max(d) <= 1e-6, (int(np.argmax(d)), float(np.max(d)))
 
 
 def test_maximum_horizon(lpvmpc):
@@ -503,3 +508,98 @@ def test_dropin_controller_with_steering_delay(lpvmpc):
     ctl.solve(c["x0"], 0.0, c["u_prev"], False, c["vel_ref"], A_L, B_L, C_L, 10)
     assert ctl.iters == int(c["iter_orc"]) and ctl.status_val == 1
     relclose(ctl.xPred, c["xPred"], 1e-6); relclose(ctl.uPred, c["uPred"], 1e-6)
+
+
+# ---- what bounds the unpinned OSQP stage ---------------------------------------------------
+def _bounds(c):
+    return np.where(c["l"] < -1e29, -np.inf, c["l"]), np.where(c["u"] > 1e29, np.inf, c["u"])
+
+
+@pytest.mark.parametrize("name", ["plan_n30_lshape", "plan_n40_lshape"])
+def test_planner_point_passes_osqp_stopping_rule_and_objective_gap(lpvmpc, name):
+    """The planner's returned point, checked without the oracle's solver: OSQP's termination test re-evaluated in numpy on the
+    device's primal point (with the multipliers of the same iteration) and the objective against the KKT-certified optimum
+    of the golden case (relative gap <= 1e-3, one-sided: an eps = 1e-3 iterate may undercut the optimum from slightly outside
+    the feasible set).  Until round 2 only the controller had this check."""
+    tab = lpvmpc.Map("L_shape", 0.2).PointAndTangent
+    checked = 0
+    for i, c in enumerate(cases(name)):
+        N = int(c["N"])
+        eng = lpvmpc.BatchedSolver("planner", N, float(c["dt"]), c["Q"], c["R"], c["dR"], L_cf=c["L_cf"], track=tab)
+        out = eng.solve_AB(c["x0"][None], c["A"][None], c["B"][None], None, np.zeros((1, 2)), max_ey=float(c["max_ey"]))
+        eng.close()
+        if int(out["status"][0]) != 1:
+            continue
+        l, u = _bounds(c)
+        z = np.concatenate([out["xPred"][0].reshape(-1), out["uPred"][0].reshape(-1)])
+        ok, info = kkt_cert.osqp_termination_ok(c["P"], c["q"], c["Aqp"], l, u, z, c["y_orc"])
+        assert ok, (name, i, info)
+        xs = c["x_star"]
+        if np.all(np.isfinite(xs)):
+            f = lambda v: 0.5 * v @ c["P"] @ v + c["q"] @ v
+            assert f(z) - f(xs) <= 1e-3 * max(1.0, abs(f(xs))), (name, i, f(z), f(xs))
+            checked += 1
+    assert checked >= 3
+
+
+@pytest.mark.parametrize("interval", [25, 50, 100])
+def test_rho_update_interval_sensitivity_on_the_device(lpvmpc, interval):
+    """adaptive_rho_interval is the one OSQP default that is machine dependent in the wheel (0 = from the measured set-up
+    time).  For 25 / 50 / 100 the device agrees with the oracle run at the same setting (status, iterations) and its result
+    stays inside the stated float tolerance: polished controller solves within 1e-3 of the KKT-certified optimum, un-polished
+    ones and the planner within OSQP's stopping rule and a 1e-3 relative objective gap (tests/test_oracle_osqp.py holds the
+    same test for the oracle alone)."""
+    from tests.test_oracle_osqp import check_against_optimum
+    oval, lsh = lpvmpc.Map("oval", 0.2).PointAndTangent, lpvmpc.Map("L_shape", 0.2).PointAndTangent
+    for name in ("ctrl_n10_cfg1", "ctrl_n20_oval", "ctrl_n20_delay"):
+        for i, c in enumerate(cases(name)):
+            N = int(c["N"])
+            hist = np.asarray(c["steer_hist"], float).reshape(-1) if "steer_hist" in c else np.zeros(0)
+            eng = lpvmpc.BatchedSolver("controller", N, float(c["dt"]), c["Q"], c["R"], c["dR"], track=oval,
+                                       steering_delay=len(hist), adaptive_rho_interval=interval)
+            u_old = np.concatenate([np.asarray(c["old_u"], float).reshape(-1), hist])[None]
+            out = eng.solve_AB(c["x0"][None], c["A"][None], c["B"][None], vfull(c)[None], u_old)
+            eng.close()
+            r = O.solve_qp(c["P"], c["q"], c["Aqp"], c["l"], c["u"], adaptive_rho_interval=interval)
+            assert (int(out["status"][0]), int(out["iters"][0]), int(out["polish"][0])) == (r.info.status_val, r.info.iter, r.info.status_polish), (name, i, interval)
+            z = np.concatenate([out["xPred"][0].reshape(-1), out["uPred"][0].reshape(-1)])
+            check_against_optimum(c, z, r.y, int(out["polish"][0]) == 1, 6, (name, i, interval))
+    for name in ("plan_n30_lshape", "plan_n40_lshape"):
+        for i, c in enumerate(cases(name)):
+            N = int(c["N"])
+            eng = lpvmpc.BatchedSolver("planner", N, float(c["dt"]), c["Q"], c["R"], c["dR"], L_cf=c["L_cf"], track=lsh,
+                                       adaptive_rho_interval=interval)
+            out = eng.solve_AB(c["x0"][None], c["A"][None], c["B"][None], None, np.zeros((1, 2)), max_ey=float(c["max_ey"]))
+            eng.close()
+            r = O.solve_qp(c["P"], c["q"], c["Aqp"], c["l"], c["u"], adaptive_rho_interval=interval)
+            assert (int(out["status"][0]), int(out["iters"][0])) == (r.info.status_val, r.info.iter), (name, i, interval)
+            if r.info.status_val == 1 and np.all(np.isfinite(c["x_star"])):
+                z = np.concatenate([out["xPred"][0].reshape(-1), out["uPred"][0].reshape(-1)])
+                check_against_optimum(c, z, r.y, False, 5, (name, i, interval))
+
+
+def test_curvature_lookup_failure_reaches_the_caller(lpvmpc):
+    """Where the reference's Curvature() raises (UTIL:44-48: no segment contains s -- s < 0, s exactly at the end of the closing
+    segment) the device lookup yields NaN: the LPV blocks are NaN, no iteration is run, the instance comes back UNSOLVED with
+    NaN outputs, its neighbours in the batch are untouched.  A far-ahead or non-finite abscissa (diverged roll-out) ends the same
+    way instead of spinning in the wrap loop."""
+    from lpvmpc import workloads
+    w = workloads.planner_batch(6, N=30, seed=5)
+    L_track = float(w["track"][-1, 3] + w["track"][-1, 4])
+    SS = w["curv_s"].copy()
+    SS[1, 3] = -0.5                      # no segment: the reference raises
+    SS[2, 0] = L_track                   # exactly the track length: not wrapped (s > L is false), not inside the last segment
+    SS[3, 7] = 1e12                      # would take 5e10 subtractions
+    SS[4, 2] = np.inf
+    eng = workloads.make_solver(w)
+    S, A, Bm = eng.lpv(w["x0"], w["u_prev"], None, SS)
+    out = eng.solve(w["x0"], w["u_prev"], None, SS, w["u_old"], w["max_ey"])
+    ref = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+    eng.close()
+    for b in (1, 2, 3, 4):
+        assert not np.all(np.isfinite(A[b])), b
+        assert int(out["status"][b]) == -10 and int(out["iters"][b]) == 0, (b, out["status"][b])
+        assert np.all(np.isnan(out["uPred"][b])) and np.all(np.isnan(out["xPred"][b]))
+    for b in (0, 5):
+        assert np.all(np.isfinite(A[b]))
+        assert np.array_equal(out["uPred"][b], ref["uPred"][b], equal_nan=True) and out["status"][b] == ref["status"][b]

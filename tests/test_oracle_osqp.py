@@ -111,3 +111,71 @@ def test_primal_infeasibility_verdicts_agree_with_an_lp_solver():
         assert (r.status == 0) == (st == 1), (b, st, r.status)
         seen[1 if st == 1 else -3] += 1
     assert seen[1] >= 10 and seen[-3] >= 8
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The one OSQP default this restatement cannot take from the wheel: adaptive_rho_interval = 0 means "decided from the measured
+# set-up time", i.e. machine dependent (the oracle, like the HIP path, fixes it at 25 = the first termination check).  What the
+# reference's results can depend on is bounded here: whatever multiple of the check interval OSQP would have picked, the
+# returned point stays within the float tolerance this package states: controller |u - u*| <= 1e-3 and
+# |x - x*| <= 1e-3 max(1, |x*|) against the KKT-certified optimum; planner: OSQP's own stopping rule and a relative objective
+# gap <= 1e-3 (one-sided; its QP is close to an LP, the distance to x* is reported, not gated).
+RHO_INTERVALS = (25, 50, 100)
+
+
+def check_against_optimum(c, x, y, polished, nx, tag):
+    """The float tolerance of this package: a polished controller solve is within 1e-3 of the
+    KKT-certified optimum (u absolutely, x relative to max(1, |x*|)); an un-polished one -- OSQP returns its ADMM iterate at
+    eps = 1e-3 -- satisfies OSQP's stopping rule and reaches the optimal objective to 1e-3 relative.  Returns (du, dx)."""
+    N = int(c["N"])
+    l, u = bounds(c)
+    xs, us, _ = L.unpack_solution(c["x_star"], nx, 2, N)
+    xr, ur, _ = L.unpack_solution(x, nx, 2, N)
+    du, dx = float(np.max(np.abs(ur - us))), float(np.max(np.abs(xr - xs)))
+    if polished:
+        assert du <= 1e-3, (tag, du)
+        assert dx <= 1e-3 * max(1.0, float(np.max(np.abs(xs)))), (tag, dx)
+    else:
+        if y is not None:
+            ok, info = kkt_cert.osqp_termination_ok(c["P"], c["q"], c["Aqp"], l, u, x, y)
+            assert ok, (tag, info)
+        f = lambda v: 0.5 * v @ c["P"] @ v + c["q"] @ v
+        assert f(x) - f(c["x_star"]) <= 1e-3 * max(1.0, abs(f(c["x_star"]))), tag      # one-sided, see the planner test
+    return du, dx
+
+
+@pytest.mark.parametrize("interval", RHO_INTERVALS)
+@pytest.mark.parametrize("name", ["ctrl_n10_cfg1", "ctrl_n20_oval", "ctrl_n20_delay"])
+def test_controller_result_is_insensitive_to_the_rho_update_interval(name, interval):
+    worst = [0.0, 0.0]
+    for i, c in enumerate(cases(name)):
+        r = O.solve_qp(c["P"], c["q"], c["Aqp"], c["l"], c["u"], adaptive_rho_interval=interval)
+        assert r.info.status_val == 1, (name, i, interval, r.info.status_val)
+        du, dx = check_against_optimum(c, r.x, r.y, r.info.status_polish == 1, 6, (name, i, interval))
+        if r.info.status_polish == 1:
+            worst = [max(worst[0], du), max(worst[1], dx)]
+    print("%s interval %d (polished runs): max |u - u*| = %.2e, max |x - x*| = %.2e" % (name, interval, worst[0], worst[1]))
+
+
+@pytest.mark.parametrize("interval", RHO_INTERVALS)
+@pytest.mark.parametrize("name", ["plan_n30_lshape", "plan_n40_lshape"])
+def test_planner_result_is_insensitive_to_the_rho_update_interval(name, interval):
+    base = {}
+    for i, c in enumerate(cases(name)):
+        l, u = bounds(c)
+        r = O.solve_qp(c["P"], c["q"], c["Aqp"], c["l"], c["u"], adaptive_rho_interval=interval)
+        infeasible_at_25 = int(c["status_orc"]) in (-3, 3)
+        # the verdict on feasibility does not depend on the interval
+        assert (r.info.status_val in (-3, 3)) == infeasible_at_25, (name, i, interval, r.info.status_val, int(c["status_orc"]))
+        if r.info.status_val != 1:
+            continue
+        ok, info = kkt_cert.osqp_termination_ok(c["P"], c["q"], c["Aqp"], l, u, r.x, r.y)
+        assert ok, (name, i, interval, info)
+        xs = c["x_star"]
+        if np.all(np.isfinite(xs)):
+            f = lambda x: 0.5 * x @ c["P"] @ x + c["q"] @ x
+            # one-sided: an eps = 1e-3 iterate may sit slightly outside the feasible set and undercut the optimum
+            assert f(r.x) - f(xs) <= 1e-3 * max(1.0, abs(f(xs))), (name, i, interval)
+            base[i] = float(np.max(np.abs(r.x - xs)))
+    if base:
+        print("%s interval %d: distance to x* (reported only) max %.2e" % (name, interval, max(base.values())))
