@@ -20,7 +20,8 @@ struct Tyre {
 
 __device__ inline Tyre tyre_terms(const DevCfg &c, double Cf, double Cr, double vx, double vy, double delta) {
     Tyre t;
-    const double sd = sin(delta), cd = cos(delta);
+    double sd, cd;
+    sincos(delta, &sd, &cd);           // one argument reduction for both (the roll-out is a serial chain of these calls)
     const double m = c.m, I = c.Iz, lf = c.lf, lr = c.lr;
     t.a12 = (sd * Cf) / (m * vx);
     t.a13 = (sd * Cf * lf) / (m * vx) + vy;
@@ -39,7 +40,8 @@ __device__ inline void ctrl_stage(const DevCfg &c, double Cf, double Cr, double 
                                   double ey, double cur, double delta, double ab[6][8]) {
     const Tyre t = tyre_terms(c, Cf, Cr, vx, vy, delta);
     const double dt = c.dt;
-    const double se = sin(epsi), ce = cos(epsi);
+    double se, ce;
+    sincos(epsi, &se, &ce);
     const double den = 1.0 - ey * cur;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
