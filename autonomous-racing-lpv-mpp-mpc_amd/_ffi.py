@@ -69,7 +69,7 @@ EXPORTS = ("lpvmpc_version", "lpvmpc_default_config", "lpvmpc_create", "lpvmpc_d
            "lpvmpc_solve_batch", "lpvmpc_solve_batch_dev", "lpvmpc_last_kernel_ms", "lpvmpc_set_timing",
            "lpvmpc_kernel_time_stats", "lpvmpc_set_option",
            "lpvmpc_local_position_batch", "lpvmpc_global_position_batch", "lpvmpc_plant_step_batch",
-           "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read", "lpvmpc_cl_release",
+           "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read", "lpvmpc_cl_release", "lpvmpc_join", "lpvmpc_resume_time_stats",
            "lpvmpc_handoff_default_config", "lpvmpc_handoff_length", "lpvmpc_handoff_operators", "lpvmpc_handoff_setup",
            "lpvmpc_handoff_batch", "lpvmpc_cascade_init", "lpvmpc_cascade_tick", "lpvmpc_cascade_read")
 
@@ -119,6 +119,8 @@ def load():
     lib.lpvmpc_cl_tick.argtypes = [vp, _i]
     lib.lpvmpc_cl_read.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.lpvmpc_cl_release.argtypes = [vp]
+    lib.lpvmpc_join.argtypes = [vp, vp]
+    lib.lpvmpc_resume_time_stats.argtypes = [vp, P(_d), P(_i)]
     lib.lpvmpc_handoff_default_config.argtypes = [P(HandoffConfig)]
     lib.lpvmpc_handoff_default_config.restype = None
     lib.lpvmpc_handoff_length.argtypes = [_i, _d, P(HandoffConfig)]
@@ -132,7 +134,7 @@ def load():
                  "lpvmpc_cascade_init", "lpvmpc_cascade_tick", "lpvmpc_cascade_read"):
         getattr(lib, name).restype = C.c_int
     for name in ("lpvmpc_local_position_batch", "lpvmpc_global_position_batch", "lpvmpc_plant_step_batch",
-                 "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read", "lpvmpc_cl_release"):
+                 "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read", "lpvmpc_cl_release", "lpvmpc_join", "lpvmpc_resume_time_stats"):
         getattr(lib, name).restype = C.c_int
     for name in ("lpvmpc_reserve", "lpvmpc_lpv_batch", "lpvmpc_estimate_abc_batch", "lpvmpc_solve_batch_AB",
                  "lpvmpc_solve_batch", "lpvmpc_solve_batch_dev", "lpvmpc_set_timing"):

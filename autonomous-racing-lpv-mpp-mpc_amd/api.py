@@ -129,6 +129,16 @@ class BatchedSolver:
     def last_kernel_ms(self):
         return float(self._lib.lpvmpc_last_kernel_ms(self._h))
 
+    def join(self, stream=0):
+        """Order ``stream`` behind the outstanding resume launches of the straggler deferral (option "defer_after"): the
+        outputs of the deferred calls are complete for work enqueued on ``stream`` afterwards."""
+        self._chk(self._lib.lpvmpc_join(self._h, C.c_void_p(int(stream))))
+
+    def resume_time_stats(self):
+        tot = C.c_double(0.0); n = C.c_int32(0)
+        self._chk(self._lib.lpvmpc_resume_time_stats(self._h, C.byref(tot), C.byref(n)))
+        return tot.value, n.value
+
     def kernel_time_stats(self):
         """(total_ms, launches) of the solve kernel since set_timing(True)."""
         tot, n = C.c_double(0.0), C.c_int32(0)

@@ -1206,8 +1206,70 @@ struct Solver {
     }
 
     // ---- the whole solve --------------------------------------------------------------------------
-    __device__ __forceinline__ void run(const SolveArgs &a, int inst) {
+    // ---- straggler deferral: park / restore (SolveArgs::defer_after, ::resume) ------------------------------------------
+    // A pool entry = the instance's LDS image followed by kParkScalars doubles {c, cinv, rho, iter, to_chk, to_adp}.  Everything
+    // the factorisation reads (scaled tiles, D / E, bounds, weights) is part of the image and does not change between set-up
+    // and the end of the ADMM loop, so factor() after a restore reproduces the registers of the uninterrupted run.
+    // where an instance's results go: the launch's arguments, or -- for a resumed instance -- the pointers its pool entry carries
+    // (a resume pass continues instances of several earlier calls).  Read where needed (uniform: scalar registers), not kept
+    // live through the ADMM loop.
+    struct Outs { double *xPred, *uPred; int32_t *status, *iters, *polish; double *resid, *state; };
+    __device__ __forceinline__ Outs outs_of(const SolveArgs &a, int entry) const {
+        if (entry < 0) return Outs{a.xPred, a.uPred, a.status, a.iters, a.polish, a.resid, a.state};
+        const unsigned long long *pw = reinterpret_cast<const unsigned long long *>(a.pool_in + (size_t)entry * a.pool_stride + lds_doubles(N) + 8);
+        auto word = [&](int i) {
+            const unsigned long long v = pw[i];
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return ((unsigned long long)hi << 32) | lo;
+        };
+        return Outs{(double *)word(0), (double *)word(1), (int32_t *)word(2), (int32_t *)word(3), (int32_t *)word(4), (double *)word(5), (double *)word(6)};
+    }
+    __device__ __forceinline__ bool try_park(const SolveArgs &a, int entry, int inst, int iter, int to_chk, int to_adp) {
+        if (tid == 0) RED[79] = (double)atomicAdd(a.pool_count, 1);
+        sync();
+        const int slot = (int)RED[79];
+        sync();
+        if (slot >= a.pool_cap) return false;                    // pool full: this instance simply goes on here
+        const int n = (int)lds_doubles(N);
+        double *dst = a.pool + (size_t)slot * a.pool_stride;
+        for (int i = tid; i < n; i += kStride) dst[i] = tA[i];          // tA is the base of the LDS block
+        if (tid == 0) {
+            double *sc = dst + n;
+            sc[0] = c; sc[1] = cinv; sc[2] = rho; sc[3] = (double)iter; sc[4] = (double)to_chk; sc[5] = (double)to_adp; sc[6] = (double)inst;
+            const Outs o = outs_of(a, entry);
+            unsigned long long *pw = reinterpret_cast<unsigned long long *>(sc + 8);
+            pw[0] = (unsigned long long)o.xPred; pw[1] = (unsigned long long)o.uPred; pw[2] = (unsigned long long)o.status;
+            pw[3] = (unsigned long long)o.iters; pw[4] = (unsigned long long)o.polish; pw[5] = (unsigned long long)o.resid;
+            pw[6] = (unsigned long long)o.state;
+            if (o.status) o.status[inst] = LPVMPC_PENDING_;
+            if (o.iters) o.iters[inst] = iter;
+        }
+        return true;
+    }
+    // restores entry `entry` of a.pool_in; returns the instance index
+    __device__ __forceinline__ int restore(const SolveArgs &a, int entry, int &iter, int &to_chk, int &to_adp) {
+        const int n = (int)lds_doubles(N);
+        const double *src = a.pool_in + (size_t)entry * a.pool_stride;
+        for (int i = tid; i < n; i += kStride) tA[i] = src[i];
+        const double *sc = src + n;
+        c = sc[0]; cinv = sc[1];
+        set_rho(sc[2]);
+        iter = (int)sc[3]; to_chk = (int)sc[4]; to_adp = (int)sc[5];
+        const int inst = __builtin_amdgcn_readfirstlane((int)sc[6]);
+        pol = false;
+        sync();
+        return inst;
+    }
+
+    // inst: instance index; entry: pool entry to continue (a.resume) or -1
+    __device__ __forceinline__ void run(const SolveArgs &a, int inst, int entry = -1) {
         bool bad = false;              // this thread saw a non-finite input word
+        const bool resuming = entry >= 0;
+        int iter0 = 1, to_chk0 = 0, to_adp0 = 0;
+        if (resuming) {
+            inst = restore(a, entry, iter0, to_chk0, to_adp0);
+            ++iter0;
+        } else {
         // ---------- load + build the unscaled problem ----------
         {   // weights -> LDS (the configuration block itself stays in global memory)
             double v = 0.0;
@@ -1287,9 +1349,12 @@ struct Solver {
         sync();
         cache_row_coefficients();
         set_rho(fmin(fmax(cfg.rho, kRhoMin), kRhoMax));
-        factor(cfg.sigma);
-        if (a.warm && a.state) warm_start(a.state + (size_t)inst * 3 * NS * 8, a.warm == 2);
-        recompute_w();                      // cold start: x = z = y = 0
+        }
+        factor(cfg.sigma);                      // first factorisation, or the one that puts a restored instance back into its registers
+        if (!resuming) {
+            if (a.warm && a.state) warm_start(a.state + (size_t)inst * 3 * NS * 8, a.warm == 2);
+            recompute_w();                      // cold start: x = z = y = 0
+        }
 
         // ---------- ADMM ----------
         const double alpha = cfg.alpha, sigma = cfg.sigma;
@@ -1303,8 +1368,9 @@ struct Solver {
         const int max_iter = cfg.max_iter, chk_every = cfg.check_termination > 0 ? cfg.check_termination : 0;
         const int adp_every = (cfg.adaptive_rho && cfg.adaptive_rho_interval > 0) ? cfg.adaptive_rho_interval : 0;
         const double rho_tol = cfg.rho_tol;
-        int to_chk = chk_every, to_adp = adp_every;
-        for (iter = 1; iter <= max_iter; ++iter) {
+        int to_chk = resuming ? to_chk0 : chk_every, to_adp = resuming ? to_adp0 : adp_every;
+        const int defer_after = a.defer_after > 0 ? (resuming ? iter0 - 1 + a.defer_after : a.defer_after) : 0;     // park at the first check at or beyond this iteration
+        for (iter = iter0; iter <= max_iter; ++iter) {
             checked = chk_every > 0 && --to_chk == 0;
             const bool adapt = adp_every > 0 && --to_adp == 0;
             if (checked) to_chk = chk_every;
@@ -1326,6 +1392,8 @@ struct Solver {
                     if (rn > rho * rho_tol || rn < rho / rho_tol) { set_rho(rn); factor(sigma); }
                 }
                 recompute_w();              // the residual evaluation used ZT* as scratch (and rho may have changed)
+                // straggler deferral: unsolved at this check and past the budget -> park and end the workgroup (block-uniform)
+                if (checked && defer_after > 0 && iter >= defer_after && iter < max_iter && try_park(a, entry, inst, iter, to_chk, to_adp)) return;
             }
         }
         if (iter > max_iter) iter = max_iter;
@@ -1342,7 +1410,8 @@ struct Solver {
         if (status == LPVMPC_DUAL_INFEASIBLE_ || status == LPVMPC_DUAL_INFEASIBLE_INACC_) obj = -kInfty;
 
         const double rho_admm = rho;
-        double *const st_out = a.state ? a.state + (size_t)inst * 3 * NS * 8 : nullptr;
+        const Outs o_ = outs_of(a, entry);
+        double *const st_out = o_.state ? o_.state + (size_t)inst * 3 * NS * 8 : nullptr;
         if (st_out) save_duals(st_out);        // ADMM duals (the polish below reuses the y arrays)
         // ---------- polish ----------
         if (cfg.polish && status == LPVMPC_SOLVED_) {
@@ -1361,31 +1430,31 @@ struct Solver {
         for (int e = opaque(tid); e < NS * 8; e += kStride) {
             const int k = e >> 3, r = e & 7;
             const double v = sol ? D[e] * X[e] : nan;
-            if (r < NX) a.xPred[((size_t)inst * NS + k) * NX + r] = v;
-            else if (r < NB && k < N) a.uPred[((size_t)inst * N + k) * 2 + (r - NX)] = v;
+            if (r < NX) o_.xPred[((size_t)inst * NS + k) * NX + r] = v;
+            else if (r < NB && k < N) o_.uPred[((size_t)inst * N + k) * 2 + (r - NX)] = v;
             if (st_out) st_out[e] = sol ? v : 0.0;
         }
         if (st_out && !sol) {      // no solution: do not seed the next solve with garbage
             for (int e = opaque(tid); e < NS * 8; e += kStride) { st_out[NS * 8 + e] = 0.0; st_out[2 * NS * 8 + e] = 0.0; }
         }
 #ifdef LPVMPC_STAMPS
-        if (tid == 0 && a.resid) {     // diagnostic build: resid carries per-iteration cycle counts instead
-            double *o = a.resid + (size_t)inst * 4;
+        if (tid == 0 && o_.resid) {     // diagnostic build: resid carries per-iteration cycle counts instead
+            double *o = o_.resid + (size_t)inst * 4;
 #if LPVMPC_STAMPS == 2
             o[0] = (double)stamp[4]; o[1] = (double)stamp[5]; o[2] = (double)stamp[6]; o[3] = (double)stamp[7];      // factor phases, summed over the solve
 #else
             o[0] = (double)stamp[0] / iter; o[1] = (double)stamp[1] / iter; o[2] = (double)stamp[2] / iter; o[3] = (double)stamp[3] / iter;
 #endif
-            if (a.status) a.status[inst] = status;
-            if (a.iters) a.iters[inst] = iter;
+            if (o_.status) o_.status[inst] = status;
+            if (o_.iters) o_.iters[inst] = iter;
             return;
         }
 #endif
         if (tid == 0) {
-            if (a.status) a.status[inst] = status;
-            if (a.iters) a.iters[inst] = iter;
-            if (a.polish) a.polish[inst] = status_polish;
-            if (a.resid) { double *o = a.resid + (size_t)inst * 4; o[0] = pri_res; o[1] = dua_res; o[2] = obj; o[3] = rho_admm; }
+            if (o_.status) o_.status[inst] = status;
+            if (o_.iters) o_.iters[inst] = iter;
+            if (o_.polish) o_.polish[inst] = status_polish;
+            if (o_.resid) { double *o = o_.resid + (size_t)inst * 4; o[0] = pri_res; o[1] = dua_res; o[2] = obj; o[3] = rho_admm; }
         }
     }
 
@@ -1521,10 +1590,14 @@ constexpr int min_waves_per_simd() { return (NW == 2 && NT <= 20) ? 2 : 1; }
 template <int NX, int NT, int NW, bool MF = false>
 __global__ void __launch_bounds__(64 * NW, (min_waves_per_simd<NT, NW>())) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
     extern __shared__ __align__(16) double smem[];
-    const int inst = blockIdx.x;
-    if (inst >= a.B) return;
+    int inst = blockIdx.x, entry = -1;
+    if (a.resume) {
+        const int n = *a.pool_in_count;
+        entry = blockIdx.x;
+        if (entry >= (n < a.pool_cap ? n : a.pool_cap)) return;
+    } else if (inst >= a.B) return;
     Solver<NX, NT, NW, MF> s(*cfgp, smem);
-    s.run(a, inst);
+    s.run(a, inst, entry);
 }
 
 template <int NX, int NT, int NW, bool MF = false>
@@ -1542,7 +1615,7 @@ static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveA
         if (err != hipSuccess) return err;
         word.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((admm_solve_kernel<NX, NT, NW, MF>), dim3(a.B), dim3(64 * NW), lds, stream, dcfg, a);
+    hipLaunchKernelGGL((admm_solve_kernel<NX, NT, NW, MF>), dim3(a.resume ? a.pool_cap : a.B), dim3(64 * NW), lds, stream, dcfg, a);
     return hipGetLastError();
 }
 

@@ -6,7 +6,10 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -69,6 +72,54 @@ static void free_ws(lpvmpc_handle *h) {
     h->cap = 0;
 }
 
+extern "C" int lpvmpc_join(lpvmpc_handle *h, void *stream);
+// ---- straggler deferral: the two pools ---------------------------------------------------------------------------------
+static void free_defer(lpvmpc_handle *h) {
+    for (int i = 0; i < 2; ++i) {
+        if (h->dpool[i]) (void)hipFree(h->dpool[i]);
+        if (h->dcount[i]) (void)hipFree(h->dcount[i]);
+        h->dpool[i] = nullptr; h->dcount[i] = nullptr;
+    }
+    h->defer_cur_cap = 0;
+}
+static int ensure_defer(lpvmpc_handle *h, int B, hipStream_t st) {
+    const int cap = h->defer_cap > 0 ? h->defer_cap : (B / 8 > 64 ? B / 8 : 64);
+    // an entry holds the LDS image of whichever kernel variant runs (the run-time-horizon kernel keeps its factor tiles in LDS:
+    // the largest image) plus the loop scalars and output pointers
+    const int stride = (h->cfg.N + 1) * (3 * lpvmpc::kTS + 19 * 8 + 8) + 16 + 64 + 8 + 80 + 64 + lpvmpc::kParkScalars;
+    if (h->dpool[0] && h->defer_cur_cap >= cap && h->defer_stride == stride) return LPVMPC_OK;
+    if (h->dpool[0]) {      // growing: finish what is parked in the old pools first
+        int rc = lpvmpc_join(h, (void *)(h->defer_stream ? h->defer_stream : st)); if (rc) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->defer_stream ? h->defer_stream : st));
+    }
+    free_defer(h);
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(h, hipMalloc((void **)&h->dpool[i], (size_t)cap * stride * 8));
+        HIP_TRY(h, hipMalloc((void **)&h->dcount[i], 4));
+        HIP_TRY(h, hipMemsetAsync(h->dcount[i], 0, 4, st));
+    }
+    if (!h->defer_event) HIP_TRY(h, hipEventCreateWithFlags(&h->defer_event, hipEventDisableTiming));
+    h->defer_cur_cap = cap; h->defer_stride = stride; h->dcur = 0;
+    return LPVMPC_OK;
+}
+// one resume pass on `st`: continues the entries of pool[dcur] for `budget` more iterations (0 = to completion), parks the
+// unfinished ones in the other pool, which becomes the current one
+static int resume_pass(lpvmpc_handle *h, int budget, hipStream_t st) {
+    const int A = h->dcur, Bp = 1 - A;
+    SolveArgs a{};
+    a.B = h->defer_cur_cap; a.resume = 1; a.defer_after = budget;
+    a.pool_in = h->dpool[A]; a.pool_in_count = h->dcount[A];
+    a.pool = h->dpool[Bp]; a.pool_count = h->dcount[Bp];
+    a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride; a.x0_stride = h->nx;
+    const int slot = h->rv_count % 1024;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->rv0[slot], st));
+    HIP_TRY(h, lpvmpc::launch_solve(h->dev, h->d_cfg, a, st, h->force_generic));
+    if (h->timing) { HIP_TRY(h, hipEventRecord(h->rv1[slot], st)); h->rv_count++; }
+    HIP_TRY(h, hipMemsetAsync(h->dcount[A], 0, 4, st));             // pool A has been consumed
+    h->dcur = Bp;
+    return LPVMPC_OK;
+}
+
 static int ensure_ws(lpvmpc_handle *h, int B) {
     if (B <= h->cap) return LPVMPC_OK;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -109,6 +160,8 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->d_status = h->d_iters = h->d_polish = nullptr; h->d_state = nullptr; h->warm_mode = 0; h->state_valid_B = 0;
     h->cl_plant = h->cl_local = h->cl_cmd = nullptr; h->cl_B = 0; h->cl_first_it = 1; h->cl_q9 = 1; h->cl_ticks = 0;
     h->d_Wop = h->d_FWop = nullptr; h->ho_M = 0; h->cascade = nullptr; h->cascade_owner = nullptr; h->cascade_prefetch = 1;
+    h->defer_after = 0; h->defer_budget = 200; h->defer_cap = 0; h->defer_cur_cap = 0; h->defer_stride = 0; h->rv_count = 0;
+    h->dpool[0] = h->dpool[1] = nullptr; h->dcount[0] = h->dcount[1] = nullptr; h->dcur = 0; h->defer_stream = nullptr; h->defer_event = nullptr;
     h->h_pack_in = h->h_pack_out = h->d_pack_in = h->d_pack_out = nullptr;
     DevCfg &d = h->dev;
     std::memset(&d, 0, sizeof(d));
@@ -158,6 +211,10 @@ extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
     if (h->d_Wop) (void)hipFree(h->d_Wop);
     if (h->d_FWop) (void)hipFree(h->d_FWop);
     if (h->d_cfg) (void)hipFree(h->d_cfg);
+    free_defer(h);
+    if (h->defer_event) (void)hipEventDestroy(h->defer_event);
+    for (hipEvent_t e : h->rv0) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->rv1) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
     delete h;
@@ -174,6 +231,21 @@ extern "C" int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t val
         h->warm_mode = value; h->state_valid_B = 0; return LPVMPC_OK;
     }
     if (std::strcmp(name, "kernel_variant") == 0) { if (value < 0 || value > 3) return fail(h, LPVMPC_E_ARG, "kernel_variant must be 0, 1, 2 or 3"); h->force_generic = value; return LPVMPC_OK; }
+    if (std::strcmp(name, "defer_after") == 0) {
+        if (value < 0) return fail(h, LPVMPC_E_ARG, "defer_after must be >= 0 (iterations; 0 = off)");
+        if (value == 0 && h->defer_after > 0 && h->dpool[0]) { int rc = lpvmpc_join(h, (void *)h->defer_stream); if (rc) return rc; }   // nothing stays parked
+        h->defer_after = value; return LPVMPC_OK;
+    }
+    if (std::strcmp(name, "defer_budget") == 0) {
+        if (value < 0) return fail(h, LPVMPC_E_ARG, "defer_budget must be >= 0 (iterations per resume pass; 0 = every pass runs to completion)");
+        h->defer_budget = value; return LPVMPC_OK;
+    }
+    if (std::strcmp(name, "defer_pool") == 0) {
+        if (value < 0) return fail(h, LPVMPC_E_ARG, "defer_pool must be >= 0 (pool entries; 0 = max(64, B / 8))");
+        HIP_TRY(h, hipSetDevice(h->cfg.device));
+        if (h->dpool[0]) { int rc = lpvmpc_join(h, (void *)h->defer_stream); if (rc) return rc; HIP_TRY(h, hipStreamSynchronize(h->defer_stream)); }
+        free_defer(h); h->defer_cap = value; return LPVMPC_OK;
+    }
     if (std::strcmp(name, "cascade_prefetch") == 0) { h->cascade_prefetch = value != 0 ? 1 : 0; return LPVMPC_OK; }   // read by lpvmpc_cascade_init
     return fail(h, LPVMPC_E_ARG, "lpvmpc_set_option: unknown option '%s'", name);
 }
@@ -192,7 +264,11 @@ extern "C" int lpvmpc_set_timing(lpvmpc_handle *h, int32_t on) {
         h->ev0.resize(kEventRing); h->ev1.resize(kEventRing);
         for (int i = 0; i < kEventRing; ++i) { HIP_TRY(h, hipEventCreate(&h->ev0[i])); HIP_TRY(h, hipEventCreate(&h->ev1[i])); }
     }
-    h->timing = on != 0; h->ev_count = 0; h->last_ms = -1.0;
+    if (on && h->rv0.empty()) {
+        h->rv0.resize(kEventRing); h->rv1.resize(kEventRing);
+        for (int i = 0; i < kEventRing; ++i) { HIP_TRY(h, hipEventCreate(&h->rv0[i])); HIP_TRY(h, hipEventCreate(&h->rv1[i])); }
+    }
+    h->timing = on != 0; h->ev_count = 0; h->rv_count = 0; h->last_ms = -1.0;
     return LPVMPC_OK;
 }
 
@@ -431,8 +507,52 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
     rc = launch_lpv(h, B, x0, u_prev, vel_ref, curv_s, cf_new, lap, nullptr, h->d_AB, st); if (rc) return rc;
     SolveArgs a{B, x0, h->d_AB, ctrl ? vel_ref : nullptr, u_old, ctrl ? nullptr : max_ey, xPred, uPred, status, iters, polish, resid,
                 h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0, h->nx};
-    rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
+    if (h->defer_after > 0) {
+        // Straggler deferral: this launch parks what is still unsolved after defer_after iterations; the resume pass behind it
+        // (same stream) continues everything that is parked on this handle -- from this call and from earlier ones -- for
+        // defer_budget more iterations.  No launch lasts much longer than its budget, so the stream is never held by one slow
+        // instance; lpvmpc_join runs the pass that finishes whatever is still parked.
+        rc = ensure_defer(h, B, st); if (rc) return rc;
+        if (h->defer_stream && h->defer_stream != st) {            // the pools are ordered by stream: hand them over
+            HIP_TRY(h, hipEventRecord(h->defer_event, h->defer_stream));
+            HIP_TRY(h, hipStreamWaitEvent(st, h->defer_event, 0));
+        }
+        h->defer_stream = st;
+        a.defer_after = h->defer_after; a.resume = 0; a.pool = h->dpool[h->dcur]; a.pool_count = h->dcount[h->dcur];
+        a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride;
+        rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
+        rc = resume_pass(h, h->defer_budget, st); if (rc) return rc;
+    } else {
+        rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
+    }
     if (h->warm_mode) h->state_valid_B = B;
+    return LPVMPC_OK;
+}
+
+extern "C" int lpvmpc_join(lpvmpc_handle *h, void *stream) {
+    if (!h) return fail(nullptr, LPVMPC_E_ARG, "lpvmpc_join: handle is NULL");
+    if (!h->dpool[0]) return LPVMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    if (h->defer_stream && h->defer_stream != st) {
+        HIP_TRY(h, hipEventRecord(h->defer_event, h->defer_stream));
+        HIP_TRY(h, hipStreamWaitEvent(st, h->defer_event, 0));
+    }
+    h->defer_stream = st;
+    return resume_pass(h, 0, st);                                  // to completion: nothing stays parked
+}
+
+extern "C" int lpvmpc_resume_time_stats(lpvmpc_handle *h, double *total_ms, int32_t *count) {
+    if (!h || !total_ms || !count) return LPVMPC_E_ARG;
+    const int n = h->rv_count < kEventRing ? h->rv_count : kEventRing;
+    double tot = 0.0;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventSynchronize(h->rv1[i]));
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->rv0[i], h->rv1[i]));
+        tot += ms;
+    }
+    *total_ms = tot; *count = n;
     return LPVMPC_OK;
 }
 

@@ -62,7 +62,23 @@ struct SolveArgs {
     double *state;          // [B][3][8(N+1)] unscaled x, y(dynamics rows), y(box rows) of the previous solve, or null
     int warm;               // 0 cold start (reference behaviour), 1 warm start from state, 2 same shifted by one stage
     int x0_stride;          // doubles between consecutive instances' x0 (NX, or N*NX when x0 = first rolled-out state)
+    // straggler deferral (lpvmpc_set_option "defer_after"): an instance that is still unsolved at a termination check after its
+    // iteration budget is PARKED -- its whole LDS image, loop state and output pointers go to a pool entry -- and the workgroup
+    // ends; a later launch of the same kernel with resume = 1 (one workgroup per entry of pool_in) restores it, re-factors K
+    // with the saved rho (a pure function of the saved image, so the iterates continue bit for bit) and runs it for another
+    // budget (parking it again in pool) or to completion (defer_after = 0).
+    int defer_after;        // main launch: park at the first check with iter >= defer_after; resume launch: after that many more
+                            // iterations; 0: run to completion
+    int resume;             // 1: continue the parked instances of pool_in (blockIdx.x = entry)
+    double *pool;           // [pool_cap][pool_stride] entries written by this launch
+    int32_t *pool_count;    // entries requested so far in pool (may exceed pool_cap: the surplus instances were not parked)
+    const double *pool_in;  // resume: entries to continue
+    const int32_t *pool_in_count;
+    int pool_cap, pool_stride;
 };
+constexpr int kParkScalars = 16;     // behind the LDS image of a pool entry: c, cinv, rho, iter, to_chk, to_adp, instance index and the
+                                     // instance's output pointers (xPred, uPred, status, iters, polish, resid, state) as 64-bit words
+constexpr int LPVMPC_PENDING_ = -11; // status of a parked instance until its resume launch has finished it (lpvmpc.h: LPVMPC_PENDING)
 
 // host-side launchers (defined next to their kernels)
 int solve_has_fast_path(int kind, int N);

@@ -47,6 +47,18 @@ struct lpvmpc_handle {
     // planner -> controller hand-off operators (lpvmpc_handoff_setup, planner handles): [M][N] row-major each
     double *d_Wop, *d_FWop;
     int ho_M;
+    // straggler deferral (options "defer_after" / "defer_budget" / "defer_pool", lpvmpc_solve_batch_dev only): two pools of
+    // parked instances used alternately -- launches park into pool[dcur], the resume pass that follows continues the entries
+    // of pool[dcur] and parks what is still unsolved after its budget into the other pool, which becomes dcur
+    int defer_after, defer_budget, defer_cap;   // iterations before parking (0 = off); iterations per resume pass; pool entries (0 = default)
+    int defer_cur_cap, defer_stride;
+    double *dpool[2];
+    int32_t *dcount[2];
+    int dcur;
+    hipStream_t defer_stream;           // stream of the last deferred call (lpvmpc_join orders against it)
+    hipEvent_t defer_event;
+    std::vector<hipEvent_t> rv0, rv1;   // event pairs around the resume launches (timing)
+    int rv_count;
     int cascade_prefetch;               // option "cascade_prefetch" (default 1)
     lpvmpc_cascade *cascade;            // owned by the controller handle of a cascade (lpvmpc_cascade_init)
     lpvmpc_handle *cascade_owner;       // planner handle: the controller handle whose cascade drives it (its workspace carries the planner recursion)

@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU (default: configs[1] = 1024)")
-    ap.add_argument("--streams", type=int, default=64,
+    ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the K steps are issued on round-robin (independent batches overlap, so the few "
                          "slow instances of one batch do not leave the GPU idle); 1 = strictly back-to-back steps")
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
@@ -57,6 +57,13 @@ def main():
                          "planner, N=20; cfg5 = configs[4]: planner + controller + plant cascade, a step is one 30 Hz "
                          "controller tick of --batch vehicles per GPU (default 8192 / gpus) -- extra measurements, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--defer", type=int, default=-1,
+                    help="straggler deferral (lpvmpc_set_option defer_after): an instance still unsolved after this many ADMM "
+                         "iterations is parked and continued, --defer-budget iterations at a time, by the resume pass that follows "
+                         "every step on the same stream, so the few many-thousand-iteration instances do not hold the step's stream; "
+                         "the timed region ends with the passes that finish everything (lpvmpc_join); 0 = off (every launch lasts as "
+                         "long as its slowest instance); default: 100 for the headline workload, 0 otherwise")
+    ap.add_argument("--defer-budget", type=int, default=100, help="iterations per resume pass of the straggler deferral (0 = to completion)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs outside the timed region (serial steps, batch latencies, one launch of all distinct "
                          "instances, single-solve latency): what the profiling passes use")
@@ -66,6 +73,10 @@ def main():
                     help="exercise the launcher, the sharding and the collectives with the gloo backend and no device work "
                          "(CPU test of the N > 1 path; the printed line carries \"dry_run\": true and no measurement)")
     args = ap.parse_args()
+    if args.defer < 0:
+        args.defer = 100 if args.workload == "cfg2" else 0
+    if args.streams <= 0:
+        args.streams = 4 if args.defer > 0 else 64          # with deferral no launch is long: a few streams fill the GPU
 
     # --gpus N given to a plain `python bench.py`: become the launcher.  Nothing has touched the GPU yet (torch is not
     # even imported), the children are fresh processes (never an exec of a process that initialised HIP).
@@ -75,9 +86,9 @@ def main():
         return dry_run(args)
 
     # independent batches are pipelined over several HIP streams; give the runtime as many hardware queues
-    # (16 hardware queues: with 8, the streams that share a queue with a launch holding a many-thousand-iteration instance wait
+    # (without deferral: 16 hardware queues; with 8, the streams that share a queue with a launch holding a many-thousand-iteration instance wait
     # behind it; beyond ~20 the queues are time-sliced and every launch slows down -- tools/queue_sweep.sh)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(16, args.streams))))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if args.defer > 0 else str(max(4, min(16, args.streams))))
     import numpy as np
     import torch                      # first: liblpvmpc then binds to the HIP runtime torch loaded
     import torch.distributed as dist
@@ -111,8 +122,9 @@ def main():
     # re-solve the same 1024 instances and the rare many-thousand-iteration instances of the distribution are part of the
     # measurement.  Steps issued on different streams are independent.
     S = max(1, args.streams)
+    NBAT = max(S, 32)                                   # distinct input batches (seeds) the steps cycle through
     make = workloads.planner_batch if planner else workloads.controller_batch
-    ws = [make(B, N=N, seed=(1 if planner else 0) + i + 1000 * rank) for i in range(S)]
+    ws = [make(B, N=N, seed=(1 if planner else 0) + i + 1000 * rank) for i in range(NBAT)]
     w = ws[0]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     ins = [dict(x0=t(wi["x0"]), u_prev=t(wi["u_prev"]), curv=t(wi["curv_s"]), u_old=t(wi["u_old"]),
@@ -120,6 +132,8 @@ def main():
     engines = [workloads.make_solver(w, device=local_rank) for _ in range(S)]
     for e in engines:
         e.set_option("kernel_variant", args.kernel_variant)
+        e.set_option("defer_after", args.defer)
+        e.set_option("defer_budget", args.defer_budget)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
 
     def new_outs(n):
@@ -127,31 +141,38 @@ def main():
                     uPred=torch.empty((n, N, 2), dtype=torch.float64, device=dev),
                     status=torch.empty(n, dtype=torch.int32, device=dev), iters=torch.empty(n, dtype=torch.int32, device=dev),
                     resid=torch.empty((n, 4), dtype=torch.float64, device=dev), polish=torch.empty(n, dtype=torch.int32, device=dev))
-    outs = []
     for e in engines:
         e.reserve(B)
-        outs.append(new_outs(B))
+    outs = [new_outs(B) for _ in range(NBAT)]            # one output set per input batch (a deferred instance writes its results late)
     counter = [0]
-    ran = [False] * S                                   # slot i has solved its whole batch at least once (its outputs are valid)
 
-    def solve_slot(i, n=B):
+    def solve_slot(i, n=B, e=None):
+        """Batch i (inputs and outputs i) on engine / stream e (default i mod S)."""
+        e = i % S if e is None else e
         o, d = outs[i], ins[i]
-        engines[i].solve_dev(n, d["x0"], d["u_prev"], d["vel_ref"], d["curv"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"],
+        engines[e].solve_dev(n, d["x0"], d["u_prev"], d["vel_ref"], d["curv"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"],
                              o["status"], o["iters"], o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"],
-                             stream=streams[i].cuda_stream)
-        if n == B:
-            ran[i] = True
+                             stream=streams[e].cuda_stream)
 
     def step():
-        i = counter[0] % S
+        j = counter[0]
         counter[0] += 1
-        solve_slot(i)
-        return i
+        solve_slot(j % NBAT, e=j % S)
+        return j % NBAT
 
     def fence():
+        if args.defer > 0:                       # finish what the straggler deferral still holds: part of the work being timed
+            for i, e in enumerate(engines):
+                e.join(streams[i].cuda_stream)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+        torch.cuda.synchronize()
+
+    def sync():
+        if args.defer > 0:
+            for i, e in enumerate(engines):
+                e.join(streams[i].cuda_stream)
         torch.cuda.synchronize()
 
     # set-up, not a step: a one-instance solve on every stream so that its hardware queue, the kernel's code object and the
@@ -159,7 +180,7 @@ def main():
     # the driver asks for fewer warm-up steps than there are streams)
     for i in range(S):
         solve_slot(i, 1)
-    torch.cuda.synchronize()
+    sync()
     for _ in range(args.warmup):
         step()
     for e in engines:
@@ -170,9 +191,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     k_ms = k_n = 0
+    r_ms = r_n = 0
     for e in engines:
         ms_, n_ = e.kernel_time_stats()
         k_ms += ms_; k_n += n_
+        if args.defer > 0:
+            ms_, n_ = e.resume_time_stats()
+            r_ms += ms_; r_n += n_
         e.set_timing(False)
     used = sorted(set(timed_slots))
     it_slot = {i: outs[i]["iters"].cpu().numpy().astype(np.int64) for i in used}
@@ -181,6 +206,11 @@ def main():
     bytes_slot = {i: algorithmic_bytes(it_slot[i], N=N, nx=nx, m_rows=m_rows)[0] for i in used}
     bytes_iter = algorithmic_bytes(it_slot[used[0]], N=N, nx=nx, m_rows=m_rows)[1]
     bytes_timed = float(sum(bytes_slot[i] for i in timed_slots))            # algorithmic bytes of exactly the K timed launches
+    # with straggler deferral a launch on the step's stream runs an instance for at most Kp iterations (the first termination
+    # check at or beyond defer_after); the rest of a parked instance's iterations belong to its resume launch
+    Kp = -(-args.defer // 25) * 25 if args.defer > 0 else 0
+    main_bytes_slot = {i: (algorithmic_bytes(np.minimum(it_slot[i], Kp), N=N, nx=nx, m_rows=m_rows)[0] if Kp else bytes_slot[i]) for i in used}
+    main_bytes_timed = float(sum(main_bytes_slot[i] for i in timed_slots))
     iters_timed = float(sum(it_slot[i].sum() for i in timed_slots))
     solved_timed = float(sum((st_slot[i] == 1).sum() for i in timed_slots))
 
@@ -188,56 +218,54 @@ def main():
     if not args.no_extras:
         # round 1's protocol for continuity: the same K steps with EVERY slot solving the seed-0 batch (no instance beyond 700
         # iterations), same streams and engines -- kernel progress separated from the change of protocol
-        torch.cuda.synchronize(); t1 = time.perf_counter()
+        sync(); t1 = time.perf_counter()
         for j in range(args.steps):
-            i = j % S
-            o, d = outs[i], ins[0]
-            engines[i].solve_dev(B, d["x0"], d["u_prev"], d["vel_ref"], d["curv"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"],
+            e = j % S
+            o, d = outs[j % NBAT], ins[0]
+            engines[e].solve_dev(B, d["x0"], d["u_prev"], d["vel_ref"], d["curv"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"],
                                  o["status"], o["iters"], o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"],
-                                 stream=streams[i].cuda_stream)
-        torch.cuda.synchronize()
+                                 stream=streams[e].cuda_stream)
+        sync()
         extras["seed0_replicated_solves_per_s"] = B * args.steps / (time.perf_counter() - t1)
         # strictly serial steps on ONE stream (every step waits for its predecessor's slowest instance), batches of slots 0, 1, ...
         n_serial = min(args.steps, 20)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
+        sync(); t1 = time.perf_counter()
         for j in range(n_serial):
-            o, d = outs[j % S], ins[j % S]
-            engines[0].solve_dev(B, d["x0"], d["u_prev"], d["vel_ref"], d["curv"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"],
-                                 o["status"], o["iters"], o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"],
-                                 stream=streams[0].cuda_stream)
-        torch.cuda.synchronize()
+            solve_slot(j % NBAT, e=0)
+        sync()
         extras["single_stream_solves_per_s_per_gpu"] = B * n_serial / (time.perf_counter() - t1)
         # latency of one synchronous batch: every distinct batch once (p50 over batches), and the seed-0 batch alone
         lat = []
-        for i in range(S):
-            torch.cuda.synchronize(); t1 = time.perf_counter(); solve_slot(i); torch.cuda.synchronize()
+        for i in range(NBAT):
+            sync(); t1 = time.perf_counter(); solve_slot(i); sync()
             lat.append((time.perf_counter() - t1) * 1e3)
         extras["p50_batch_latency_ms"] = float(np.median(lat))
         extras["max_batch_latency_ms"] = float(np.max(lat))
         l0 = []
         for _ in range(7):
-            torch.cuda.synchronize(); t1 = time.perf_counter(); solve_slot(0); torch.cuda.synchronize()
+            sync(); t1 = time.perf_counter(); solve_slot(0); sync()
             l0.append((time.perf_counter() - t1) * 1e3)
         extras["seed0_batch_latency_ms"] = float(np.median(l0))
         # isolated launches of the seed-0 batch (nothing else on the GPU): the per-launch kernel time without neighbours
         engines[0].set_timing(True)
         for _ in range(5):
-            solve_slot(0); torch.cuda.synchronize()
+            solve_slot(0); sync()
         ms_, n_ = engines[0].kernel_time_stats(); engines[0].set_timing(False)
         iso_ms = ms_ / max(n_, 1)
         it0 = outs[0]["iters"].cpu().numpy().astype(np.int64)
         extras["isolated_seed0_launch"] = {"kernel_avg_ms": iso_ms, "launches": n_,
-                                           "frac": algorithmic_bytes(it0, N=N, nx=nx, m_rows=m_rows)[0] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                           "max_admm_iters": int(it0.max())}
-        # ONE launch of all the distinct instances of this rank (S x B; 32768 at the defaults): one workspace, one stream
-        if not planner and S * B <= 65536:
+                                           "frac": algorithmic_bytes(np.minimum(it0, Kp) if Kp else it0, N=N, nx=nx, m_rows=m_rows)[0] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "max_admm_iters": int(it0.max()),
+                                           "counts": ("the main launch and the iterations it runs (an instance's first %d)" % Kp) if Kp else "the whole solve"}
+        # ONE plain launch (no deferral) of all the distinct instances of this rank (32 x B = 32768 at the defaults): one workspace, one stream
+        if not planner and NBAT * B <= 65536:
             cat = lambda k: None if ins[0][k] is None else torch.cat([d[k] for d in ins], dim=0)
             big_in = {k: cat(k) for k in ("x0", "u_prev", "vel_ref", "curv", "u_old", "max_ey")}
             big = workloads.make_solver(w, device=local_rank); big.set_option("kernel_variant", args.kernel_variant)
-            big.reserve(S * B); bo = new_outs(S * B)
+            big.reserve(NBAT * B); bo = new_outs(NBAT * B)
 
             def big_launch():
-                big.solve_dev(S * B, big_in["x0"], big_in["u_prev"], big_in["vel_ref"], big_in["curv"], big_in["u_old"], big_in["max_ey"],
+                big.solve_dev(NBAT * B, big_in["x0"], big_in["u_prev"], big_in["vel_ref"], big_in["curv"], big_in["u_old"], big_in["max_ey"],
                               bo["xPred"], bo["uPred"], bo["status"], bo["iters"], bo["resid"], bo["polish"], cf_new=w["cf_new"],
                               lap=w["lap"], stream=streams[0].cuda_stream)
             big_launch(); torch.cuda.synchronize()
@@ -245,7 +273,7 @@ def main():
             for _ in range(3):
                 t1 = time.perf_counter(); big_launch(); torch.cuda.synchronize(); tb.append(time.perf_counter() - t1)
             bi = bo["iters"].cpu().numpy().astype(np.int64)
-            extras["single_launch"] = {"instances": S * B, "solves_per_s": S * B / float(np.median(tb)), "ms": float(np.median(tb)) * 1e3,
+            extras["single_launch"] = {"instances": NBAT * B, "solves_per_s": NBAT * B / float(np.median(tb)), "ms": float(np.median(tb)) * 1e3,
                                        "max_admm_iters": int(bi.max()),
                                        "frac": algorithmic_bytes(bi, N=N, nx=nx)[0] / float(np.median(tb)) / 1e9 / HBM_PEAK_GBS}
             big.close()
@@ -270,7 +298,7 @@ def main():
     if rank == 0:
         total = B * world * args.steps
         k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
-        bytes_launch = bytes_timed / max(args.steps, 1)         # mean algorithmic bytes of a timed launch (rank 0)
+        bytes_launch = main_bytes_timed / max(args.steps, 1)    # mean algorithmic bytes of a timed launch on the step's stream (rank 0)
         achieved = bytes_launch / k_avg_s / 1e9 if k_n else float("nan")
         pmc = load_pmc(B, planner)
         out = {
@@ -290,8 +318,8 @@ def main():
                                          "oval, racing tuning, OSQP defaults + polish, cold start" % B) if not planner else
                                         ("configs[2]: batch=%d LPV-MPP planner solves per GPU (velocity-max cost), N=30, "
                                          "L-shape track, OSQP defaults + polish, cold start" % B),
-                            "batch_per_gpu": B, "horizon": N, "nx": nx, "nu": 2, "streams": S,
-                            "distinct_batches_timed": len(used), "batch_seeds": "slot i = seed %d + i + 1000 rank" % (1 if planner else 0),
+                            "batch_per_gpu": B, "horizon": N, "nx": nx, "nu": 2, "streams": S, "defer_after": args.defer,
+                            "distinct_batches_timed": len(used), "batch_seeds": "step j solves batch j mod %d = seed %d + (j mod %d) + 1000 rank" % (NBAT, 1 if planner else 0, NBAT),
                             "mean_admm_iters": agg[0] / total,
                             "max_admm_iters_rank0": int(max(it_slot[i].max() for i in used)),
                             "solved_fraction": agg[1] / total}, **extras),
@@ -301,6 +329,13 @@ def main():
                          "valu": pmc.get("valu"), "valu_source": pmc.get("source") if pmc.get("valu") else None,
                          "kernel": "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, "" if planner or args.kernel_variant == 3 else ", MFMA sweeps"),
                          "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
+                         "resume_launches": ({"count": r_n, "avg_ms": r_ms / max(r_n, 1),
+                                              "note": "straggler deferral: the launches counted above park what is unsolved after %d iterations; "
+                                                      "these passes of the same kernel (one behind every step, plus the closing lpvmpc_join passes) "
+                                                      "continue the parked instances %d iterations at a time (a few workgroups each).  "
+                                                      "algorithmic_bytes_per_launch and frac count only the iterations the main launch runs (an "
+                                                      "instance's first %d); aggregate_* count all" % (args.defer, args.defer_budget, Kp),
+                                              "algorithmic_bytes_per_batch_all_iterations": bytes_timed / max(args.steps, 1)} if args.defer > 0 else None),
                          "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_admm_iteration": bytes_iter,
                          "aggregate_algorithmic_GBps": agg[2] / elapsed / 1e9,
                          "aggregate_frac_per_gpu": bytes_timed / elapsed / 1e9 / HBM_PEAK_GBS,

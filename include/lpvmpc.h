@@ -57,6 +57,8 @@ extern "C" {
 #define LPVMPC_NON_CVX                      -7
 #define LPVMPC_UNSOLVED                    -10      /* also: non-finite input data (NaN / Inf in x0, A, B, vel_ref, uOld,
                                                       max_ey) -- no iteration is run, xPred / uPred are NaN, iters = 0 */
+#define LPVMPC_PENDING                     -11      /* straggler deferral only (option "defer_after"): the instance was parked by the
+                                                      * main launch; its resume launch has not written the final status yet */
 
 typedef struct lpvmpc_config {
     int32_t kind;            /* LPVMPC_KIND_* */
@@ -117,8 +119,27 @@ int lpvmpc_last_error_code(void);
  * "warm_start": 0 = every solve starts from x = z = y = 0 like the reference (fresh OSQP object per call,
  * CTRL:302,316 / PLAN:204-208; default); 1 = start from the previous solve's (x, y) of the same handle and
  * batch size; 2 = the same shifted by one stage (receding horizon).  Opt-in, changes iteration counts, not optima.
- * "cascade_prefetch" (0/1, default 1): read by lpvmpc_cascade_init on the controller handle, see there. */
+ * "cascade_prefetch" (0/1, default 1): read by lpvmpc_cascade_init on the controller handle, see there.
+ * "kernel_variant" 3 = the DPP two-wavefront controller kernel of round 1 (the default N = 20 controller kernel runs its KKT
+ * sweeps on the matrix cores).
+ * "defer_after" (iterations, 0 = off, default): STRAGGLER DEFERRAL for lpvmpc_solve_batch_dev.  One OSQP solve in a thousand
+ * needs thousands of ADMM iterations where the typical one needs 50; a launch lasts as long as its slowest instance, so those
+ * few hold the caller's stream for milliseconds.  With defer_after = K an instance that is still unsolved at a termination
+ * check with iter >= K is parked (status LPVMPC_PENDING, whole solver state saved) and the launch ends.  Every deferred call
+ * is followed, on the same stream, by a resume pass of the same kernel that continues everything parked on the handle -- from
+ * this call and from earlier ones -- for "defer_budget" more iterations (default 200; 0 = to completion) and parks again what
+ * is still unsolved.  Results are bit-identical to the plain call (a restored instance re-factors K from its saved state).
+ * Completion contract: an instance's outputs are final when its status is no longer LPVMPC_PENDING; lpvmpc_join(h, stream)
+ * enqueues the pass that finishes whatever is still parked, so work behind it in `stream` sees complete outputs.  Until then
+ * the output buffers of the deferred calls must stay valid and must not be reused for other data.
+ * "defer_pool" (entries, 0 = max(64, B / 8), default): capacity of each of the two pools; instances that find the pool full
+ * are not parked (they finish inside the launch that holds them). */
 int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value);
+/* Straggler deferral (see "defer_after"): enqueues on `stream` (a hipStream_t; ordered behind the stream of the handle's last
+ * deferred call if it is another one) the resume pass that runs every parked instance to completion.  No-op without deferral. */
+int lpvmpc_join(lpvmpc_handle *h, void *stream);
+/* Like lpvmpc_kernel_time_stats (below) for the resume launches of the straggler deferral. */
+int lpvmpc_resume_time_stats(lpvmpc_handle *h, double *total_ms, int32_t *count);
 
 /* Pre-size the device workspace for batches up to B (otherwise grown on demand). */
 int lpvmpc_reserve(lpvmpc_handle *h, int32_t B);

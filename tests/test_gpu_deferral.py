@@ -1,0 +1,106 @@
+"""GPU: straggler deferral (lpvmpc_set_option "defer_after" / "defer_budget").  A deferred call parks the instances that are
+still unsolved after K iterations; resume passes of the same kernel continue them, a budget of iterations at a time, and
+lpvmpc_join finishes what is left.  Nothing about the results may change: status, iteration count, polish flag, residuals and
+every word of xPred / uPred are BIT-IDENTICAL to the plain call (a restored instance re-factors K from its saved state, a pure
+function of it)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev_call(torch, eng, w, B, planner, stream=None):
+    dev = torch.device("cuda", 0)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    N, nx = w["N"], (5 if planner else 6)
+    ins = dict(x0=t(w["x0"]), u_prev=t(w["u_prev"]), vel=t(w["vel_ref"]), curv=t(w["curv_s"]), u_old=t(w["u_old"]), mey=t(w["max_ey"]))
+    o = dict(xPred=torch.full((B, N + 1, nx), -7.0, dtype=torch.float64, device=dev), uPred=torch.full((B, N, 2), -7.0, dtype=torch.float64, device=dev),
+             status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev),
+             resid=torch.zeros((B, 4), dtype=torch.float64, device=dev), polish=torch.zeros(B, dtype=torch.int32, device=dev))
+    eng.solve_dev(B, ins["x0"], ins["u_prev"], ins["vel"], ins["curv"], ins["u_old"], ins["mey"], o["xPred"], o["uPred"], o["status"], o["iters"],
+                  o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"], stream=0 if stream is None else stream.cuda_stream)
+    return ins, o
+
+
+def _host(o):
+    return {k: v.cpu().numpy() for k, v in o.items()}
+
+
+def _same(a, b):
+    for k in ("status", "iters", "polish"):
+        assert np.array_equal(a[k], b[k]), k
+    for k in ("xPred", "uPred", "resid"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("K,budget", [(25, 50), (100, 200), (100, 0)])
+def test_deferred_controller_batch_is_bit_identical(K, budget):
+    import torch
+    from lpvmpc import workloads
+    B = 1024
+    w = workloads.controller_batch(B, N=20, seed=3)            # contains instances with 100 .. 2400 iterations
+    plain = workloads.make_solver(w); plain.reserve(B)
+    _, o = _dev_call(torch, plain, w, B, False); torch.cuda.synchronize(); ref = _host(o); plain.close()
+    assert ref["iters"].max() >= 1000 and np.sum(ref["iters"] > K) >= 4
+    eng = workloads.make_solver(w); eng.reserve(B)
+    eng.set_option("defer_after", K); eng.set_option("defer_budget", budget)
+    keep, o = _dev_call(torch, eng, w, B, False)
+    torch.cuda.synchronize()
+    if budget:                                # one bounded pass cannot have finished the 2400-iteration instance
+        assert np.any(_host(o)["status"] == -11)
+    eng.join(0); torch.cuda.synchronize()
+    _same(_host(o), ref)
+    # several calls in flight on one stream (more than the handle has pool segments) with different inputs each
+    outs = []
+    st = torch.cuda.Stream()
+    for j in range(20):
+        wj = workloads.controller_batch(256, N=20, seed=40 + j)
+        outs.append((wj, _dev_call(torch, eng, wj, 256, False, stream=st)))
+    eng.join(st.cuda_stream); torch.cuda.synchronize()
+    chk = workloads.make_solver(w)
+    for wj, (_, oj) in outs[::5]:
+        r = chk.solve(wj["x0"], wj["u_prev"], wj["vel_ref"], wj["curv_s"], wj["u_old"], None, wj["cf_new"], wj["lap"])
+        h = _host(oj)
+        assert not np.any(h["status"] == -11)
+        assert np.array_equal(h["iters"], r["iters"]) and np.array_equal(h["uPred"], r["uPred"], equal_nan=True)
+    chk.close(); eng.close()
+
+
+def test_deferral_pool_overflow_and_pending_status():
+    """Pools too small for the stragglers: the surplus instances simply finish inside the launch that holds them; results
+    unchanged."""
+    import torch
+    from lpvmpc import workloads
+    B = 1024
+    w = workloads.controller_batch(B, N=20, seed=3)
+    plain = workloads.make_solver(w)
+    ref = plain.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"]); plain.close()
+    n_over = int(np.sum(ref["iters"] > 50))
+    assert n_over > 8
+    eng = workloads.make_solver(w); eng.reserve(B)
+    eng.set_option("defer_pool", 4); eng.set_option("defer_after", 50)
+    _, o = _dev_call(torch, eng, w, B, False)
+    eng.join(0); torch.cuda.synchronize()
+    h = _host(o)
+    assert np.array_equal(h["iters"], ref["iters"]) and np.array_equal(h["status"], ref["status"])
+    assert np.array_equal(h["uPred"], ref["uPred"], equal_nan=True) and np.array_equal(h["xPred"], ref["xPred"], equal_nan=True)
+    eng.close()
+
+
+def test_deferred_planner_batch_is_bit_identical():
+    """The DPP two-wavefront planner kernel (N = 30) and the run-time-horizon kernel go through the same park / restore."""
+    import torch
+    from lpvmpc import workloads
+    B = 256
+    w = workloads.planner_batch(B, N=30, seed=1)
+    for variant in (0, 1):
+        plain = workloads.make_solver(w); plain.set_option("kernel_variant", variant); plain.reserve(B)
+        _, o = _dev_call(torch, plain, w, B, True); torch.cuda.synchronize(); ref = _host(o); plain.close()
+        eng = workloads.make_solver(w); eng.set_option("kernel_variant", variant); eng.reserve(B)
+        eng.set_option("defer_after", 100)
+        _, o = _dev_call(torch, eng, w, B, True)
+        eng.join(0); torch.cuda.synchronize()
+        got = _host(o)
+        assert np.array_equal(got["status"], ref["status"]), (variant, np.nonzero(got["status"] != ref["status"])[0][:10], got["status"][got["status"] != ref["status"]][:10], ref["status"][got["status"] != ref["status"]][:10], ref["iters"][got["status"] != ref["status"]][:10])
+        _same(got, ref)
+        eng.close()

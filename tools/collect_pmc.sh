@@ -5,7 +5,7 @@
 OUT=${1:-gpurun_out/pmc}
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 10 --warmup 2 --streams 1 --no-cpu-baseline --no-extras"
+CMD="python3 bench.py --steps 10 --warmup 2 --streams 1 --defer 0 --no-cpu-baseline --no-extras"
 echo "$CMD" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1 || { tail -5 $OUT/fetch.log; exit 1; }
