@@ -1640,7 +1640,9 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
         if (!generic && cfg.N == 8) return launch_one<6, 8, 1>(cfg, dcfg, a, stream);      // the launch file's controller horizon (MAIN_LAUNCH.launch:117)
         return launch_one<6, 0, 1>(cfg, dcfg, a, stream);
     }
-    if (!generic && cfg.N == 30) return one_wave ? launch_one<5, 30, 1>(cfg, dcfg, a, stream) : launch_one<5, 30, 2>(cfg, dcfg, a, stream);
+    const bool mf = kernel_variant == 4;      // diagnostic: the planner kernels with MFMA sweeps (slower at one wavefront per SIMD)
+    if (!generic && cfg.N == 30) return one_wave ? launch_one<5, 30, 1>(cfg, dcfg, a, stream)
+                                          : (mf ? launch_one<5, 30, 2, true>(cfg, dcfg, a, stream) : launch_one<5, 30, 2>(cfg, dcfg, a, stream));
     if (!generic && cfg.N == 40) return launch_one<5, 40, 2>(cfg, dcfg, a, stream);
     if (!generic && cfg.N == 20) return launch_one<5, 20, 2>(cfg, dcfg, a, stream);      // the planner half of configs[3]
     return launch_one<5, 0, 1>(cfg, dcfg, a, stream);

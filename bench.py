@@ -64,6 +64,7 @@ def main():
                          "the timed region ends with the passes that finish everything (lpvmpc_join); 0 = off (every launch lasts as "
                          "long as its slowest instance); default: 100 for the headline workload, 0 otherwise")
     ap.add_argument("--defer-budget", type=int, default=100, help="iterations per resume pass of the straggler deferral (0 = to completion)")
+    ap.add_argument("--defer-pool", type=int, default=0, help="entries of each of the two pools of parked instances (0 = max(64, B / 8))")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs outside the timed region (serial steps, batch latencies, one launch of all distinct "
                          "instances, single-solve latency): what the profiling passes use")
@@ -132,6 +133,7 @@ def main():
     engines = [workloads.make_solver(w, device=local_rank) for _ in range(S)]
     for e in engines:
         e.set_option("kernel_variant", args.kernel_variant)
+        e.set_option("defer_pool", args.defer_pool)
         e.set_option("defer_after", args.defer)
         e.set_option("defer_budget", args.defer_budget)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]

@@ -144,22 +144,24 @@ def test_fused_batch_cfg2_against_oracle(lpvmpc):
 
 
 def test_kernel_variants_agree(lpvmpc):
-    """Three kernels run the same algorithm: variant 0 (default: compile-time horizon, two wavefronts per
-    instance, two-sided elimination), variant 2 (compile-time horizon, one wavefront) and variant 1 (run-time
-    horizon, factor tiles in LDS): identical statuses / polish flags, iteration counts equal (the factorisations
-    differ in elimination order, i.e. in round-off only), solutions equal to 1e-6 (1e-8 when polished)."""
+    """Four kernels run the same algorithm: variant 0 (default: compile-time horizon, two wavefronts per instance, two-sided
+    elimination; controller N = 20: sweeps and factorisation on the matrix cores), variant 3 (the same with DPP sweeps: what
+    the planner kernels use), variant 2 (compile-time horizon, one wavefront) and variant 1 (run-time horizon, factor tiles in
+    LDS): identical statuses / polish flags, iteration counts equal (the factorisations differ in elimination order, i.e. in
+    round-off only), solutions equal to 1e-6 (1e-8 when polished).  This cross-check is also the run-time guard behind the
+    build's assembly scan (Makefile: a toolchain that mis-compiles one instantiation shows up here)."""
     from lpvmpc import workloads
     for w in (workloads.controller_batch(128, N=20, seed=5), workloads.planner_batch(64, N=30, seed=6),
               workloads.planner_batch(48, N=40, seed=7), workloads.controller_batch(64, N=10, seed=8),
               workloads.controller_batch(64, N=8, seed=9), workloads.planner_batch(64, N=20, seed=10)):
         outs = []
-        for variant in (0, 1, 2):
+        for variant in (0, 1, 2, 3):
             eng = workloads.make_solver(w)
             eng.set_option("kernel_variant", variant)
             outs.append(eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], w["max_ey"], w["cf_new"], w["lap"]))
             eng.close()
         a = outs[1]
-        for b in (outs[0], outs[2]):
+        for b in (outs[0], outs[2], outs[3]):
             assert np.array_equal(a["status"], b["status"]), np.nonzero(a["status"] != b["status"])
             assert np.array_equal(a["iters"], b["iters"]), (np.nonzero(a["iters"] != b["iters"]), a["iters"][a["iters"] != b["iters"]], b["iters"][a["iters"] != b["iters"]])
             assert np.array_equal(a["polish"], b["polish"])

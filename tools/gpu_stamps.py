@@ -15,3 +15,14 @@ for B in (256, 1024):
     print("B=%d cycles/iter: build_rhs %.0f | kkt fwd+pivot %.0f | kkt bwd %.0f | update %.0f | total %.0f (median over instances)" % (
         B, *np.median(r, axis=0), np.median(r.sum(1))))
     eng.close()
+
+# planner N = 30: DPP sweeps (default) against the MFMA sweeps (kernel_variant 4, diagnostic)
+for variant in (0, 4):
+    w = workloads.planner_batch(512, N=30, seed=1)
+    eng = workloads.make_solver(w, adaptive_rho=0, polish=0, check_termination=0, max_iter=200)
+    eng.set_option("kernel_variant", variant)
+    out = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+    r = out["resid"]
+    print("planner N=30 variant %d B=512 cycles/iter: build_rhs %.0f | kkt fwd+pivot %.0f | kkt bwd %.0f | update %.0f | total %.0f" % (
+        variant, *np.median(r, axis=0), np.median(r.sum(1))))
+    eng.close()
