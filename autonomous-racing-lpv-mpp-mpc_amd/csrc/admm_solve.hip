@@ -1592,7 +1592,16 @@ __global__ void __launch_bounds__(64 * NW, (min_waves_per_simd<NT, NW>())) admm_
     extern __shared__ __align__(16) double smem[];
     int inst = blockIdx.x, entry = -1;
     if (a.resume) {
-        const int n = *a.pool_in_count;
+        // every workgroup of a resume pass reads the number of parked entries; the last one to have read it clears the counters
+        // (this launch consumes the pool; launches behind it in the stream park into it again)
+        int &n_parked = *reinterpret_cast<int *>(smem);          // (the instance's LDS image is restored over it afterwards)
+        if (threadIdx.x == 0) {
+            n_parked = atomicAdd(a.pool_in_count, 0);
+            __threadfence();
+            if (atomicAdd(a.pool_in_count + 1, 1) == (int)gridDim.x - 1) { a.pool_in_count[0] = 0; a.pool_in_count[1] = 0; }
+        }
+        __syncthreads();
+        const int n = n_parked;
         entry = blockIdx.x;
         if (entry >= (n < a.pool_cap ? n : a.pool_cap)) return;
     } else if (inst >= a.B) return;

@@ -95,8 +95,8 @@ static int ensure_defer(lpvmpc_handle *h, int B, hipStream_t st) {
     free_defer(h);
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(h, hipMalloc((void **)&h->dpool[i], (size_t)cap * stride * 8));
-        HIP_TRY(h, hipMalloc((void **)&h->dcount[i], 4));
-        HIP_TRY(h, hipMemsetAsync(h->dcount[i], 0, 4, st));
+        HIP_TRY(h, hipMalloc((void **)&h->dcount[i], 8));
+        HIP_TRY(h, hipMemsetAsync(h->dcount[i], 0, 8, st));
     }
     if (!h->defer_event) HIP_TRY(h, hipEventCreateWithFlags(&h->defer_event, hipEventDisableTiming));
     h->defer_cur_cap = cap; h->defer_stride = stride; h->dcur = 0;
@@ -115,7 +115,6 @@ static int resume_pass(lpvmpc_handle *h, int budget, hipStream_t st) {
     if (h->timing) HIP_TRY(h, hipEventRecord(h->rv0[slot], st));
     HIP_TRY(h, lpvmpc::launch_solve(h->dev, h->d_cfg, a, st, h->force_generic));
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->rv1[slot], st)); h->rv_count++; }
-    HIP_TRY(h, hipMemsetAsync(h->dcount[A], 0, 4, st));             // pool A has been consumed
     h->dcur = Bp;
     return LPVMPC_OK;
 }

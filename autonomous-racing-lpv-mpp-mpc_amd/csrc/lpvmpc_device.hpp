@@ -73,7 +73,8 @@ struct SolveArgs {
     double *pool;           // [pool_cap][pool_stride] entries written by this launch
     int32_t *pool_count;    // entries requested so far in pool (may exceed pool_cap: the surplus instances were not parked)
     const double *pool_in;  // resume: entries to continue
-    const int32_t *pool_in_count;
+    int32_t *pool_in_count; // [2]: entries, and the number of resume workgroups that have read it (the last reader clears both:
+                            // the pool is empty again when the pass ends, without a separate memset launch)
     int pool_cap, pool_stride;
 };
 constexpr int kParkScalars = 16;     // behind the LDS image of a pool entry: c, cinv, rho, iter, to_chk, to_adp, instance index and the

@@ -331,6 +331,7 @@ def main():
                          "valu": pmc.get("valu"), "valu_source": pmc.get("source") if pmc.get("valu") else None,
                          "kernel": "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, "" if planner or args.kernel_variant == 3 else ", MFMA sweeps"),
                          "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
+                         "all_launches_avg_ms": (k_ms + r_ms) / max(k_n + r_n, 1),     # main + resume launches: what a kernel trace averages under the one kernel name
                          "resume_launches": ({"count": r_n, "avg_ms": r_ms / max(r_n, 1),
                                               "note": "straggler deferral: the launches counted above park what is unsolved after %d iterations; "
                                                       "these passes of the same kernel (one behind every step, plus the closing lpvmpc_join passes) "
