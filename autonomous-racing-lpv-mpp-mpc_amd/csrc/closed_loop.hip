@@ -91,6 +91,30 @@ __global__ void __launch_bounds__(64) cl_command_plant_kernel(int B, int N, cons
     for (int i = 0; i < 8; ++i) plant[(size_t)b * 8 + i] = st[i];
 }
 
+// the same followed by the NEXT tick's measurement (cl_measure_kernel on the state just advanced): one launch less per
+// control tick; the measurement goes to its own buffer, the previous tick's local state stays readable
+__global__ void __launch_bounds__(64) cl_command_plant_measure_kernel(const DevCfg *__restrict__ cp, int B, int N, const double *__restrict__ uPred,
+                                                                      double *__restrict__ cmd, double *__restrict__ plant, PlantCfg pc,
+                                                                      double hw, double slack, int q9_swap, double *__restrict__ local_next,
+                                                                      double *__restrict__ u_old) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double servo = uPred[(size_t)b * N * 2 + 0], motor = uPred[(size_t)b * N * 2 + 1];
+    cmd[b * 2 + 0] = servo; cmd[b * 2 + 1] = motor;
+    double st[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = plant[(size_t)b * 8 + i];
+    for (int k = 0; k < pc.n_sub; ++k) plant_step(pc, st, motor, servo);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) plant[(size_t)b * 8 + i] = st[i];
+    double s, ey, epsi; int inside;
+    local_position(*cp, hw, slack, st[0], st[1], st[6], s, ey, epsi, inside);
+    double *ls = local_next + (size_t)b * 6;
+    ls[0] = st[2] < 0.01 ? 0.01 : st[2]; ls[1] = st[3]; ls[2] = st[7];
+    ls[3] = q9_swap ? ey : epsi; ls[4] = s; ls[5] = q9_swap ? epsi : ey;
+    u_old[b * 2 + 0] = servo; u_old[b * 2 + 1] = motor;
+}
+
 #define LPVMPC_GRID(n) dim3(((n) + 63) / 64), dim3(64)
 hipError_t launch_local_position(const DevCfg *dcfg, int B, const double *xypsi, double hw, double slack, double *out, hipStream_t s) {
     hipLaunchKernelGGL(local_position_kernel, LPVMPC_GRID(B), 0, s, dcfg, B, xypsi, hw, slack, out);
@@ -115,6 +139,12 @@ hipError_t launch_cl_seed(int B, int N, const double *local_state, double *xlast
 }
 hipError_t launch_cl_command_plant(int B, int N, const double *uPred, double *cmd, double *plant, PlantCfg pc, hipStream_t s) {
     hipLaunchKernelGGL(cl_command_plant_kernel, LPVMPC_GRID(B), 0, s, B, N, uPred, cmd, plant, pc);
+    return hipGetLastError();
+}
+
+hipError_t launch_cl_command_plant_measure(const DevCfg *dcfg, int B, int N, const double *uPred, double *cmd, double *plant, PlantCfg pc,
+                                           double hw, double slack, int q9_swap, double *local_next, double *u_old, hipStream_t s) {
+    hipLaunchKernelGGL(cl_command_plant_measure_kernel, LPVMPC_GRID(B), 0, s, dcfg, B, N, uPred, cmd, plant, pc, hw, slack, q9_swap, local_next, u_old);
     return hipGetLastError();
 }
 

@@ -157,7 +157,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->d_x0 = h->d_uprev = h->d_vel = h->d_curv = h->d_uold = h->d_maxey = h->d_AB = h->d_states = nullptr;
     h->d_xPred = h->d_uPred = h->d_resid = h->d_xlast = h->d_delta = nullptr;
     h->d_status = h->d_iters = h->d_polish = nullptr; h->d_state = nullptr; h->warm_mode = 0; h->state_valid_B = 0;
-    h->cl_plant = h->cl_local = h->cl_cmd = nullptr; h->cl_B = 0; h->cl_first_it = 1; h->cl_q9 = 1; h->cl_ticks = 0;
+    h->cl_plant = h->cl_local = h->cl_cmd = nullptr; h->cl_local_next = nullptr; h->cl_next_valid = 0; h->cl_B = 0; h->cl_first_it = 1; h->cl_q9 = 1; h->cl_ticks = 0;
     h->d_Wop = h->d_FWop = nullptr; h->ho_M = 0; h->cascade = nullptr; h->cascade_owner = nullptr; h->cascade_prefetch = 1;
     h->defer_after = 0; h->defer_budget = 200; h->defer_cap = 0; h->defer_cur_cap = 0; h->defer_stride = 0; h->rv_count = 0;
     h->dpool[0] = h->dpool[1] = nullptr; h->dcount[0] = h->dcount[1] = nullptr; h->dcur = 0; h->defer_stream = nullptr; h->defer_event = nullptr;
@@ -200,6 +200,7 @@ extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     free_ws(h);
     if (h->cl_plant) (void)hipFree(h->cl_plant);
+    if (h->cl_local_next) (void)hipFree(h->cl_local_next);
     if (h->cl_local) (void)hipFree(h->cl_local);
     if (h->cl_cmd) (void)hipFree(h->cl_cmd);
     if (h->cascade) lpvmpc_cascade_free(h);
@@ -641,8 +642,8 @@ extern "C" int lpvmpc_cl_release(lpvmpc_handle *h) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->cascade) { HIP_TRY(h, hipDeviceSynchronize()); lpvmpc_cascade_free(h); }
-    if (h->cl_plant) { (void)hipFree(h->cl_plant); (void)hipFree(h->cl_local); (void)hipFree(h->cl_cmd); h->cl_plant = h->cl_local = h->cl_cmd = nullptr; }
-    h->cl_B = 0; h->cl_ticks = 0; h->cl_first_it = 1;
+    if (h->cl_plant) { (void)hipFree(h->cl_plant); (void)hipFree(h->cl_local); (void)hipFree(h->cl_cmd); (void)hipFree(h->cl_local_next); h->cl_plant = h->cl_local = h->cl_cmd = h->cl_local_next = nullptr; }
+    h->cl_B = 0; h->cl_ticks = 0; h->cl_first_it = 1; h->cl_next_valid = 0;
     return LPVMPC_OK;
 }
 
@@ -654,7 +655,9 @@ extern "C" int lpvmpc_cl_init(lpvmpc_handle *h, int32_t B, const double *plant0,
     if (h->cfg.steering_delay != 0) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_init: the fleet engines run the reference's steeringDelay = 0 (CMAIN:49)");
     if (!plant0 || n_sub < 1 || !(dt_sim > 0)) return fail(h, LPVMPC_E_ARG, "lpvmpc_cl_init: bad argument");
     rc = lpvmpc_need_track(h, "lpvmpc_cl_init"); if (rc) return rc;
-    if (h->cl_plant) { (void)hipFree(h->cl_plant); (void)hipFree(h->cl_local); (void)hipFree(h->cl_cmd); h->cl_plant = h->cl_local = h->cl_cmd = nullptr; }
+    if (h->cl_plant) { (void)hipFree(h->cl_plant); (void)hipFree(h->cl_local); (void)hipFree(h->cl_cmd); (void)hipFree(h->cl_local_next); h->cl_plant = h->cl_local = h->cl_cmd = h->cl_local_next = nullptr; }
+    h->cl_next_valid = 0;
+    HIP_TRY(h, hipMalloc((void **)&h->cl_local_next, (size_t)B * 6 * 8));
     HIP_TRY(h, hipMalloc((void **)&h->cl_plant, (size_t)B * 8 * 8));
     HIP_TRY(h, hipMalloc((void **)&h->cl_local, (size_t)B * 6 * 8));
     HIP_TRY(h, hipMalloc((void **)&h->cl_cmd, (size_t)B * 2 * 8));
@@ -676,7 +679,9 @@ extern "C" int lpvmpc_cl_tick(lpvmpc_handle *h, int32_t n_ticks) {
     const int B = h->cl_B, N = h->cfg.N;
     hipStream_t st = h->stream;
     for (int t = 0; t < n_ticks; ++t) {
-        HIP_TRY(h, lpvmpc::launch_cl_measure(h->d_cfg, B, h->cl_plant, h->cl_cmd, h->cl_hw, h->cl_slack, h->cl_q9, h->cl_local, h->d_uold, st));
+        // the measurement of this tick: made by the launch that advanced the plant at the end of the previous tick, or here
+        if (h->cl_next_valid) { double *t_ = h->cl_local; h->cl_local = h->cl_local_next; h->cl_local_next = t_; }
+        else HIP_TRY(h, lpvmpc::launch_cl_measure(h->d_cfg, B, h->cl_plant, h->cl_cmd, h->cl_hw, h->cl_slack, h->cl_q9, h->cl_local, h->d_uold, st));
         const double *x0 = h->cl_local; int x0_stride = 6;
         if (h->cl_first_it < 10) {                                           // CMAIN:310-315: seed mode
             HIP_TRY(h, lpvmpc::launch_cl_seed(B, N, h->cl_local, h->d_xlast, h->d_delta, st));
@@ -690,7 +695,9 @@ extern "C" int lpvmpc_cl_tick(lpvmpc_handle *h, int32_t n_ticks) {
                     h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0, x0_stride};
         int rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
         if (h->warm_mode) h->state_valid_B = B;
-        HIP_TRY(h, lpvmpc::launch_cl_command_plant(B, N, h->d_uPred, h->cl_cmd, h->cl_plant, h->cl_pc, st));
+        HIP_TRY(h, lpvmpc::launch_cl_command_plant_measure(h->d_cfg, B, N, h->d_uPred, h->cl_cmd, h->cl_plant, h->cl_pc, h->cl_hw, h->cl_slack, h->cl_q9,
+                                                            h->cl_local_next, h->d_uold, st));
+        h->cl_next_valid = 1;
         h->cl_ticks++;
     }
     return LPVMPC_OK;

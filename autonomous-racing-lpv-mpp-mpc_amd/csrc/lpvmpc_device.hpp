@@ -98,6 +98,8 @@ hipError_t launch_cl_measure(const DevCfg *dcfg, int B, const double *plant, con
                              int q9_swap, double *local_state, double *u_old, hipStream_t s);
 hipError_t launch_cl_seed(int B, int N, const double *local_state, double *xlast, double *delta, hipStream_t s);
 hipError_t launch_cl_command_plant(int B, int N, const double *uPred, double *cmd, double *plant, PlantCfg pc, hipStream_t s);
+hipError_t launch_cl_command_plant_measure(const DevCfg *dcfg, int B, int N, const double *uPred, double *cmd, double *plant, PlantCfg pc,
+                                           double hw, double slack, int q9_swap, double *local_next, double *u_old, hipStream_t s);
 
 
 // planner -> controller hand-off and trajectory-tracking measurement (handoff.hip)

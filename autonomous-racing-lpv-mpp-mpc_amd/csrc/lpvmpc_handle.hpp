@@ -31,6 +31,8 @@ struct lpvmpc_handle {
     int warm_mode, state_valid_B;   // 0 off (default); instances whose state is valid from the previous solve
     // closed-loop fleet (lpvmpc_cl_*): plant [B][8], local state [B][6], command [B][2] and scratch
     double *cl_plant, *cl_local, *cl_cmd;
+    double *cl_local_next;   // measurement of the coming tick, made by the launch that advanced the plant (valid: cl_next_valid)
+    int cl_next_valid;
     int cl_B, cl_first_it, cl_q9, cl_ticks;
     double cl_hw, cl_slack;
     lpvmpc::PlantCfg cl_pc;
