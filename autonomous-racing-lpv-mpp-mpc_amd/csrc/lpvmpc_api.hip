@@ -198,6 +198,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
 extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();          // launches of this handle may still be running on the caller's streams (deferred calls: their resume passes)
     free_ws(h);
     if (h->cl_plant) (void)hipFree(h->cl_plant);
     if (h->cl_local_next) (void)hipFree(h->cl_local_next);
@@ -504,6 +505,8 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
     if (!ctrl && (!curv_s || !max_ey)) return fail(h, LPVMPC_E_ARG, "lpvmpc_solve_batch_dev: planner needs SS and max_ey");
     if ((ctrl && lap == 0) || !ctrl) { rc = lpvmpc_need_track(h, "lpvmpc_solve_batch_dev"); if (rc) return rc; }
     hipStream_t st = (hipStream_t)stream;
+    // a warm start reads the previous call's final (x, y): with straggler deferral, finish what that call left parked first
+    if (h->warm_mode && h->defer_after > 0 && h->dpool[0]) { rc = lpvmpc_join(h, stream); if (rc) return rc; }
     rc = launch_lpv(h, B, x0, u_prev, vel_ref, curv_s, cf_new, lap, nullptr, h->d_AB, st); if (rc) return rc;
     SolveArgs a{B, x0, h->d_AB, ctrl ? vel_ref : nullptr, u_old, ctrl ? nullptr : max_ey, xPred, uPred, status, iters, polish, resid,
                 h->warm_mode ? h->d_state : nullptr, (h->warm_mode && h->state_valid_B == B) ? h->warm_mode : 0, h->nx};

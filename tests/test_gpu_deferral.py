@@ -104,3 +104,38 @@ def test_deferred_planner_batch_is_bit_identical():
         assert np.array_equal(got["status"], ref["status"]), (variant, np.nonzero(got["status"] != ref["status"])[0][:10], got["status"][got["status"] != ref["status"]][:10], ref["status"][got["status"] != ref["status"]][:10], ref["iters"][got["status"] != ref["status"]][:10])
         _same(got, ref)
         eng.close()
+
+
+def test_deferral_with_warm_start_bad_inputs_and_housekeeping():
+    """Deferral next to the other options: the opt-in warm start (its state buffer travels with the parked instance), non-finite
+    inputs (those instances never iterate, nothing to park), join without a call, switching the option off (implies a join),
+    destroying a handle that still holds parked instances."""
+    import torch
+    from lpvmpc import workloads
+    B = 512
+    w = workloads.controller_batch(B, N=20, seed=3)
+    w["x0"][7, 2] = np.nan                                    # one bad instance
+    runs = {}
+    for defer in (0, 50):
+        eng = workloads.make_solver(w); eng.reserve(B)
+        eng.set_option("warm_start", 2); eng.set_option("defer_budget", 75)
+        eng.join(0)                                           # nothing to join yet
+        eng.set_option("defer_after", defer)
+        outs = []
+        for _ in range(3):                                    # cold solve, then two warm-started ones
+            _, o = _dev_call(torch, eng, w, B, False)
+            eng.join(0); torch.cuda.synchronize()
+            outs.append(_host(o))
+        runs[defer] = outs
+        if defer:
+            _, o = _dev_call(torch, eng, w, B, False)         # leave instances parked ...
+            eng.set_option("defer_after", 0)                  # ... switching off finishes them
+            torch.cuda.synchronize()
+            assert not np.any(_host(o)["status"] == -11)
+            eng.set_option("defer_after", defer)
+            _dev_call(torch, eng, w, B, False)                # parked again, never joined: close() must cope
+        eng.close()
+    for a, b in zip(runs[0], runs[50]):
+        _same(a, b)
+    assert runs[0][0]["status"][7] == -10 and np.all(np.isnan(runs[0][0]["uPred"][7]))
+    assert runs[0][1]["iters"].sum() < runs[0][0]["iters"].sum()          # the warm start did take effect
