@@ -26,7 +26,7 @@ for shape in ("oval", "L_shape", "3110", "Euge_Track"):
                 ref = O.plan_tick_batch(w, nthreads=16)
             eng.close()
             # no answer from the oracle: KKT breakdown (-10), or a rolled-out abscissa outside the track table, where the
-            # reference's Curvature() raises (the C oracle marks it with NaN, the device uses the first / last segment)
+            # reference's Curvature() raises (the C oracle marks it with NaN, the device reports LPVMPC_UNSOLVED with NaN outputs)
             sane = (ref["status"] != -10) & ~(np.isnan(ref["uPred"]).any(axis=(1, 2)) & (ref["status"] == 1))
             fin = np.isfinite(ref["uPred"]).all(axis=(1, 2)) & np.isfinite(a["uPred"]).all(axis=(1, 2)) & sane
             d = np.abs(a["uPred"][fin] - ref["uPred"][fin]).max(axis=(1, 2)) if fin.any() else np.zeros(0)
