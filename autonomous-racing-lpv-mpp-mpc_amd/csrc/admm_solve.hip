@@ -256,7 +256,10 @@ struct Solver {
     // stages; ABS = true gives the infinity norm of the (scaled) column instead.  Branch-free: the Pm row is
     // zero outside its diagonal block, the stage-N input rows are switched off explicitly.
     template <bool ABS, bool RAW = false>
-    __device__ __forceinline__ double P_row(int k, const double *v) const {
+    __device__ __forceinline__ double P_row(int k, const double *v) const { return P_row_d<ABS, RAW>(k, v, D); }
+    // the same with the variable scaling taken from Dv (the equilibration alternates between two copies of D)
+    template <bool ABS, bool RAW = false>
+    __device__ __forceinline__ double P_row_d(int k, const double *v, const double *D) const {
         const int a = tj, e = k * 8 + a;
         const double2 *pr = reinterpret_cast<const double2 *>(Pm + a * 8);
         const double2 *dr = reinterpret_cast<const double2 *>(D + k * 8);
@@ -302,61 +305,62 @@ struct Solver {
         double pacc[kRounds];
         const LaneC lc = lane_consts();
         const int r0 = lc.r0, r1 = lc.r1, r2 = lc.r2, bvar = lc.bvar;
-        for (int it = 0; it < cfg.scaling; ++it) {
-            // infinity norms of the columns of [P A'; A 0] -> step factors in XT (variables), ZTd / ZTb (rows)
+        // One equilibration pass reads the scalings (Ds, Es, Bs) and writes the updated ones to (Dn, En, Bn): the passes
+        // alternate between the arrays D / Ed / Eb and XT / ZTd / ZTb (free during set-up), so the norms and the update
+        // D <- D / sqrt(norm) are one element loop and one barrier (the values are those of the two-loop form, bit for bit).
+        auto pass = [&](bool first, const double *Ds, const double *Es, const double *Bs, double *Dn, double *En, double *Bn) {
+            // infinity norms of the columns of [P A'; A 0] -> new scalings
             auto norms = [&](int e, double pcol) {
                 const int k = e >> 3, a = tj, kn = k < N ? k + 1 : N, kp = k > 0 ? k - 1 : 0;
-                const double de = D[e], ede = Ed[e], ebe = Eb[e];
+                const double de = Ds[e], ede = Es[e], ebe = Bs[e];
                 const double *col = tA + k * kTS + a, *row = tA + kp * kTS + a * 8;
                 double cmax = 0.0, rmax = 0.0;
 #pragma unroll
-                for (int r = 0; r < NX; ++r) cmax = fmax(cmax, fabs(col[r * 8]) * Ed[kn * 8 + r]);      // stage-N tile is zero
+                for (int r = 0; r < NX; ++r) cmax = fmax(cmax, fabs(col[r * 8]) * Es[kn * 8 + r]);      // stage-N tile is zero
 #pragma unroll
-                for (int b = 0; b < NB; ++b) rmax = fmax(rmax, fabs(row[b]) * D[kp * 8 + b]);
+                for (int b = 0; b < NB; ++b) rmax = fmax(rmax, fabs(row[b]) * Ds[kp * 8 + b]);
                 double dn = 0.0;
                 if (a < nvar(k)) {
                     dn = fmax(pcol, cmax * de);
-                    if (r0 < nbox(k)) dn = fmax(dn, Eb[k * 8 + r0] * de);
-                    if (r1 < nbox(k)) dn = fmax(dn, Eb[k * 8 + r1] * de);
-                    if (r2 < nbox(k)) dn = fmax(dn, Eb[k * 8 + r2] * de);
+                    if (r0 < nbox(k)) dn = fmax(dn, Bs[k * 8 + r0] * de);
+                    if (r1 < nbox(k)) dn = fmax(dn, Bs[k * 8 + r1] * de);
+                    if (r2 < nbox(k)) dn = fmax(dn, Bs[k * 8 + r2] * de);
                     if (a < NX) dn = fmax(dn, ede * de);
                 }
                 double en = 0.0;          // dynamics row (k, a)
                 if (a < NX) { en = ede * de; if (k >= 1) en = fmax(en, rmax * ede); }
                 double bn = 0.0;          // box row (k, a)
-                if (a < nbox(k)) bn = ebe * D[k * 8 + bvar];
-                XT[e] = inv_sqrt(limit_scaling(dn));
-                ZTd[e] = inv_sqrt(limit_scaling(en));
-                ZTb[e] = inv_sqrt(limit_scaling(bn));
+                if (a < nbox(k)) bn = ebe * Ds[k * 8 + bvar];
+                Dn[e] = de * inv_sqrt(limit_scaling(dn));
+                En[e] = ede * inv_sqrt(limit_scaling(en));
+                Bn[e] = ebe * inv_sqrt(limit_scaling(bn));
             };
             if constexpr (kReg) {
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) {
                     const int e = tid + r * kStride;
-                    if (e < NS * 8) norms(e, it == 0 ? P_colnorm(e >> 3, tj) : pacc[r] * c * D[e]);
+                    if (e < NS * 8) norms(e, first ? P_row_d<true>(e >> 3, Ds, Ds) : pacc[r] * c * Ds[e]);
                 }
             } else {
-                for (int e = opaque(tid); e < NS * 8; e += kStride) norms(e, P_colnorm(e >> 3, tj));
+                for (int e = opaque(tid); e < NS * 8; e += kStride) norms(e, P_row_d<true>(e >> 3, Ds, Ds));
             }
             sync();
-            for (int e = opaque(tid); e < NS * 8; e += kStride) { D[e] *= XT[e]; Ed[e] *= ZTd[e]; Eb[e] *= ZTb[e]; }
-            sync();
-            // cost normalisation
+            // cost normalisation (with the new D)
             double psum = 0.0, qmax = 0.0;
             if constexpr (kReg) {
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) {
                     const int e = tid + r * kStride;
                     if (e < NS * 8) {
-                        pacc[r] = P_colacc(e >> 3);
-                        psum += pacc[r] * c * D[e];
-                        qmax = fmax(qmax, fabs(c * D[e] * Qv[e]));
+                        pacc[r] = P_row_d<true, true>(e >> 3, Dn, Dn);
+                        psum += pacc[r] * c * Dn[e];
+                        qmax = fmax(qmax, fabs(c * Dn[e] * Qv[e]));
                     }
                 }
             } else {
                 for (int e = opaque(tid); e < NS * 8; e += kStride) {
-                    psum += P_colnorm(e >> 3, tj);
-                    qmax = fmax(qmax, fabs(c * D[e] * Qv[e]));
+                    psum += P_row_d<true>(e >> 3, Dn, Dn);
+                    qmax = fmax(qmax, fabs(c * Dn[e] * Qv[e]));
                 }
             }
             const SumMax pq = bsum_bmax<0>(psum, qmax);
@@ -364,6 +368,17 @@ struct Solver {
             qmax = limit_scaling(pq.m);
             const double ct = limit_scaling(fmax(psum, qmax));
             c *= 1.0 / ct;
+        };
+        const int n_it = cfg.scaling;
+        int it = 0;
+        for (; it + 1 < n_it; it += 2) {
+            pass(it == 0, D, Ed, Eb, XT, ZTd, ZTb);
+            pass(false, XT, ZTd, ZTb, D, Ed, Eb);
+        }
+        if (it < n_it) {        // odd count: one more pass, then bring the result home
+            pass(it == 0, D, Ed, Eb, XT, ZTd, ZTb);
+            for (int e = opaque(tid); e < NS * 8; e += kStride) { D[e] = XT[e]; Ed[e] = ZTd[e]; Eb[e] = ZTb[e]; }
+            sync();
         }
         cinv = 1.0 / c;
         // A <- E A D on the stored [A|B] tiles, four stages per trip (all loads before the stores)
