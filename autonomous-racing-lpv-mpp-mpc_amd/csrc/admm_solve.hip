@@ -87,6 +87,27 @@ struct Solver {
         int r0, r1, r2, bvar; // box rows acting on variable tj (7 = none, its coefficient is 0; r2 = the delay row on delta); variable of box row tj
         double rmask;         // 1 if tj is a real dynamics row
     };
+    // ADMM weight of this thread's box rows (one per element round) and its reciprocal: the class of a row (loose / equality /
+    // inequality, OSQP set_rho_vec) follows from its bounds alone, so the pair is fixed between two rho updates -- kept in
+    // registers instead of three f64 compares and eight selects per element and iteration in update()
+    static constexpr bool kCacheW = kReg && MF;       // (the other instantiations have no registers to spare)
+    static constexpr int kRnd = kCacheW ? ((NT + 1) * 8 + kStride - 1) / kStride : 1;
+    double wbx[kRnd], wbxi[kRnd];
+    __device__ __forceinline__ void cache_box_weights() {
+        if constexpr (kCacheW) {
+#pragma unroll
+            for (int r = 0; r < kRnd; ++r) {
+                const int e = tid + r * kStride;
+                double w = rho, wi = rinv;
+                if (e < NS * 8) {
+                    const double lo = Lo[e], hi = Hi[e];
+                    const bool loose = lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling, eq = hi - lo < kRhoTol;
+                    w = loose ? kRhoMin : (eq ? rho_eq : rho); wi = loose ? 1.0 / kRhoMin : (eq ? rinv_eq : rinv);
+                }
+                wbx[r] = w; wbxi[r] = wi;
+            }
+        }
+    }
     int lpack;                // r0 | r1 << 4 | r2 << 8 | bvar << 12 | (tj < NX) << 16: one register for the whole solve, unpacked where used
     __device__ __forceinline__ LaneC lane_consts() const {
         LaneC l;
@@ -1169,7 +1190,7 @@ struct Solver {
         const LaneC lc = lane_consts();
         const int bvar = lc.bvar;
         const double rmask = lc.rmask;
-        for (int e = opaque(tid); e < NS * 8; e += kStride) {
+        auto element = [&](int e, bool cached, double wc, double wic) {
             const int k = e >> 3;
             const double xt = XT[e], xo = X[e];
             const double zd = Zd[e], yd = Yd[e], zb = Zb[e], yb = Yb[e], lo = Lo[e], hi = Hi[e];
@@ -1182,8 +1203,11 @@ struct Solver {
             const double znd = clipd(zrd + rinv_eq * yd, b, b);
             const double dyd = rho_eq * (zrd - znd), ynd = yd + dyd;
             // box row (k, tj)
-            const bool loose = lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling, eq = hi - lo < kRhoTol;
-            const double w = loose ? kRhoMin : (eq ? rho_eq : rho), winv = loose ? 1.0 / kRhoMin : (eq ? rinv_eq : rinv);
+            double w = wc, winv = wic;
+            if (!cached) {
+                const bool loose = lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling, eq = hi - lo < kRhoTol;
+                w = loose ? kRhoMin : (eq ? rho_eq : rho); winv = loose ? 1.0 / kRhoMin : (eq ? rinv_eq : rinv);
+            }
             const double zrb = alpha * (sb * xv) + oma * zb;
             const double znb = clipd(zrb + winv * yb, lo, hi);
             const double dyb = w * (zrb - znb), ynb = yb + dyb;
@@ -1192,6 +1216,16 @@ struct Solver {
             Yb[e] = ynb; Zb[e] = znb; ZTb[e] = w * znb - ynb;
             X[e] = xn;
             if (want_delta) { DYd[e] = dyd; DYb[e] = dyb; DX[e] = xn - xo; }
+        };
+        if constexpr (kCacheW) {
+            const int t0 = opaque(tid);
+#pragma unroll
+            for (int r = 0; r < kRnd; ++r) {
+                const int e = t0 + r * kStride;
+                if (e < NS * 8) element(e, true, wbx[r], wbxi[r]);
+            }
+        } else {
+            for (int e = opaque(tid); e < NS * 8; e += kStride) element(e, false, 0.0, 0.0);
         }
         sync();
     }
@@ -1365,6 +1399,7 @@ struct Solver {
         cache_row_coefficients();
         set_rho(fmin(fmax(cfg.rho, kRhoMin), kRhoMax));
         }
+        cache_box_weights();
         factor(cfg.sigma);                      // first factorisation, or the one that puts a restored instance back into its registers
         if (!resuming) {
             if (a.warm && a.state) warm_start(a.state + (size_t)inst * 3 * NS * 8, a.warm == 2);
@@ -1404,7 +1439,7 @@ struct Solver {
                 if (checked) { status = check_termination(R, false); if (status != LPVMPC_UNSOLVED_) break; }
                 if (adapt) {
                     const double rn = rho_estimate(R, rho);
-                    if (rn > rho * rho_tol || rn < rho / rho_tol) { set_rho(rn); factor(sigma); }
+                    if (rn > rho * rho_tol || rn < rho / rho_tol) { set_rho(rn); cache_box_weights(); factor(sigma); }
                 }
                 recompute_w();              // the residual evaluation used ZT* as scratch (and rho may have changed)
                 // straggler deferral: unsolved at this check and past the budget -> park and end the workgroup (block-uniform)
