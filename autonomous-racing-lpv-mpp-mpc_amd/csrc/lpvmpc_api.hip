@@ -6,10 +6,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
-#include <atomic>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -72,6 +70,7 @@ static void free_ws(lpvmpc_handle *h) {
     h->cap = 0;
 }
 
+static const int kEventRing = 1024;      // event pairs kept by lpvmpc_set_timing (main launches, and separately resume passes)
 extern "C" int lpvmpc_join(lpvmpc_handle *h, void *stream);
 // ---- straggler deferral: the two pools ---------------------------------------------------------------------------------
 static void free_defer(lpvmpc_handle *h) {
@@ -111,7 +110,7 @@ static int resume_pass(lpvmpc_handle *h, int budget, hipStream_t st) {
     a.pool_in = h->dpool[A]; a.pool_in_count = h->dcount[A];
     a.pool = h->dpool[Bp]; a.pool_count = h->dcount[Bp];
     a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride; a.x0_stride = h->nx;
-    const int slot = h->rv_count % 1024;
+    const int slot = h->rv_count % kEventRing;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->rv0[slot], st));
     HIP_TRY(h, lpvmpc::launch_solve(h->dev, h->d_cfg, a, st, h->force_generic));
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->rv1[slot], st)); h->rv_count++; }
@@ -226,6 +225,11 @@ extern "C" const char *lpvmpc_last_error(const lpvmpc_handle *h) { return h ? h-
 
 extern "C" int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value) {
     if (!h || !name) return fail(h, LPVMPC_E_ARG, "lpvmpc_set_option: bad arguments");
+    if ((std::strcmp(name, "force_generic_kernel") == 0 || std::strcmp(name, "kernel_variant") == 0) && h->dpool[0]) {
+        // parked instances hold the LDS image of the kernel variant that parked them: finish them before the variant changes
+        int rc = lpvmpc_join(h, (void *)h->defer_stream); if (rc) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->defer_stream));
+    }
     if (std::strcmp(name, "force_generic_kernel") == 0) { h->force_generic = value != 0 ? 1 : 0; return LPVMPC_OK; }
     if (std::strcmp(name, "warm_start") == 0) {
         if (value < 0 || value > 2) return fail(h, LPVMPC_E_ARG, "warm_start must be 0 (off), 1 (previous solution) or 2 (shifted by one stage)");
@@ -256,7 +260,6 @@ extern "C" int lpvmpc_reserve(lpvmpc_handle *h, int32_t B) {
     return ensure_ws(h, B);
 }
 
-static const int kEventRing = 1024;
 
 extern "C" int lpvmpc_set_timing(lpvmpc_handle *h, int32_t on) {
     if (!h) return LPVMPC_E_ARG;
