@@ -90,7 +90,7 @@ struct Solver {
     // ADMM weight of this thread's box rows (one per element round) and its reciprocal: the class of a row (loose / equality /
     // inequality, OSQP set_rho_vec) follows from its bounds alone, so the pair is fixed between two rho updates -- kept in
     // registers instead of three f64 compares and eight selects per element and iteration in update()
-    static constexpr bool kCacheW = kReg && MF;       // (the other instantiations have no registers to spare)
+    static constexpr bool kCacheW = kReg && (MF || (NW == 2 && NT > 20));   // (the N <= 20 DPP / one-wave instantiations have no registers to spare)
     static constexpr int kRnd = kCacheW ? ((NT + 1) * 8 + kStride - 1) / kStride : 1;
     double wbx[kRnd], wbxi[kRnd];
     __device__ __forceinline__ void cache_box_weights() {
