@@ -158,6 +158,34 @@ def test_cascade_fleet_vs_oracle():
     ctrl.close(); plan.close()
 
 
+def test_sub_fleets_side_by_side_equal_the_whole_fleet():
+    """bench.py's cfg5 leg cuts the fleet into sub-fleets with their own engine pairs, all enqueued before any is read:
+    vehicles are independent, so the results have to be bit-identical to one fleet holding all of them."""
+    c = load("cascade")
+    B, K = 48, 15
+    plant0 = fleet_start(c, 5, B)
+    cmd0 = np.tile(c["cmd0"], (B, 1)); uPred0 = np.tile(c["uPred0"], (B, 1, 1))
+
+    def run(cuts):
+        fleets = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            plan, mp = planner()
+            plan.handoff_setup()
+            ctrl = controller_tt(mp)
+            ctrl.cascade_init(plan, plant0[a:b], cmd0[a:b], uPred0[a:b], half_width=mp.halfWidth, slack=mp.slack, plan_max_ey=0.2)
+            fleets.append((ctrl, plan))
+        for ctrl, _ in fleets:
+            ctrl.cascade_tick(K)
+        outs = [ctrl.cascade_read() for ctrl, _ in fleets]
+        for ctrl, plan in fleets:
+            ctrl.close(); plan.close()
+        return {k: np.concatenate([o[k] for o in outs]) for k in ("plant", "local", "cmd", "iters", "status", "lap", "plan_iters", "plan_status")}
+
+    whole, parts = run([0, B]), run([0, 7, 30, B])
+    for k in whole:
+        assert np.array_equal(whole[k], parts[k], equal_nan=whole[k].dtype.kind == "f"), k
+
+
 def test_infeasible_planner_instance_stays_contained():
     """With this start the planner QP of vehicle 0 (and later of a few others) turns primal infeasible (at vx ~ 1.1 m/s the
     forward-Euler lateral dynamics of the planner model are unstable at dt = 0.05, the 40-step prediction blows up).
