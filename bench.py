@@ -325,6 +325,10 @@ def main():
                             "distinct_batches_timed": len(used), "batch_seeds": "step j solves batch j mod %d = seed %d + (j mod %d) + 1000 rank" % (NBAT, 1 if planner else 0, NBAT),
                             "mean_admm_iters": agg[0] / total,
                             "max_admm_iters_rank0": int(max(it_slot[i].max() for i in used)),
+                            # an instance is a serial chain of ADMM iterations (2.4 us each with a CU to itself, 3.3 us on a full
+                            # GPU: DESIGN.md section 5), so the timed region cannot end sooner than its slowest instance does
+                            "slowest_instance_floor_ms": int(max(it_slot[i].max() for i in used)) * (3.7e-3 if planner else 2.4e-3),
+                            "timed_region_ms": elapsed * 1e3,
                             "solved_fraction": agg[1] / total}, **extras),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

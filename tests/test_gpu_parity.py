@@ -283,6 +283,23 @@ def test_planner_n40_batch_against_oracle(lpvmpc):
     assert np.max(d) <= 1e-6, (int(np.argmax(d)), float(np.max(d)))
 
 
+def test_second_device_gets_the_large_lds_opt_in(lpvmpc):
+    """The > 64 KB LDS opt-in of a kernel is a per-device function attribute: a handle on device 1 created after one on
+    device 0 has to get its own (N = 40 planner: 75 KB).  Needs two visible GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    from lpvmpc import workloads
+    w = workloads.planner_batch(64, N=40, seed=1)
+    outs = []
+    for dev in (0, 1):
+        eng = workloads.make_solver(w, device=dev)
+        outs.append(eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"]))
+        eng.close()
+    for k in ("status", "iters", "uPred", "xPred"):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=outs[0][k].dtype.kind == "f"), k
+
+
 def test_maximum_horizon(lpvmpc):
     """LPVMPC_MAX_N = 52 for both problem kinds (largest LDS footprint, run-time-horizon kernel) against the C oracle;
     one more stage is refused at creation."""
