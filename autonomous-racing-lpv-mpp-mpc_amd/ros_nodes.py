@@ -130,20 +130,22 @@ class ControllerNode(object):
 class PlannerNode(object):
     """Loop state and one iteration of the trajectory-planner node."""
 
-    def __init__(self, track_map, N, dt, half_width, params=None, device=0):
+    def __init__(self, track_map, N, dt, half_width, params=None, device=0, testing=False):
         self.map, self.N, self.dt, self.HW = track_map, int(N), float(dt), float(half_width)
+        self.testing = bool(testing)         # PLANNER_TEST.launch (Testing = 1): no estimator, start from [1, 0, 0, 0, 0] (PMAIN:59-69, 144-146)
         self.Planner = LPV_MPC_Planner(PLAN_Q, PLAN_R, PLAN_dR, PLAN_L, N, dt, track_map, "OSQP", params=params, device=device)   # PMAIN:98-106
         self.handoff = PlannerHandoff(self.Planner)
         self.first_it = 1
 
-    def step(self, current_state):
-        """current_state = [vx vy psiDot x y psi] (pos_info; only used on the first iteration, PMAIN:137-141).
+    def step(self, current_state=None):
+        """current_state = [vx vy psiDot x y psi] (pos_info; only used on the first iteration, PMAIN:137-141; ignored in
+        testing mode, where the first state is [1, 0, 0] at the pose (0, 0, 0) the node's arrays start from, PMAIN:145-146).
         Returns the five My_Planning arrays."""
         P = self.Planner
         if self.first_it == 1:
-            G = np.asarray(current_state, float)
+            G = np.array([1.0, 0.0, 0.0, 0.0, 0.0, 0.0]) if self.testing else np.asarray(current_state, float)
             x0 = np.array([G[0], G[1], G[2], 0.0, 0.0])
-            _s, x0[4], x0[3], _inside = self.map.getLocalPosition(G[3], G[4], G[5])           # PMAIN:141 (quirk Q9)
+            _s, x0[4], x0[3], _inside = self.map.getLocalPosition(G[3], G[4], G[5])           # PMAIN:141 / 146 (quirk Q9)
             xx, uu = planner_seed(self.N, x0, 0.2, self.dt)
             P.solve(x0, xx, uu, 0, 0, 0, self.first_it, self.HW)
             self.first_it += 1
@@ -214,15 +216,17 @@ def planner_main():
     HW = rospy.get_param("/TrajectoryPlanner/halfWidth")
     loop_rate = rospy.get_param("/TrajectoryPlanner/Frecuency")
     N = rospy.get_param("/TrajectoryPlanner/N")
+    testing = int(rospy.get_param("/TrajectoryPlanner/Testing", 0)) == 1      # PLANNER_TEST.launch: planner alone, open loop (PMAIN:59-69)
     state = _Latest([0.0] * 6)
     lap = _Latest(0)
-    rospy.Subscriber("pos_info", pos_info, lambda m: state.set([m.v_x, m.v_y, m.psiDot, m.x, m.y, m.psi]))
+    if not testing:
+        rospy.Subscriber("pos_info", pos_info, lambda m: state.set([m.v_x, m.v_y, m.psiDot, m.x, m.y, m.psi]))
     rospy.Subscriber("Racing_Info", Racing_Info, lambda m: lap.set(m.LapNumber))
     rate = rospy.Rate(loop_rate)
-    node = PlannerNode(_ros_map(), N, 1.0 / loop_rate, HW)
+    node = PlannerNode(_ros_map(), N, 1.0 / loop_rate, HW, testing=testing)
     refs = My_Planning()
     while not rospy.is_shutdown():
-        if lap.value >= 1:                                     # PMAIN:129
+        if lap.value >= 1 or testing:                          # PMAIN:129
             refs.x_d, refs.y_d, refs.psi_d, refs.vx_d, refs.curv_d = [list(a) for a in node.step(state.value)]
             pub.publish(refs)
         rate.sleep()

@@ -185,7 +185,7 @@ def test_ros_wiring_with_stub_rospy(monkeypatch):
     rospy.init_node = lambda name: None
     rospy.Publisher = Pub
     rospy.Subscriber = subscriber
-    rospy.get_param = lambda k, *a: params[k]
+    rospy.get_param = lambda k, *a: params[k] if k in params or not a else a[0]
     rospy.Rate = lambda hz: types.SimpleNamespace(sleep=lambda: None)
     rospy.sleep = lambda s: None
     rospy.is_shutdown = is_shutdown
@@ -209,3 +209,12 @@ def test_ros_wiring_with_stub_rospy(monkeypatch):
     refs = published["My_Planning"]
     assert len(refs) == 3 and all(len(refs[-1][k]) == 61 for k in ("x_d", "y_d", "psi_d", "vx_d", "curv_d"))
     assert np.all(np.isfinite(refs[-1]["vx_d"])) and refs[-1]["vx_d"][0] >= 0.9
+
+    # PLANNER_TEST.launch: Testing = 1 -- no estimator subscription, no lap gate, first state [1, 0, 0] at the pose (0, 0, 0)
+    params["/TrajectoryPlanner/Testing"] = 1
+    callbacks.clear(); published["My_Planning"] = []
+    ticks["n"] = 0; ticks["limit"] = 3
+    ros_nodes.planner_main()
+    assert "pos_info" not in callbacks
+    refs = published["My_Planning"]
+    assert len(refs) == 3 and np.all(np.isfinite(refs[-1]["vx_d"])) and abs(refs[0]["x_d"][0]) < 0.2 and abs(refs[0]["y_d"][0]) < 0.05
