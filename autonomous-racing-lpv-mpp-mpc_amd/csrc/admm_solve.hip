@@ -1200,7 +1200,7 @@ struct Solver {
             // dynamics row (k, tj): bounds l = u = b
             const double ztd = rmask * (ei * xt - dot);
             const double zrd = alpha * ztd + oma * zd;
-            const double znd = clipd(zrd + rinv_eq * yd, b, b);
+            const double znd = b;           // the projection of zrd + yd / rho on the one-point set [b, b]
             const double dyd = rho_eq * (zrd - znd), ynd = yd + dyd;
             // box row (k, tj)
             double w = wc, winv = wic;
@@ -1611,7 +1611,7 @@ struct Solver {
         A_mul(DX, Zd, Zb);
         sync();
         for (int e = opaque(tid); e < NS * 8; e += kStride) {
-            { const double b = dyn_bound(e), t = Zd[e] + Yd[e], z = clipd(t, b, b); Zd[e] = z; Yd[e] = t - z; }
+            { const double b = dyn_bound(e), t = Zd[e] + Yd[e]; Zd[e] = b; Yd[e] = t - b; }         // projection on [b, b]
             { const double t = Zb[e] + Yb[e], z = clipd(t, Lo[e], Hi[e]); Zb[e] = z; Yb[e] = t - z; }
         }
         sync();

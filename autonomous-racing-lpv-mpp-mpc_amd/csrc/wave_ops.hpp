@@ -172,7 +172,14 @@ __device__ inline double inv_sqrt(double x) {
 }
 // projection on [lo, hi] (lo <= hi): two instructions (v_max_f64, v_min_f64) instead of compare / select pairs; equal to
 // t < lo ? lo : (t > hi ? hi : t) for every non-NaN t (a NaN maps to lo, as OSQP's c_min(c_max(z, l), u) does)
-__device__ inline double clipd(double t, double lo, double hi) { return fmin(fmax(t, lo), hi); }
+// Written as the two instructions themselves: through fmax / fmin the compiler first quiets each operand that comes from memory
+// (a v_max_f64 x, x apiece), which the hardware's IEEE-mode max / min do anyway.
+__device__ inline double clipd(double t, double lo, double hi) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(t), "v"(lo));
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(r), "v"(hi));
+    return r;
+}
 
 
 }  // namespace lpvmpc
