@@ -31,6 +31,13 @@
  * use 100.
  *
  * What pins this oracle instead of OSQP itself (tests/test_oracle_osqp.py):
+ *   - the one trace of the real solver available without the wheel: the log OSQP prints for the "Setup and solve"
+ *     example of its own documentation (2 variables, 3 constraints, alpha = 1.0).  This file reproduces every printed
+ *     digit of it -- iteration 1: objective -4.9384e-03, residuals 1.00e+00 / 2.00e+02; iteration 50: 1.8800e+00,
+ *     1.91e-07 / 7.50e-07, rho 1.38e+00, "solved" after 50 iterations -- and only with the rho update at iteration 25
+ *     (test_oracle_reproduces_the_published_osqp_log, test_published_osqp_log_selects_the_rho_update_interval).
+ *     It is a published vector of the third-party solver, not a fixture of the reference repository, so the stage
+ *     stays "unpinned" in the sense of the rule above; it is the strongest anchor there is.
  *   - a solver-independent KKT certificate of every returned solution
  *     (oracle/kkt_cert.py: active-set solve with numpy, stationarity/feasibility/
  *     complementarity <= 1e-8), and
