@@ -34,7 +34,7 @@ namespace lpvmpc {
 #define STAMP(slot) do { } while (0)
 #endif
 
-template <int NX, int NT, int NW, bool MF = false>
+template <int NX, int NT, int NW, bool MF = false, bool GS = false>
 struct Solver {
 #ifdef LPVMPC_STAMPS
     unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -90,7 +90,9 @@ struct Solver {
     // ADMM weight of this thread's box rows (one per element round) and its reciprocal: the class of a row (loose / equality /
     // inequality, OSQP set_rho_vec) follows from its bounds alone, so the pair is fixed between two rho updates -- kept in
     // registers instead of three f64 compares and eight selects per element and iteration in update()
-    static constexpr bool kCacheW = kReg && (MF || (NW == 2 && NT > 20));   // (the N <= 20 DPP / one-wave instantiations have no registers to spare)
+    static constexpr bool kGs = GS;                 // the equilibration vectors D / Ed / Eb live in global memory (SolveArgs::scal)
+    static_assert(!GS || (NW == 2 && NT > 20 && !MF), "global scalings: planner two-wavefront kernels only");
+    static constexpr bool kCacheW = kReg && !GS && (MF || (NW == 2 && NT > 20));   // (the N <= 20 DPP / one-wave instantiations have no registers to spare)
     static constexpr int kRnd = kCacheW ? ((NT + 1) * 8 + kStride - 1) / kStride : 1;
     double wbx[kRnd], wbxi[kRnd];
     __device__ __forceinline__ void cache_box_weights() {
@@ -128,6 +130,13 @@ struct Solver {
         X = p; p += V; Qv = p; p += V; D = p; p += V; XT = p; p += V; DX = p; p += V; VT = p; p += V; AT = p; p += V;
         Zd = p; p += V; Yd = p; p += V; Ed = p; p += V; ZTd = p; p += V; DYd = p; p += V;
         Zb = p; p += V; Yb = p; p += V; Eb = p; p += V; ZTb = p; p += V; DYb = p; p += V;
+        if constexpr (GS) {     // D, Ed, Eb are bound to global memory by run(): the same walk without their three slots
+            p = smem + NS * kTS;
+            X = p; p += V; Qv = p; p += V; XT = p; p += V; DX = p; p += V; VT = p; p += V; AT = p; p += V;
+            Zd = p; p += V; Yd = p; p += V; ZTd = p; p += V; DYd = p; p += V;
+            Zb = p; p += V; Yb = p; p += V; ZTb = p; p += V; DYb = p; p += V;
+            D = Ed = Eb = nullptr;
+        }
         Lo = p; p += V; Hi = p; p += V;
         beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; RED = p; p += 80; SINK = p; p += 64 + 8 * NS;
         {
@@ -146,7 +155,7 @@ struct Solver {
         tlane = 8 * dgroup(lj) + li;
     }
     static __host__ __device__ size_t lds_doubles(int N) {
-        return (size_t)(N + 1) * ((kReg ? 1 : 3) * kTS + 19 * 8 + 8) + 16 + 64 + 8 + 80 + 64;
+        return (size_t)(N + 1) * ((kReg ? 1 : 3) * kTS + (GS ? 16 : 19) * 8 + 8) + 16 + 64 + 8 + 80 + 64;
     }
 
     // ---- problem structure ---------------------------------------------------------------------
@@ -1314,6 +1323,7 @@ struct Solver {
     __device__ __forceinline__ void run(const SolveArgs &a, int inst, int entry = -1) {
         bool bad = false;              // this thread saw a non-finite input word
         const bool resuming = entry >= 0;
+        if constexpr (GS) { D = a.scal + (size_t)inst * 3 * (NS * 8); Ed = D + NS * 8; Eb = Ed + NS * 8; }
         int iter0 = 1, to_chk0 = 0, to_adp0 = 0;
         if (resuming) {
             inst = restore(a, entry, iter0, to_chk0, to_adp0);
@@ -1630,15 +1640,16 @@ struct Solver {
 
 // waves per SIMD the kernel must allow: workgroups per CU are LDS-limited (4 at N = 20, 2 at N = 30 / 40), so only
 // the N <= 20 two-wavefront kernels need two waves per SIMD (<= 256 registers); the others may use up to 512
-template <int NT, int NW>
+// -- and the planner N = 30 kernel with its equilibration vectors in global memory (three instances per CU: six waves on four SIMDs)
+template <int NT, int NW, bool GS>
 #ifdef LPVMPC_FORCE_TWO_WAVES_PER_SIMD
 constexpr int min_waves_per_simd() { return NW; }      // diagnostic: provoke register spilling in the big-N kernels
 #else
-constexpr int min_waves_per_simd() { return (NW == 2 && NT <= 20) ? 2 : 1; }
+constexpr int min_waves_per_simd() { return ((NW == 2 && NT <= 20) || GS) ? 2 : 1; }
 #endif
 
-template <int NX, int NT, int NW, bool MF = false>
-__global__ void __launch_bounds__(64 * NW, (min_waves_per_simd<NT, NW>())) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
+template <int NX, int NT, int NW, bool MF = false, bool GS = false>
+__global__ void __launch_bounds__(64 * NW, (min_waves_per_simd<NT, NW, GS>())) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
     extern __shared__ __align__(16) double smem[];
     int inst = blockIdx.x, entry = -1;
     if (a.resume) {
@@ -1655,13 +1666,13 @@ __global__ void __launch_bounds__(64 * NW, (min_waves_per_simd<NT, NW>())) admm_
         entry = blockIdx.x;
         if (entry >= (n < a.pool_cap ? n : a.pool_cap)) return;
     } else if (inst >= a.B) return;
-    Solver<NX, NT, NW, MF> s(*cfgp, smem);
+    Solver<NX, NT, NW, MF, GS> s(*cfgp, smem);
     s.run(a, inst, entry);
 }
 
-template <int NX, int NT, int NW, bool MF = false>
+template <int NX, int NT, int NW, bool MF = false, bool GS = false>
 static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream) {
-    const size_t lds = Solver<NX, NT, NW, MF>::lds_doubles(cfg.N) * sizeof(double);
+    const size_t lds = Solver<NX, NT, NW, MF, GS>::lds_doubles(cfg.N) * sizeof(double);
     // The LDS opt-in is a per-function AND per-device attribute: remember it per (instantiation, device ordinal).  Handles on
     // different devices may launch from different threads (lpvmpc.h: thread-safe across handles), hence the atomic mask.
     static std::atomic<uint64_t> attr_mask[4];           // 256 device ordinals
@@ -1670,11 +1681,11 @@ static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveA
     const uint64_t bit = 1ull << (dev & 63);
     std::atomic<uint64_t> &word = attr_mask[(dev >> 6) & 3];
     if (!(word.load(std::memory_order_acquire) & bit)) {
-        hipError_t err = hipFuncSetAttribute((const void *)admm_solve_kernel<NX, NT, NW, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t err = hipFuncSetAttribute((const void *)admm_solve_kernel<NX, NT, NW, MF, GS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (err != hipSuccess) return err;
         word.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((admm_solve_kernel<NX, NT, NW, MF>), dim3(a.resume ? a.pool_cap : a.B), dim3(64 * NW), lds, stream, dcfg, a);
+    hipLaunchKernelGGL((admm_solve_kernel<NX, NT, NW, MF, GS>), dim3(a.resume ? a.pool_cap : a.B), dim3(64 * NW), lds, stream, dcfg, a);
     return hipGetLastError();
 }
 
@@ -1700,8 +1711,12 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
         return launch_one<6, 0, 1>(cfg, dcfg, a, stream);
     }
     const bool mf = kernel_variant == 4;      // diagnostic: the planner kernels with MFMA sweeps (slower at one wavefront per SIMD)
+    // default at N = 30: the equilibration vectors in global memory (three instances per CU) whenever the caller provides the
+    // room and nothing is parked or resumed (a parked image is the LDS image); kernel_variant 5 keeps them in LDS (two per CU)
+    const bool gs = kernel_variant == 0 && a.scal != nullptr && a.defer_after == 0 && !a.resume;
     if (!generic && cfg.N == 30) return one_wave ? launch_one<5, 30, 1>(cfg, dcfg, a, stream)
-                                          : (mf ? launch_one<5, 30, 2, true>(cfg, dcfg, a, stream) : launch_one<5, 30, 2>(cfg, dcfg, a, stream));
+                                          : (mf ? launch_one<5, 30, 2, true>(cfg, dcfg, a, stream)
+                                                : (gs ? launch_one<5, 30, 2, false, true>(cfg, dcfg, a, stream) : launch_one<5, 30, 2>(cfg, dcfg, a, stream)));
     if (!generic && cfg.N == 40) return launch_one<5, 40, 2>(cfg, dcfg, a, stream);
     if (!generic && cfg.N == 20) return launch_one<5, 20, 2>(cfg, dcfg, a, stream);      // the planner half of configs[3]
     return launch_one<5, 0, 1>(cfg, dcfg, a, stream);

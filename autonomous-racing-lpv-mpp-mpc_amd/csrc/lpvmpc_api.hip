@@ -62,11 +62,11 @@ extern "C" void lpvmpc_default_config(int32_t kind, lpvmpc_config *c) {
 
 static void free_ws(lpvmpc_handle *h) {
     void *ptrs[] = {h->d_x0, h->d_uprev, h->d_vel, h->d_curv, h->d_uold, h->d_maxey, h->d_AB, h->d_states,
-                    h->d_xPred, h->d_uPred, h->d_resid, h->d_xlast, h->d_delta, h->d_status, h->d_iters, h->d_polish, h->d_state};
+                    h->d_xPred, h->d_uPred, h->d_resid, h->d_xlast, h->d_delta, h->d_status, h->d_iters, h->d_polish, h->d_state, h->d_scal};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     h->d_x0 = h->d_uprev = h->d_vel = h->d_curv = h->d_uold = h->d_maxey = h->d_AB = h->d_states = nullptr;
     h->d_xPred = h->d_uPred = h->d_resid = h->d_xlast = h->d_delta = nullptr;
-    h->d_status = h->d_iters = h->d_polish = nullptr; h->d_state = nullptr; h->state_valid_B = 0;
+    h->d_status = h->d_iters = h->d_polish = nullptr; h->d_state = nullptr; h->d_scal = nullptr; h->state_valid_B = 0;
     h->cap = 0;
 }
 
@@ -130,6 +130,7 @@ static int ensure_ws(lpvmpc_handle *h, int B) {
     ALLOC(h->d_xPred, b * (N + 1) * nx * 8); ALLOC(h->d_uPred, b * N * 2 * 8); ALLOC(h->d_resid, b * 4 * 8);
     ALLOC(h->d_xlast, b * N * 6 * 8); ALLOC(h->d_delta, b * N * 8);
     ALLOC(h->d_state, b * 3 * (N + 1) * 8 * 8);
+    if (h->cfg.kind == LPVMPC_KIND_PLANNER && N == 30) ALLOC(h->d_scal, b * 3 * (N + 1) * 8 * 8);      // see SolveArgs::scal
     ALLOC(h->d_status, b * 4); ALLOC(h->d_iters, b * 4); ALLOC(h->d_polish, b * 4);
 #undef ALLOC
     h->cap = B;
@@ -155,7 +156,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->d_cfg = nullptr; h->cap = 0; h->force_generic = 0; h->timing = false; h->last_ms = -1.0; h->stream = nullptr; h->ev_count = 0;
     h->d_x0 = h->d_uprev = h->d_vel = h->d_curv = h->d_uold = h->d_maxey = h->d_AB = h->d_states = nullptr;
     h->d_xPred = h->d_uPred = h->d_resid = h->d_xlast = h->d_delta = nullptr;
-    h->d_status = h->d_iters = h->d_polish = nullptr; h->d_state = nullptr; h->warm_mode = 0; h->state_valid_B = 0;
+    h->d_status = h->d_iters = h->d_polish = nullptr; h->d_state = nullptr; h->d_scal = nullptr; h->warm_mode = 0; h->state_valid_B = 0;
     h->cl_plant = h->cl_local = h->cl_cmd = nullptr; h->cl_local_next = nullptr; h->cl_next_valid = 0; h->cl_B = 0; h->cl_first_it = 1; h->cl_q9 = 1; h->cl_ticks = 0;
     h->d_Wop = h->d_FWop = nullptr; h->ho_M = 0; h->cascade = nullptr; h->cascade_owner = nullptr; h->cascade_prefetch = 1;
     h->defer_after = 0; h->defer_budget = 200; h->defer_cap = 0; h->defer_cur_cap = 0; h->defer_stride = 0; h->rv_count = 0;
@@ -235,7 +236,7 @@ extern "C" int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t val
         if (value < 0 || value > 2) return fail(h, LPVMPC_E_ARG, "warm_start must be 0 (off), 1 (previous solution) or 2 (shifted by one stage)");
         h->warm_mode = value; h->state_valid_B = 0; return LPVMPC_OK;
     }
-    if (std::strcmp(name, "kernel_variant") == 0) { if (value < 0 || value > 4) return fail(h, LPVMPC_E_ARG, "kernel_variant must be 0 .. 4"); h->force_generic = value; return LPVMPC_OK; }
+    if (std::strcmp(name, "kernel_variant") == 0) { if (value < 0 || value > 5) return fail(h, LPVMPC_E_ARG, "kernel_variant must be 0 .. 5"); h->force_generic = value; return LPVMPC_OK; }
     if (std::strcmp(name, "defer_after") == 0) {
         if (value < 0) return fail(h, LPVMPC_E_ARG, "defer_after must be >= 0 (iterations; 0 = off)");
         if (value == 0 && h->defer_after > 0 && h->dpool[0]) { int rc = lpvmpc_join(h, (void *)h->defer_stream); if (rc) return rc; }   // nothing stays parked
@@ -312,7 +313,9 @@ static int launch_lpv(lpvmpc_handle *h, int B, const double *x0, const double *u
 int lpvmpc_launch_solve_timed(lpvmpc_handle *h, const SolveArgs &a, hipStream_t st) {
     const int slot = h->ev_count % kEventRing;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0[slot], st));
-    HIP_TRY(h, lpvmpc::launch_solve(h->dev, h->d_cfg, a, st, h->force_generic));
+    SolveArgs b = a;
+    if (h->d_scal && a.B <= h->cap) b.scal = h->d_scal;          // (the launcher ignores it for deferred / resumed launches)
+    HIP_TRY(h, lpvmpc::launch_solve(h->dev, h->d_cfg, b, st, h->force_generic));
     if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev1[slot], st)); h->ev_count++; }
     return LPVMPC_OK;
 }

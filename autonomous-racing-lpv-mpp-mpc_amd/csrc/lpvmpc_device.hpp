@@ -76,6 +76,10 @@ struct SolveArgs {
     int32_t *pool_in_count; // [2]: entries, and the number of resume workgroups that have read it (the last reader clears both:
                             // the pool is empty again when the pass ends, without a separate memset launch)
     int pool_cap, pool_stride;
+    // planner N = 30, no deferral: the three equilibration vectors (D, E of the dynamics rows, E of the box rows) of instance i
+    // live at scal + i * 3 * 8 (N + 1) in global memory instead of LDS (they are read at set-up, at the termination checks and by
+    // the factorisations, never inside an ADMM iteration), which brings the instance under a third of a CU's LDS; null: in LDS
+    double *scal;
 };
 constexpr int kParkScalars = 16;     // behind the LDS image of a pool entry: c, cinv, rho, iter, to_chk, to_adp, instance index and the
                                      // instance's output pointers (xPred, uPred, status, iters, polish, resid, state) as 64-bit words

@@ -27,6 +27,7 @@ struct lpvmpc_handle {
     // device workspace
     double *d_x0, *d_uprev, *d_vel, *d_curv, *d_uold, *d_maxey, *d_AB, *d_states, *d_xPred, *d_uPred, *d_resid;
     double *d_xlast, *d_delta;
+    double *d_scal;          // planner N = 30: the kernel's equilibration vectors [cap][3][8(N+1)] (SolveArgs::scal), else null
     double *d_state;         // warm-start state [cap][3][8(N+1)] (opt-in)
     int warm_mode, state_valid_B;   // 0 off (default); instances whose state is valid from the previous solve
     // closed-loop fleet (lpvmpc_cl_*): plant [B][8], local state [B][6], command [B][2] and scratch

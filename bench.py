@@ -334,7 +334,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc.get("traffic_bytes_per_launch"), "traffic_source": pmc.get("source"),
                          "valu": pmc.get("valu"), "valu_source": pmc.get("source") if pmc.get("valu") else None,
-                         "kernel": "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, "" if planner or args.kernel_variant == 3 else ", MFMA sweeps"),
+                         "kernel": "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, (", equilibration vectors in global memory (3 instances per CU)" if args.kernel_variant == 0 and args.defer == 0 else "")
+                                                                            if planner else ("" if args.kernel_variant == 3 else ", MFMA sweeps")),
                          "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
                          "all_launches_avg_ms": (k_ms + r_ms) / max(k_n + r_n, 1),     # main + resume launches: what a kernel trace averages under the one kernel name
                          "resume_launches": ({"count": r_n, "avg_ms": r_ms / max(r_n, 1),

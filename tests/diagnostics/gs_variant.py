@@ -1,0 +1,18 @@
+import sys, time
+sys.path.insert(0, "/root/repo")
+import numpy as np, lpvmpc
+from lpvmpc import workloads
+w = workloads.planner_batch(4096, N=30, seed=1)
+outs = {}
+for v in (5, 0):
+    eng = workloads.make_solver(w); eng.set_option("kernel_variant", v)
+    o = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+    t0 = time.perf_counter()
+    for _ in range(3):
+        o = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+    t = (time.perf_counter() - t0) / 3
+    outs[v] = o
+    print("variant", v, "host-call time %.2f ms" % (t * 1e3), "iters mean %.1f" % o["iters"].mean(), flush=True)
+    eng.close()
+for k in ("status", "iters", "polish", "xPred", "uPred", "resid"):
+    print(k, np.array_equal(outs[0][k], outs[5][k], equal_nan=True))

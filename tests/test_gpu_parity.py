@@ -175,6 +175,26 @@ def test_kernel_variants_agree(lpvmpc):
                 assert np.max(np.abs(a["uPred"][pol] - b["uPred"][pol])) < 1e-8
 
 
+def test_planner_n30_global_scalings_kernel_is_bit_identical(lpvmpc):
+    """The default planner N = 30 kernel keeps its three equilibration vectors in global memory (three instances per CU);
+    kernel_variant 5 is the same code with them in LDS (two per CU).  Same arithmetic: every output word has to be equal, for a
+    batch that fills the chip unevenly and a small ragged one.  (With straggler deferral the handle uses the LDS form -- a parked
+    image is the LDS image -- tests/test_gpu_deferral.py compares that against this kernel.)"""
+    from lpvmpc import workloads
+    for B in (1700, 37):
+        w = workloads.planner_batch(B, N=30, seed=14)
+        outs = {}
+        for variant in (0, 5):
+            eng = workloads.make_solver(w)
+            eng.set_option("kernel_variant", variant)
+            outs[variant] = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+            outs[variant] = {k: np.array(v) for k, v in outs[variant].items() if isinstance(v, np.ndarray)}
+            eng.close()
+        for k in ("status", "iters", "polish", "xPred", "uPred", "resid"):
+            assert np.array_equal(outs[0][k], outs[5][k], equal_nan=True), k
+        assert (outs[0]["iters"] > 100).any()
+
+
 def _agree(out, ref, b, nx, tol_x):
     assert int(out["status"][b]) == int(ref["status"][b]), (b, out["status"][b], ref["status"][b], out["iters"][b], ref["iters"][b])
     assert int(out["iters"][b]) == int(ref["iters"][b]), (b, out["iters"][b], ref["iters"][b])

@@ -3,7 +3,10 @@
 
 The N = 20 kernels run at two wavefronts per SIMD (256 registers): a spill there is scratch traffic on the one path whose
 HBM traffic is supposed to be inputs + outputs only (round 1 carried 6 MB of scratch stores per 1024-instance launch).
-Usage: check_kernel_resources.py file.s [name-substring ...]   (default: every kernel of the file)"""
+Usage: check_kernel_resources.py file.s [name-substring ...] [--allow name-substring=bytes ...]
+(default: every kernel of the file; --allow tolerates up to that much scratch per lane in the kernels it names: the planner
+N = 30 kernel that has to fit 256 registers to run three instances per CU keeps 17 loop-invariant registers of its
+termination-check / re-factorisation code in scratch, none on the per-iteration path -- DESIGN.md section 4)"""
 import re
 import sys
 
@@ -29,14 +32,23 @@ def kernels(path):
 
 
 if __name__ == "__main__":
-    path, pats = sys.argv[1], sys.argv[2:]
+    path, args = sys.argv[1], sys.argv[2:]
+    allow, pats = {}, []
+    while args:
+        a = args.pop(0)
+        if a == "--allow":
+            name, _, lim = args.pop(0).partition("=")
+            allow[name] = int(lim)
+        else:
+            pats.append(a)
     bad = 0
     for k in kernels(path):
         if pats and not any(p in k["name"] for p in pats):
             continue
         spills, scratch = k.get("vgpr_spill_count", 0), k.get("private_segment_fixed_size", 0)
-        flag = spills > 0 or scratch > 0
+        limit = max([v for n, v in allow.items() if n in k["name"]] or [0])
+        flag = scratch > limit or (spills > 0 and limit == 0)
         print("%s %-70s vgpr %3d  vgpr spills %2d  scratch %3d B  (sgpr spills %d)" % (
-            "SPILL" if flag else "ok   ", k["name"][:70], k.get("vgpr_count", -1), spills, scratch, k.get("sgpr_spill_count", 0)))
+            "SPILL" if flag else ("allow" if spills or scratch else "ok   "), k["name"][:70], k.get("vgpr_count", -1), spills, scratch, k.get("sgpr_spill_count", 0)))
         bad += flag
     sys.exit(1 if bad else 0)
