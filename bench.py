@@ -627,7 +627,7 @@ def bench_cascade(args, rank, local_rank, world, dev):
                           "ctrl_kernel_avg_ms": cms / max(cn, 1)},
                "roofline": {"bound": "hbm", "achieved": bytes_launch / k_avg_s / 1e9 if pn else float("nan"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": (bytes_launch / k_avg_s / 1e9 / HBM_PEAK_GBS) if pn else float("nan"), "traffic": None,
-                            "kernel": "admm_solve_kernel<5, 40, 2>", "kernel_avg_ms": pms / max(pn, 1), "launches": pn,
+                            "kernel": "admm_solve_kernel<5, 40, 2, MFMA sweeps>", "kernel_avg_ms": pms / max(pn, 1), "launches": pn,
                             "note": "planner solve kernel (95 % of a tick); algorithmic bytes from the iteration counts of the last planner tick; the sub-fleets' launches overlap, so kernel_avg_ms is the duration of a launch sharing the chip"}}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_cascade(c, mp, W)

@@ -95,12 +95,15 @@ def test_planner_node_with_handoff_trace():
         p.OldSteering.append(p.uPred[0, 0]); p.OldAccelera.append(p.uPred[0, 1])
         refs = ho.update()
         # the planner's polish rarely succeeds, so its iterates are eps-accurate and the open-loop recursion amplifies solver
-        # round-off by about 2x per tick (1e-12 at tick 0, 1e-7 at tick 16, 1e-5 at tick 20): the strict window is 16 ticks
+        # round-off (1e-12 at tick 0, 1e-8 at tick 13, 1e-5 at tick 17 -- tests/diagnostics/handoff_trace_growth.py).  Tick 14 is
+        # an eps-sensitive QP where every kernel variant jumps to ~1e-6 (DPP sweeps 7e-7, MFMA sweeps 1.3e-6, equal iteration
+        # counts throughout): 1e-6 for the first 14 ticks, 1e-5 for the last two
+        tol = 1e-6 if tick < 14 else 1e-5
         assert p.iters == g["plan_iters"][tick], tick
-        assert np.max(np.abs(p.xPred - g["plan_xPred"][tick])) <= 1e-6, tick
-        assert np.max(np.abs(ho.SS - g["plan_SS_out"][tick])) <= 1e-6, tick
-        assert np.max(np.abs(np.array([ho.xp, ho.yp, ho.yaw, ho.vel, ho.curv]) - g["plan_sig"][tick])) <= 1e-6, tick
-        assert refs.shape == (5, 61) and np.max(np.abs(refs - g["plan_refs"][tick])) <= 1e-6, tick
+        assert np.max(np.abs(p.xPred - g["plan_xPred"][tick])) <= tol, tick
+        assert np.max(np.abs(ho.SS - g["plan_SS_out"][tick])) <= tol, tick
+        assert np.max(np.abs(np.array([ho.xp, ho.yp, ho.yaw, ho.vel, ho.curv]) - g["plan_sig"][tick])) <= tol, tick
+        assert refs.shape == (5, 61) and np.max(np.abs(refs - g["plan_refs"][tick])) <= tol, tick
         assert np.array_equal(ho.curv_d, refs[4]) and np.array_equal(ho.vx_d, refs[3])
 
 

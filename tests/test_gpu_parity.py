@@ -145,10 +145,10 @@ def test_fused_batch_cfg2_against_oracle(lpvmpc):
 
 def test_kernel_variants_agree(lpvmpc):
     """Four kernels run the same algorithm: variant 0 (default: compile-time horizon, two wavefronts per instance, two-sided
-    elimination; controller N = 20: sweeps and factorisation on the matrix cores), variant 3 (the same with DPP sweeps: what
-    the planner kernels use), variant 2 (compile-time horizon, one wavefront) and variant 1 (run-time horizon, factor tiles in
-    LDS): identical statuses / polish flags, iteration counts equal (the factorisations differ in elimination order, i.e. in
-    round-off only), solutions equal to 1e-6 (1e-8 when polished).  This cross-check is also the run-time guard behind the
+    elimination; controller N = 20 and planner N = 40: sweeps and factorisation on the matrix cores), variant 3 (the same with
+    DPP sweeps: what the other planner kernels use), variant 2 (compile-time horizon, one wavefront) and variant 1 (run-time
+    horizon, factor tiles in LDS): identical statuses / polish flags, iteration counts equal (the factorisations differ in
+    elimination order, i.e. in round-off only), solutions equal to 5e-6 (1e-8 when polished).  This cross-check is also the run-time guard behind the
     build's assembly scan (Makefile: a toolchain that mis-compiles one instantiation shows up here)."""
     from lpvmpc import workloads
     for w in (workloads.controller_batch(128, N=20, seed=5), workloads.planner_batch(64, N=30, seed=6),
@@ -168,8 +168,8 @@ def test_kernel_variants_agree(lpvmpc):
             ok = np.isin(a["status"], (1, 2, -2))
             # polished instances sit on the same optimum; un-polished planner iterates after thousands of iterations carry
             # the (different) round-off of the two elimination orders
-            assert np.max(np.abs(a["xPred"][ok] - b["xPred"][ok])) < 1e-6
-            assert np.max(np.abs(a["uPred"][ok] - b["uPred"][ok])) < 1e-6
+            assert np.max(np.abs(a["xPred"][ok] - b["xPred"][ok])) < 5e-6         # observed: 1.5e-6 (N = 40, MFMA against LDS-tile kernel)
+            assert np.max(np.abs(a["uPred"][ok] - b["uPred"][ok])) < 5e-6
             pol = ok & (a["polish"] == 1)
             if pol.any():
                 assert np.max(np.abs(a["uPred"][pol] - b["uPred"][pol])) < 1e-8
