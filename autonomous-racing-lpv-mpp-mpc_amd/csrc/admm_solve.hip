@@ -1720,7 +1720,7 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
     // N = 40 (the cascade's planner horizon): MFMA sweeps and factorisation by default (two instances per CU, one wavefront per SIMD:
     // the shorter dependent chains count for more here than at N = 30, where three instances per CU win); kernel_variant 3 = DPP sweeps
     if (!generic && cfg.N == 40) return dpp ? launch_one<5, 40, 2>(cfg, dcfg, a, stream) : launch_one<5, 40, 2, true>(cfg, dcfg, a, stream);
-    if (!generic && cfg.N == 20) return launch_one<5, 20, 2>(cfg, dcfg, a, stream);      // the planner half of configs[3]
+    if (!generic && cfg.N == 20) return dpp ? launch_one<5, 20, 2>(cfg, dcfg, a, stream) : launch_one<5, 20, 2, true>(cfg, dcfg, a, stream);     // the planner half of configs[3]
     return launch_one<5, 0, 1>(cfg, dcfg, a, stream);
 }
 

@@ -120,7 +120,7 @@ int lpvmpc_last_error_code(void);
  * CTRL:302,316 / PLAN:204-208; default); 1 = start from the previous solve's (x, y) of the same handle and
  * batch size; 2 = the same shifted by one stage (receding horizon).  Opt-in, changes iteration counts, not optima.
  * "cascade_prefetch" (0/1, default 1): read by lpvmpc_cascade_init on the controller handle, see there.
- * "kernel_variant" 3 = the DPP two-wavefront kernels of round 1 for the controller at N = 20 and the planner at N = 40 (their
+ * "kernel_variant" 3 = the DPP two-wavefront kernels of round 1 for the controller at N = 20 and the planner at N = 20 / 40 (their
  * defaults run the KKT sweeps and the factorisation on the matrix cores); 4 = the planner N = 30 kernel with MFMA sweeps (diagnostic); 5 = the planner N = 30 kernel with
  * every vector in LDS (two instances per CU; the default keeps its three equilibration vectors in global memory and fits three).
  * "defer_after" (iterations, 0 = off, default): STRAGGLER DEFERRAL for lpvmpc_solve_batch_dev.  One OSQP solve in a thousand

@@ -9,7 +9,7 @@ import lpvmpc
 from lpvmpc import workloads
 from oracle import osqp_ref as O
 
-w = workloads.planner_batch(2048, N=40, seed=1)
+w = workloads.planner_batch(2048, N=int(os.environ.get("NPLAN", "40")), seed=1)
 ref = O.plan_tick_batch(w, nthreads=16)
 outs = {}
 for v in (0, 4):
