@@ -1645,7 +1645,7 @@ template <int NT, int NW, bool GS>
 #ifdef LPVMPC_FORCE_TWO_WAVES_PER_SIMD
 constexpr int min_waves_per_simd() { return NW; }      // diagnostic: provoke register spilling in the big-N kernels
 #else
-constexpr int min_waves_per_simd() { return ((NW == 2 && NT <= 20) || GS) ? 2 : 1; }
+constexpr int min_waves_per_simd() { return ((NW == 2 && NT <= 20) || (NW == 1 && NT > 0 && NT <= 8) || GS) ? 2 : 1; }     // N = 8 (one wavefront): 256 registers without a spill -> eight instances per CU
 #endif
 
 template <int NX, int NT, int NW, bool MF = false, bool GS = false>
