@@ -527,7 +527,7 @@ def bench_mixed(args, rank, local_rank, world, dev):
                           "solved_fraction": agg[2] / (2 * Bh * world), "stream_pairs": S,
                           "controller_kernel_avg_ms": kms[0] / max(kn[0], 1)},
                "roofline": {"bound": "hbm", "achieved": bl_p / k_avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bl_p / k_avg_s / 1e9 / HBM_PEAK_GBS,
-                            "traffic": None, "kernel": "admm_solve_kernel<5, 20, 2>", "kernel_avg_ms": kms[1] / max(kn[1], 1), "launches": kn[1],
+                            "traffic": None, "kernel": "admm_solve_kernel<5, 20, 2, MFMA sweeps>", "kernel_avg_ms": kms[1] / max(kn[1], 1), "launches": kn[1],
                             "algorithmic_bytes_per_launch": bl_p, "bytes_per_admm_iteration": bi_p,
                             "aggregate_algorithmic_GBps": (bl_c + bl_p) * args.steps * world / elapsed / 1e9,
                             "note": "dominant kernel = the planner half (about 12x the controller's iterations)"}}
