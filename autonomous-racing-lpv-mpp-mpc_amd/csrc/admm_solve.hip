@@ -1710,7 +1710,7 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
         if (!generic && cfg.N == 8) return launch_one<6, 8, 1>(cfg, dcfg, a, stream);      // the launch file's controller horizon (MAIN_LAUNCH.launch:117)
         return launch_one<6, 0, 1>(cfg, dcfg, a, stream);
     }
-    const bool mf = kernel_variant == 4;      // diagnostic: the planner kernels with MFMA sweeps (slower at one wavefront per SIMD)
+    const bool mf = kernel_variant == 4;      // diagnostic: the planner N = 30 kernel with MFMA sweeps (two instances per CU)
     // default at N = 30: the equilibration vectors in global memory (three instances per CU) whenever the caller provides the
     // room and nothing is parked or resumed (a parked image is the LDS image); kernel_variant 5 keeps them in LDS (two per CU)
     const bool gs = kernel_variant == 0 && a.scal != nullptr && a.defer_after == 0 && !a.resume;

@@ -146,7 +146,7 @@ def test_fused_batch_cfg2_against_oracle(lpvmpc):
 def test_kernel_variants_agree(lpvmpc):
     """Four kernels run the same algorithm: variant 0 (default: compile-time horizon, two wavefronts per instance, two-sided
     elimination; controller N = 20 and planner N = 40: sweeps and factorisation on the matrix cores), variant 3 (the same with
-    DPP sweeps: what the other planner kernels use), variant 2 (compile-time horizon, one wavefront) and variant 1 (run-time
+    DPP sweeps: what the planner N = 30 kernel uses), variant 2 (compile-time horizon, one wavefront) and variant 1 (run-time
     horizon, factor tiles in LDS): identical statuses / polish flags, iteration counts equal (the factorisations differ in
     elimination order, i.e. in round-off only), solutions equal to 5e-6 (1e-8 when polished).  This cross-check is also the run-time guard behind the
     build's assembly scan (Makefile: a toolchain that mis-compiles one instantiation shows up here)."""
