@@ -178,10 +178,10 @@ def test_kernel_variants_agree(lpvmpc):
 def test_planner_n30_global_scalings_kernel_is_bit_identical(lpvmpc):
     """The default planner N = 30 kernel keeps its three equilibration vectors in global memory (three instances per CU);
     kernel_variant 5 is the same code with them in LDS (two per CU).  Same arithmetic: every output word has to be equal, for a
-    batch that fills the chip unevenly and a small ragged one.  (With straggler deferral the handle uses the LDS form -- a parked
+    batch that fills the chip unevenly and a ragged one.  (With straggler deferral the handle uses the LDS form -- a parked
     image is the LDS image -- tests/test_gpu_deferral.py compares that against this kernel.)"""
     from lpvmpc import workloads
-    for B in (1700, 37):
+    for B in (1700, 601):                     # (batches of up to 512 instances take the LDS form anyway)
         w = workloads.planner_batch(B, N=30, seed=14)
         outs = {}
         for variant in (0, 5):
