@@ -1,10 +1,13 @@
+#!/usr/bin/env python3
+"""Planner N = 30: the default kernel (equilibration vectors in global memory, three instances per CU) against kernel_variant 5
+(all vectors in LDS, two per CU) on a GPU box: timing of a 4096-instance host call and word-for-word equality."""
 import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, lpvmpc
 from lpvmpc import workloads
 w = workloads.planner_batch(4096, N=30, seed=1)
 outs = {}
-for v in (5, 0):
+for v in (5, 0, 5, 0):          # alternating: the first timing of a process includes clock ramp-up
     eng = workloads.make_solver(w); eng.set_option("kernel_variant", v)
     o = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
     t0 = time.perf_counter()
