@@ -7,7 +7,7 @@ import numpy as np, lpvmpc
 from lpvmpc import workloads
 w = workloads.planner_batch(4096, N=30, seed=1)
 outs = {}
-for v in (5, 0, 5, 0):          # alternating: the first timing of a process includes clock ramp-up
+for v in (5, 0, 5, 0):          # alternating: the first timing of a process comes out slower (first-use set-up)
     eng = workloads.make_solver(w); eng.set_option("kernel_variant", v)
     o = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
     t0 = time.perf_counter()

@@ -12,7 +12,7 @@ from oracle import osqp_ref as O
 w = workloads.planner_batch(2048, N=int(os.environ.get("NPLAN", "40")), seed=1)
 ref = O.plan_tick_batch(w, nthreads=16)
 outs = {}
-for v in (3, 0, 3, 0):          # twice, alternating: the first timing of a process includes clock ramp-up
+for v in (3, 0, 3, 0):          # twice, alternating: the first timing of a process comes out slower (first-use set-up)
     eng = workloads.make_solver(w); eng.set_option("kernel_variant", v)
     o = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
     t0 = time.perf_counter()
