@@ -124,6 +124,106 @@ __global__ void __launch_bounds__(64) ctrl_lpv_kernel(const DevCfg *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same roll-out in two launches (used whenever AB is wanted, i.e. by every caller of the library).
+// Quirk Q5 makes most of a controller stage independent of the rolled-out state: vx comes from vel_ref, the steering angle from
+// u_prev.  Only vy (one summand of A[0][2]), epsi and ey (rows 3-5) and -- on lap 0 -- the curvature at the rolled-out s are not
+// known in advance.  The serial kernel above executes ~600 double-precision instructions per stage on one lane per instance
+// (two sincos, nine divisions, 48 multiply-adds, 54 strided stores): 16 wavefronts busy for 42 us at B = 1024.  Here
+//   ctrl_lpv_pre_kernel   one thread per (instance, stage): sincos(delta), the tyre terms with their six divisions, and the
+//                         whole AB tile written (the seven state-dependent entries as place-holders; slot [0][2] carries the
+//                         state-independent summand of a13);
+//   ctrl_lpv_roll_kernel  one lane per instance, per stage: sincos(epsi), 1/den and two more divisions, the seven entries,
+//                         the structurally non-zero products of the mat-vec and 13 stores.
+// Every value is formed by the same operations in the same order as in ctrl_stage / the loop above (products with the
+// structural zeros only ever added +-0), so the outputs are the same values (the sign of an exact zero aside).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) ctrl_lpv_pre_kernel(const DevCfg *__restrict__ cp, int B, const double *__restrict__ u_prev,
+                                                          const double *__restrict__ vel_ref, double cf_new, double *__restrict__ AB) {
+    const DevCfg &c = *cp;
+    const int N = c.N;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * N) return;
+    const int b = t / N, i = t - b * N;
+    const double vx = vel_ref[(size_t)b * (N + 1) + i], delta = u_prev[(size_t)t * 2];
+    const double Cf = cf_new, Cr = cf_new, m = c.m, I = c.Iz, lf = c.lf, lr = c.lr, dt = c.dt;
+    double sd, cd;
+    sincos(delta, &sd, &cd);
+    const double a12 = (sd * Cf) / (m * vx);
+    const double p13 = (sd * Cf * lf) / (m * vx);                  // a13 = p13 + vy
+    const double a22 = -(Cr + Cf * cd) / (m * vx);
+    const double a23 = -(lf * Cf * cd - lr * Cr) / (m * vx) - vx;
+    const double a32 = -(lf * Cf * cd - lr * Cr) / (I * vx);
+    const double a33 = -(lf * lf * Cf * cd + lr * lr * Cr) / (I * vx);
+    const double b11 = -(sd * Cf) / m, b21 = (cd * Cf) / m, b31 = (lf * Cf * cd) / I;
+    double ab[6][8];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int a = 0; a < 8; ++a) ab[r][a] = 0.0;
+    ab[0][0] = 1.0 + dt * (-c.mu); ab[0][1] = dt * a12; ab[0][2] = p13;
+    ab[1][1] = 1.0 + dt * a22;     ab[1][2] = dt * a23;
+    ab[2][1] = dt * a32;           ab[2][2] = 1.0 + dt * a33;
+    ab[3][2] = dt * 1.0; ab[3][3] = 1.0;
+    ab[4][4] = 1.0;
+    ab[5][5] = 1.0;
+    ab[0][6] = dt * b11; ab[0][7] = dt * 1.0;
+    ab[1][6] = dt * b21;
+    ab[2][6] = dt * b31;
+    double *o = AB + (size_t)t * 48;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int a = 0; a < 8; ++a) o[r * 8 + a] = ab[r][a];
+}
+
+__global__ void __launch_bounds__(64) ctrl_lpv_roll_kernel(const DevCfg *__restrict__ cp, int B, const double *__restrict__ x0,
+                                                           const double *__restrict__ u_prev, const double *__restrict__ curv_ref,
+                                                           int lap, double *__restrict__ states, double *__restrict__ AB) {
+    const DevCfg &c = *cp;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int N = c.N;
+    const double dt = c.dt;
+    double st[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) st[r] = x0[(size_t)b * 6 + r];
+    for (int i = 0; i < N; ++i) {
+        double *o = AB + ((size_t)b * N + i) * 48;
+        // the state-independent entries the mat-vec needs (written by ctrl_lpv_pre_kernel)
+        const double a00 = o[0], a01 = o[1], p13 = o[2], a11 = o[9], a12_ = o[10], a21 = o[17], a22_ = o[18];
+        const double b06 = o[6], b07 = o[7], b16 = o[14], b26 = o[22];
+        const double vy = st[1], epsi = st[3], s = st[4], ey = st[5];
+        const double cur = (lap == 0) ? track_curvature(c, s) : curv_ref[(size_t)b * N + i];
+        const double u0 = u_prev[((size_t)b * N + i) * 2 + 0], u1 = u_prev[((size_t)b * N + i) * 2 + 1];
+        double se, ce;
+        sincos(epsi, &se, &ce);
+        const double den = 1.0 - ey * cur;
+        const double a02 = dt * (p13 + vy);
+        const double a30 = dt * ((1.0 / den) * (-ce * cur)), a31 = dt * ((1.0 / den) * (se * cur)), a32 = dt * 1.0;
+        const double a40 = dt * (ce / den), a41 = dt * (se / den);
+        const double a50 = dt * se, a51 = dt * ce;
+        // rows of [A | B] times [st ; u]: the products with structural zeros are left out (they only ever add +-0), the rest in
+        // the order of the dense loop: ((((((0 + p0) + p1) + p2) + p3) + p4) + p5) + (b6 u0 + b7 u1)
+        double nx[6];
+        nx[0] = ((a00 * st[0] + a01 * st[1]) + a02 * st[2]) + (b06 * u0 + b07 * u1);
+        nx[1] = (a11 * st[1] + a12_ * st[2]) + (b16 * u0 + 0.0 * u1);
+        nx[2] = (a21 * st[1] + a22_ * st[2]) + (b26 * u0 + 0.0 * u1);
+        nx[3] = (((a30 * st[0] + a31 * st[1]) + a32 * st[2]) + 1.0 * st[3]) + (0.0 * u0 + 0.0 * u1);
+        nx[4] = ((a40 * st[0] + a41 * st[1]) + 1.0 * st[4]) + (0.0 * u0 + 0.0 * u1);
+        nx[5] = ((a50 * st[0] + a51 * st[1]) + 1.0 * st[5]) + (0.0 * u0 + 0.0 * u1);
+        o[2] = a02;
+        o[24] = a30; o[25] = a31;
+        o[32] = a40; o[33] = a41;
+        o[40] = a50; o[41] = a51;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            st[r] = nx[r];
+            if (states) states[((size_t)b * N + i) * 6 + r] = nx[r];
+        }
+    }
+}
+
 // controller seed-mode linearisation, CTRL:732-809 (vx from the trajectory, curvature from the map)
 __global__ void __launch_bounds__(64) ctrl_abc_kernel(const DevCfg *__restrict__ cp, int B, const double *__restrict__ xlast,
                                                       const double *__restrict__ delta, double *__restrict__ AB) {
@@ -205,7 +305,10 @@ __global__ void __launch_bounds__(64) plan_abc_kernel(const DevCfg *__restrict__
 hipError_t launch_lpv(const DevCfg &cfg, const DevCfg *dcfg, int B, const double *x0, const double *u_prev, const double *vel_ref,
                       const double *curv_s, double cf_new, int lap, double *states, double *AB, hipStream_t stream) {
     const int blocks = (B + 63) / 64;
-    if (cfg.kind == 0)
+    if (cfg.kind == 0 && AB) {
+        hipLaunchKernelGGL(ctrl_lpv_pre_kernel, dim3((B * cfg.N + 63) / 64), dim3(64), 0, stream, dcfg, B, u_prev, vel_ref, cf_new, AB);
+        hipLaunchKernelGGL(ctrl_lpv_roll_kernel, dim3(blocks), dim3(64), 0, stream, dcfg, B, x0, u_prev, curv_s, lap, states, AB);
+    } else if (cfg.kind == 0)
         hipLaunchKernelGGL(ctrl_lpv_kernel, dim3(blocks), dim3(64), 0, stream, dcfg, B, x0, u_prev, vel_ref, curv_s, cf_new, lap, states, AB);
     else
         hipLaunchKernelGGL(plan_lpv_kernel, dim3(blocks), dim3(64), 0, stream, dcfg, B, x0, u_prev, curv_s, states, AB);
