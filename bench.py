@@ -117,6 +117,8 @@ def main():
             if world > 1:
                 dist.destroy_process_group()
     planner = args.workload == "cfg3"
+    if planner and args.batch == BATCH:
+        args.batch = 4096                                  # configs[2]: 4096 planner instances per GPU
     B, N = args.batch, (30 if planner else HORIZON)
     nx = 5 if planner else 6
     # One engine (workspace + output buffers), one HIP stream and one DISTINCT batch per in-flight slot: slot i solves the
