@@ -595,6 +595,7 @@ extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0,
     rc = lpvmpc_solve_batch_dev(h, B, (const double *)p_x0, (const double *)p_up, (const double *)p_vel, (const double *)p_curv,
                                 (const double *)p_uold, (const double *)p_mey, cf_new, lap, o_x, o_u, o_st, o_it, o_res, o_pol, (void *)st);
     if (rc) return rc;
+    if (h->defer_after > 0) { rc = lpvmpc_join(h, (void *)st); if (rc) return rc; }      // a synchronous call returns finished instances only
     return io.flush_out();
 }
 

@@ -132,7 +132,8 @@ int lpvmpc_last_error_code(void);
  * is still unsolved.  Results are bit-identical to the plain call (a restored instance re-factors K from its saved state).
  * Completion contract: an instance's outputs are final when its status is no longer LPVMPC_PENDING; lpvmpc_join(h, stream)
  * enqueues the pass that finishes whatever is still parked, so work behind it in `stream` sees complete outputs.  Until then
- * the output buffers of the deferred calls must stay valid and must not be reused for other data.
+ * the output buffers of the deferred calls must stay valid and must not be reused for other data.  The synchronous host-array
+ * call lpvmpc_solve_batch joins by itself before it copies the outputs back (it never returns LPVMPC_PENDING).
  * "defer_pool" (entries, 0 = max(64, B / 8), default): capacity of each of the two pools; instances that find the pool full
  * are not parked (they finish inside the launch that holds them). */
 int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value);

@@ -139,3 +139,20 @@ def test_deferral_with_warm_start_bad_inputs_and_housekeeping():
         _same(a, b)
     assert runs[0][0]["status"][7] == -10 and np.all(np.isnan(runs[0][0]["uPred"][7]))
     assert runs[0][1]["iters"].sum() < runs[0][0]["iters"].sum()          # the warm start did take effect
+
+
+def test_host_array_call_with_deferral_returns_finished_results():
+    """lpvmpc_solve_batch (host arrays, synchronous) on a handle with straggler deferral: the call joins before it copies the
+    outputs back, so no instance comes back LPVMPC_PENDING and every word equals the plain call's."""
+    from lpvmpc import workloads
+    w = workloads.controller_batch(1024, N=20, seed=16)          # seed 16 holds an instance that runs to max_iter
+    plain = workloads.make_solver(w)
+    ref = plain.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"])
+    plain.close()
+    eng = workloads.make_solver(w)
+    eng.set_option("defer_after", 100); eng.set_option("defer_budget", 100)
+    got = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"])
+    eng.close()
+    assert ref["iters"].max() > 1000 and not np.any(got["status"] == -11)
+    for k in ("status", "iters", "polish", "xPred", "uPred", "resid"):
+        assert np.array_equal(ref[k], got[k], equal_nan=True), k
