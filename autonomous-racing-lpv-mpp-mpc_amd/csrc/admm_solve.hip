@@ -34,18 +34,26 @@ namespace lpvmpc {
 #define STAMP(slot) do { } while (0)
 #endif
 
-template <int NX, int NT, int NW, bool MF = false, bool GS = false>
+template <int NX, int NT, int NW, bool MF = false, bool GS = false, bool TAIL = false>
 struct Solver {
 #ifdef LPVMPC_STAMPS
     unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #endif
     static constexpr int NB = NX + 2;
     static constexpr bool kCtrl = (NX == 6);
-    static constexpr bool kReg = (NT > 0);          // factor tiles in registers, horizon known at compile time
+    // TAIL: the whole-CU kernel that finishes parked stragglers ("tail kernel").  NW wavefronts share ONE
+    // instance: the KKT solve of an ADMM iteration is a dense product with K^-1, which is held in the registers of all of them
+    // (dense_apply); everything else -- the factorisation K^-1 is built from, the polish solves -- runs on wavefront 0 with the
+    // LDS-tile code of the run-time-horizon kernel.  It only ever resumes pool entries: its LDS begins with the image of the
+    // kernel that parked them (the compile-time-horizon layout).
+    static constexpr bool kTail = TAIL;
+    static constexpr bool kFixN = (NT > 0);         // horizon known at compile time
+    static constexpr bool kReg = kFixN && !TAIL;    // factor tiles in registers
     static constexpr bool kTwo = (NW == 2);         // two wavefronts per instance: two-sided ("twisted") elimination
     static constexpr bool kMf = MF;                 // the two sweeps run on the matrix cores (v_mfma_f64_4x4x4_4b_f64), see mf_forward
     static_assert(!MF || (NW == 2 && NT > 0), "the MFMA sweeps are written for the two-wavefront compile-time-horizon kernels");
-    static_assert(NW == 1 || (NW == 2 && NT >= 16 && NT % 2 == 0), "two wavefronts need an even compile-time horizon >= 16");
+    static_assert(TAIL || NW == 1 || (NW == 2 && NT >= 16 && NT % 2 == 0), "two wavefronts need an even compile-time horizon >= 16");
+    static_assert(!TAIL || (NT > 0 && NW == 8 && !MF && !GS), "the tail kernel: compile-time horizon, eight wavefronts, no MFMA sweeps");
     static constexpr bool kLastOdd = ((NT / 2 - 1) & 1) != 0;   // parity of the last chain position (both chains have NT/2 stages)
     static constexpr int kMid = NT / 2;             // NW == 2: wave 0 eliminates stages 0..kMid-1 upwards, wave 1 stages
     static constexpr int kP0 = kMid, kP1 = NT - kMid;   //         NT..kMid+1 downwards; stage kMid joins the two chains
@@ -77,6 +85,18 @@ struct Solver {
     double *Pm;    // [64] unscaled stage Hessian block 2*[Q 0; 0 R + 2 diag(dR)] (LDS copy of the weights)
     double *dRl;   // [8]  dR[0..1]
     double *RED;   // [80] per-wave partial results of block-wide reductions / chain hand-over (NW == 2)
+    // tail kernel only (behind the parked image): partial results of the block-wide reductions [96], two scratch tiles per
+    // wavefront for the block sweeps that build K^-1 [NW][128], and the staging area those sweeps deliver a round of kDenseRound
+    // block columns of K^-1 through [kDenseRound][NS][64]
+    double *RT, *WS, *STG;
+    // K^-1 in registers: thread (g = tid >> 3, s = tid & 7), tid < 8 * kDenseGroups, holds rows 3g .. 3g+2 of the columns 8 c + s
+    // (c = 0 .. NS-1): 63 doubles per thread at N = 20, 7 of the 8 wavefronts
+    static constexpr int kDC = TAIL ? NT + 1 : 1;
+    static constexpr int kDenseGroups = ((NT + 1) * 8 + 2) / 3;      // groups of three rows
+    static constexpr int kDenseRound = 7;                             // block columns per staging round
+    static constexpr int kActW = ((NT + 1) * 8 + 63) / 64;            // wavefronts that own elements in the element loops
+    static_assert(!TAIL || (8 * kDenseGroups <= 64 * NW && kActW <= 4), "tail kernel: K^-1 rows / element loops do not fit the workgroup");
+    double dm0[kDC], dm1[kDC], dm2[kDC];
     double c, cinv;
     // row weights: ADMM rho classes (OSQP set_rho_vec) or, while polishing, |flag| = 1/delta on active rows
     bool pol;
@@ -92,7 +112,7 @@ struct Solver {
     // registers instead of three f64 compares and eight selects per element and iteration in update()
     static constexpr bool kGs = GS;                 // the equilibration vectors D / Ed / Eb live in global memory (SolveArgs::scal)
     static_assert(!GS || (NW == 2 && NT > 20 && !MF), "global scalings: planner two-wavefront kernels only");
-    static constexpr bool kCacheW = kReg && !GS && (MF || (NW == 2 && NT > 20));   // (the N <= 20 DPP / one-wave instantiations have no registers to spare)
+    static constexpr bool kCacheW = (kReg && !GS && (MF || (NW == 2 && NT > 20))) || TAIL;   // (the N <= 20 DPP / one-wave instantiations have no registers to spare)
     static constexpr int kRnd = kCacheW ? ((NT + 1) * 8 + kStride - 1) / kStride : 1;
     double wbx[kRnd], wbxi[kRnd];
     __device__ __forceinline__ void cache_box_weights() {
@@ -120,12 +140,12 @@ struct Solver {
     }
 
     __device__ __forceinline__ Solver(const DevCfg &cf, double *smem)
-        : cfg(cf), N(kReg ? NT : cf.N), NS((kReg ? NT : cf.N) + 1), tid(threadIdx.x), wv(threadIdx.x >> 6), lane(threadIdx.x & 63),
+        : cfg(cf), N(kFixN ? NT : cf.N), NS((kFixN ? NT : cf.N) + 1), tid(threadIdx.x), wv(threadIdx.x >> 6), lane(threadIdx.x & 63),
           ti((threadIdx.x & 63) >> 3), tj(threadIdx.x & 7), delay(kCtrl ? cf.steering_delay : 0) {
         double *p = smem;
         tA = p; p += NS * kTS;
         tS = tL = nullptr;
-        if (!kReg) { tS = p; p += NS * kTS; tL = p; p += NS * kTS; }
+        if (!kFixN) { tS = p; p += NS * kTS; tL = p; p += NS * kTS; }
         const int V = NS * 8;
         X = p; p += V; Qv = p; p += V; D = p; p += V; XT = p; p += V; DX = p; p += V; VT = p; p += V; AT = p; p += V;
         Zd = p; p += V; Yd = p; p += V; Ed = p; p += V; ZTd = p; p += V; DYd = p; p += V;
@@ -139,6 +159,10 @@ struct Solver {
         }
         Lo = p; p += V; Hi = p; p += V;
         beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; RED = p; p += 80; SINK = p; p += 64 + 8 * NS;
+        RT = WS = STG = nullptr;
+        if constexpr (TAIL) {   // behind the image: factor tiles, reduction slots, sweep scratch, staging
+            tS = p; p += NS * kTS; tL = p; p += NS * kTS; RT = p; p += 96; WS = p; p += NW * 128; STG = p; p += kDenseRound * NS * 64;
+        }
         {
             int first, cnt; rows_on(tj, first, cnt);
             const int r0 = cnt >= 1 ? first : 7, r1 = cnt >= 2 ? first + 1 : 7, r2 = (kCtrl && tj == 6) ? 6 : 7;
@@ -154,8 +178,12 @@ struct Solver {
         li = 4 * ((lane >> 3) & 1) + (lane >> 4); lj = lane & 7;
         tlane = 8 * dgroup(lj) + li;
     }
+    // the part of the LDS block that a pool entry carries (try_park / restore): everything up to and including SINK
+    static __host__ __device__ size_t image_doubles(int N) {
+        return (size_t)(N + 1) * ((kFixN ? 1 : 3) * kTS + (GS ? 16 : 19) * 8 + 8) + 16 + 64 + 8 + 80 + 64;
+    }
     static __host__ __device__ size_t lds_doubles(int N) {
-        return (size_t)(N + 1) * ((kReg ? 1 : 3) * kTS + (GS ? 16 : 19) * 8 + 8) + 16 + 64 + 8 + 80 + 64;
+        return image_doubles(N) + (TAIL ? (size_t)(N + 1) * (2 * kTS + kDenseRound * 64) + 96 + NW * 128 : 0);
     }
 
     // ---- problem structure ---------------------------------------------------------------------
@@ -193,7 +221,7 @@ struct Solver {
     // wave-local ordering of LDS traffic (one wavefront executes its DS instructions in order; this only stops
     // the compiler from moving them across)
     __device__ __forceinline__ void wsync() const {
-        if constexpr (kTwo) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        if constexpr (kTwo || TAIL) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
     }
     // all-reduce over the whole instance (one or two wavefronts); both waves combine in the same order, so
@@ -206,12 +234,27 @@ struct Solver {
     __device__ __forceinline__ double bsum(double v) const {
         v = wave_sum(v);
         if constexpr (kTwo) { double *r = RED + 64 + 4 * SLOT; if (lane == 0) r[wv] = v; __syncthreads(); v = r[0] + r[1]; }
+        if constexpr (TAIL) { double *r = RT + 8 * SLOT; if (lane == 0 && wv < kActW) r[wv] = v; __syncthreads(); v = tail_sum(r); }
+        return v;
+    }
+    // tail kernel: the wavefronts beyond kActW own no element (their partial results are the neutral element and are not stored)
+    __device__ __forceinline__ static double tail_sum(const double *r) {
+        double v = r[0];
+#pragma unroll
+        for (int w = 1; w < kActW; ++w) v += r[w];
+        return v;
+    }
+    __device__ __forceinline__ static double tail_max(const double *r) {
+        double v = r[0];
+#pragma unroll
+        for (int w = 1; w < kActW; ++w) v = fmax(v, r[w]);
         return v;
     }
     template <int SLOT>
     __device__ __forceinline__ double bmax(double v) const {
         v = wave_max(v);
         if constexpr (kTwo) { double *r = RED + 64 + 4 * SLOT; if (lane == 0) r[2 + wv] = v; __syncthreads(); v = fmax(r[2], r[3]); }
+        if constexpr (TAIL) { double *r = RT + 8 * SLOT + 4; if (lane == 0 && wv < kActW) r[wv] = v; __syncthreads(); v = tail_max(r); }
         return v;
     }
     // sum of s and max of m over the instance with one barrier
@@ -224,6 +267,12 @@ struct Solver {
             if (lane == 0) { r[wv] = s_; r[2 + wv] = m_; }
             __syncthreads();
             s_ = r[0] + r[1]; m_ = fmax(r[2], r[3]);
+        }
+        if constexpr (TAIL) {
+            double *r = RT + 8 * SLOT;
+            if (lane == 0 && wv < kActW) { r[wv] = s_; r[4 + wv] = m_; }
+            __syncthreads();
+            s_ = tail_sum(r); m_ = tail_max(r + 4);
         }
         return SumMax{s_, m_};
     }
@@ -727,19 +776,128 @@ struct Solver {
             return;
         }
         double *const T = XT;
-        for (int k = 0; k <= N; ++k) {
-            const double kd = kd_block(k, sig);
-            double s = kd, l = 0.0;
-            if (k >= 1) { const SL r = schur_step(T, ko_down(k), kd); s = r.s; l = r.l; }
-            const double w = chol_inverse(s);
-            const double sinv = publish_and_invert(T, w);
-            if constexpr (kReg) {
-                const double lt = (k & 1) ? __shfl(l, tj * 8 + ti) : l;      // odd stages keep L_k transposed
+#ifdef LPVMPC_STAMPS
+        if constexpr (TAIL) tlast = __builtin_amdgcn_s_memtime();
+#endif
+        if (!TAIL || wv == 0) {     // (tail kernel: wavefront 0 factors, the tiles go to LDS)
+            for (int k = 0; k <= N; ++k) {
+                const double kd = kd_block(k, sig);
+                double s = kd, l = 0.0;
+                if (k >= 1) { const SL r = schur_step(T, ko_down(k), kd); s = r.s; l = r.l; }
+                const double w = chol_inverse(s);
+                const double sinv = publish_and_invert(T, w);
+                if constexpr (kReg) {
+                    const double lt = (k & 1) ? __shfl(l, tj * 8 + ti) : l;      // odd stages keep L_k transposed
 #pragma unroll
-                for (int kk = 0; kk <= NT; ++kk) if (kk == k) { rL[kk] = lt; rS[kk] = sinv; }
-            } else {
-                tL[k * kTS + ((k & 1) ? (tj * 8 + ti) : lane)] = l;
-                tS[k * kTS + lane] = sinv;
+                    for (int kk = 0; kk <= NT; ++kk) if (kk == k) { rL[kk] = lt; rS[kk] = sinv; }
+                } else {
+                    tL[k * kTS + ((k & 1) ? (tj * 8 + ti) : lane)] = l;
+                    tS[k * kTS + lane] = sinv;
+                }
+            }
+        }
+        sync();
+        if constexpr (TAIL) { STAMP(4); if (!pol) { dense_build(); STAMP(5); } }      // the ADMM system: K^-1 into the registers of the workgroup
+    }
+
+    // ---- tail kernel: K^-1 as a dense matrix in registers ---------------------------------------------------------------
+    // Block column c of K^-1 (the eight unit vectors of stage c at once) by block sweeps over the LDS tiles of the
+    // factorisation K = L S L' above:   Y_c = I,  Y_k = -L_k Y_{k-1} (k > c);   V_k = S_k^-1 Y_k (k >= c), 0 (k < c);
+    // X_N = V_N,  X_k = V_k - L_{k+1}' X_{k+1}.   One wavefront per block column, kDenseRound block columns per round; every
+    // step is an 8x8x8 product with both operands read row-wise from LDS (the running matrix is kept transposed in the
+    // wavefront's scratch tile).  A round's result [column block][stage][i][j] = K^-1[8 stage + i][8 block + j] goes through STG to
+    // the threads that own those rows in dense_apply.  Element [a][b] of the tiles: S^-1 row-major, L_k row-major for even k,
+    // transposed for odd k (as the sweeps of kkt_solve want them).
+    // sum_t A[i][t] * B'[j][t]:  arow = &A[i][0] with element stride sa (1 or 8), brow = &B'[j][0] contiguous
+    template <int SA>
+    __device__ __forceinline__ static double tile_dot(const double *arow, const double *brow) {
+        double a_[8], b_[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { a_[t] = arow[t * SA]; b_[t] = brow[t]; }
+        const double p0 = (a_[0] * b_[0] + a_[1] * b_[1]) + (a_[2] * b_[2] + a_[3] * b_[3]);
+        const double p1 = (a_[4] * b_[4] + a_[5] * b_[5]) + (a_[6] * b_[6] + a_[7] * b_[7]);
+        return p0 + p1;
+    }
+    // row i of L_k (TRANSPOSED = false) or of L_k' (true) times the matrix whose transpose sits in bt
+    template <bool TRANSPOSED>
+    __device__ __forceinline__ double l_tile_dot(int k, const double *bt) const {
+        const double *t = tL + k * kTS;
+        const bool rowmajor = ((k & 1) == 0) != TRANSPOSED;     // the wanted row is contiguous in memory
+        return rowmajor ? tile_dot<1>(t + ti * 8, bt + tj * 8) : tile_dot<8>(t + ti, bt + tj * 8);
+    }
+    __device__ __forceinline__ void dense_column_block(int c, double *out) {
+        double *const Yt = WS + wv * 128, *const Xt = Yt + 64;
+        // forward sweep and pivot products
+        for (int k = 0; k < c; ++k) out[k * 64 + lane] = 0.0;
+        Yt[tj * 8 + ti] = (ti == tj) ? 1.0 : 0.0;
+        out[c * 64 + lane] = tS[c * kTS + lane];
+        wsync();
+        for (int k = c + 1; k <= N; ++k) {
+            const double y = -l_tile_dot<false>(k, Yt);
+            wsync();
+            Yt[tj * 8 + ti] = y;
+            wsync();
+            out[k * 64 + lane] = tile_dot<1>(tS + k * kTS + ti * 8, Yt + tj * 8);
+        }
+        wsync();
+        // backward sweep (in place: out[k] holds V_k until X_k replaces it)
+        Xt[tj * 8 + ti] = out[N * 64 + lane];
+        wsync();
+        for (int k = N - 1; k >= 0; --k) {
+            const double x = out[k * 64 + lane] - l_tile_dot<true>(k + 1, Xt);
+            wsync();
+            out[k * 64 + lane] = x;
+            Xt[tj * 8 + ti] = x;
+            wsync();
+        }
+    }
+    __device__ __forceinline__ void dense_build() {
+        constexpr int kRoundsD = (NT + 1 + kDenseRound - 1) / kDenseRound;
+        const int g = tid >> 3, s_ = tid & 7;
+        // rows of this thread (clamped for the threads beyond the last group: they read valid addresses and never use the values)
+        const int r0 = 3 * (g < kDenseGroups ? g : kDenseGroups - 1);
+        int off[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const int r = (r0 + q < NS * 8) ? r0 + q : NS * 8 - 1; off[q] = (r >> 3) * 64 + (r & 7) * 8 + s_; }
+#pragma unroll
+        for (int rd = 0; rd < kRoundsD; ++rd) {
+            const int c = rd * kDenseRound + wv;
+            if (wv < kDenseRound && c <= N) dense_column_block(c, STG + wv * (NS * 64));
+            sync();
+#pragma unroll
+            for (int q = 0; q < kDenseRound; ++q) {
+                const int cc = rd * kDenseRound + q;
+                if (cc <= NT) {
+                    const double *src = STG + q * (NS * 64);
+                    dm0[cc < kDC ? cc : 0] = src[off[0]]; dm1[cc < kDC ? cc : 0] = src[off[1]]; dm2[cc < kDC ? cc : 0] = src[off[2]];
+                }
+            }
+            sync();
+        }
+    }
+    // XT <- K^-1 VT (the KKT solve of an ADMM iteration in the tail kernel)
+    __device__ __forceinline__ void dense_apply() {
+        const int t0 = opaque(tid), g = t0 >> 3, s_ = t0 & 7;
+        if (g < kDenseGroups) {
+            const double *rv = VT + s_;
+            double rr[kDC];                 // the whole right-hand side slice first: one LDS round trip, not one per pair of columns
+#pragma unroll
+            for (int c = 0; c < kDC; ++c) rr[c] = rv[8 * c];
+            __builtin_amdgcn_sched_barrier(0);
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
+#pragma unroll
+            for (int c = 0; c + 1 < kDC; c += 2) {
+                a0 += dm0[c] * rr[c]; a1 += dm1[c] * rr[c]; a2 += dm2[c] * rr[c];
+                b0 += dm0[c + 1] * rr[c + 1]; b1 += dm1[c + 1] * rr[c + 1]; b2 += dm2[c + 1] * rr[c + 1];
+            }
+            if constexpr (kDC & 1) { a0 += dm0[kDC - 1] * rr[kDC - 1]; a1 += dm1[kDC - 1] * rr[kDC - 1]; a2 += dm2[kDC - 1] * rr[kDC - 1]; }
+            a0 += b0; a1 += b1; a2 += b2;
+            red_j2(a0, a1); a2 = red_j(a2);
+            if (s_ == 0) {
+                const int r = 3 * g;
+                XT[r] = a0;
+                if (r + 1 < NS * 8) XT[r + 1] = a1;
+                if (r + 2 < NS * 8) XT[r + 2] = a2;
             }
         }
         sync();
@@ -1025,6 +1183,9 @@ struct Solver {
             STAMP(2);
             return;
         }
+        // (tail kernel: the polish solves -- wavefront 0 alone, its LDS traffic ordered wave-locally, the others wait at the end)
+        auto lsync = [&]() { if constexpr (TAIL) wsync(); else sync(); };
+        if (!TAIL || wv == 0) {
         // forward: y_k = b_k - L_k y_{k-1}
         double yc = XT[ti], yr = 0.0;
         for (int k = 1; k <= N; k += 2) {
@@ -1035,13 +1196,13 @@ struct Solver {
                 if (tj == 0) XT[(k + 1) * 8 + ti] = yc;
             }
         }
-        sync();
+        lsync();
         // v_k = Sinv_k y_k
         for (int k = 0; k <= N; ++k) {
             const double t = red_j(tS[k * kTS + lane] * XT[k * 8 + tj]);
             if (tj == 0) VT[k * 8 + ti] = t;
         }
-        sync();
+        lsync();
         // backward: x_k = v_k - L_{k+1}' x_{k+1}
         double xc = VT[N * 8 + ti], xr = VT[N * 8 + tj];
         if (lane < 8) XT[N * 8 + lane] = VT[N * 8 + lane];
@@ -1053,6 +1214,7 @@ struct Solver {
                 xc = VT[k * 8 + ti] - red_j(tL[(k + 1) * kTS + lane] * xr);
                 if (tj == 0) XT[k * 8 + ti] = xc;
             }
+        }
         }
         sync();
     }
@@ -1093,6 +1255,20 @@ struct Solver {
             sync();
 #pragma unroll
             for (int i = 0; i < 8; ++i) m_[i] = fmax(RED[i], RED[16 + i]);
+        }
+        if constexpr (TAIL) {
+            if (lane == 0 && wv < kActW) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) RT[32 + wv * 8 + i] = m_[i];
+            }
+            sync();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                double v = RT[32 + i];
+#pragma unroll
+                for (int w = 1; w < kActW; ++w) v = fmax(v, RT[32 + w * 8 + i]);
+                m_[i] = v;
+            }
         }
         r.pri = m_[0]; r.dua = cinv * m_[1]; r.nAxz = m_[2]; r.nPAq = cinv * m_[3];
         r.s_pri = m_[4]; r.s_dua = m_[5]; r.s_Axz = m_[6]; r.s_PAq = m_[7];
@@ -1187,9 +1363,11 @@ struct Solver {
         sync();
     }
     // XT = sigma x - q + A' (rho z - y)        (OSQP compute_rhs, x part, reduced form)
+    // (the tail kernel writes it to VT: dense_apply reads the whole right-hand side while it stores x~ into XT)
     __device__ __forceinline__ void build_rhs(double sigma) {
         const LaneC lc = lane_consts();
-        for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
+        double *const dst = TAIL ? VT : XT;
+        for (int e = opaque(tid); e < NS * 8; e += kStride) dst[e] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
         sync();
     }
     // z~ = A x~ fused with OSQP update_x / update_z / update_y; leaves rho z - y in ZT*.
@@ -1274,7 +1452,7 @@ struct Solver {
     struct Outs { double *xPred, *uPred; int32_t *status, *iters, *polish; double *resid, *state; };
     __device__ __forceinline__ Outs outs_of(const SolveArgs &a, int entry) const {
         if (entry < 0) return Outs{a.xPred, a.uPred, a.status, a.iters, a.polish, a.resid, a.state};
-        const unsigned long long *pw = reinterpret_cast<const unsigned long long *>(a.pool_in + (size_t)entry * a.pool_stride + lds_doubles(N) + 8);
+        const unsigned long long *pw = reinterpret_cast<const unsigned long long *>(a.pool_in + (size_t)entry * a.pool_stride + image_doubles(N) + 8);
         auto word = [&](int i) {
             const unsigned long long v = pw[i];
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -1288,7 +1466,7 @@ struct Solver {
         const int slot = (int)RED[79];
         sync();
         if (slot >= a.pool_cap) return false;                    // pool full: this instance simply goes on here
-        const int n = (int)lds_doubles(N);
+        const int n = (int)image_doubles(N);
         double *dst = a.pool + (size_t)slot * a.pool_stride;
         for (int i = tid; i < n; i += kStride) dst[i] = tA[i];          // tA is the base of the LDS block
         if (tid == 0) {
@@ -1306,7 +1484,7 @@ struct Solver {
     }
     // restores entry `entry` of a.pool_in; returns the instance index
     __device__ __forceinline__ int restore(const SolveArgs &a, int entry, int &iter, int &to_chk, int &to_adp) {
-        const int n = (int)lds_doubles(N);
+        const int n = (int)image_doubles(N);
         const double *src = a.pool_in + (size_t)entry * a.pool_stride;
         for (int i = tid; i < n; i += kStride) tA[i] = src[i];
         const double *sc = src + n;
@@ -1322,13 +1500,13 @@ struct Solver {
     // inst: instance index; entry: pool entry to continue (a.resume) or -1
     __device__ __forceinline__ void run(const SolveArgs &a, int inst, int entry = -1) {
         bool bad = false;              // this thread saw a non-finite input word
-        const bool resuming = entry >= 0;
+        const bool resuming = TAIL || entry >= 0;     // (the tail kernel only ever resumes)
         if constexpr (GS) { D = a.scal + (size_t)inst * 3 * (NS * 8); Ed = D + NS * 8; Eb = Ed + NS * 8; }
         int iter0 = 1, to_chk0 = 0, to_adp0 = 0;
         if (resuming) {
             inst = restore(a, entry, iter0, to_chk0, to_adp0);
             ++iter0;
-        } else {
+        } else if constexpr (!TAIL) {
         // ---------- load + build the unscaled problem ----------
         {   // weights -> LDS (the configuration block itself stays in global memory)
             double v = 0.0;
@@ -1440,7 +1618,7 @@ struct Solver {
 #endif
             build_rhs(sigma);
             STAMP(0);
-            kkt_solve();
+            if constexpr (TAIL) { dense_apply(); STAMP(1); } else kkt_solve();
             update(alpha, checked);         // delta_x / delta_y are only read by the infeasibility tests
             STAMP(3);
             if (checked || adapt) {
@@ -1643,12 +1821,12 @@ struct Solver {
 // -- and the planner N = 30 kernel with its equilibration vectors in global memory (three instances per CU: six waves on four SIMDs)
 template <int NT, int NW, bool GS>
 #ifdef LPVMPC_FORCE_TWO_WAVES_PER_SIMD
-constexpr int min_waves_per_simd() { return NW; }      // diagnostic: provoke register spilling in the big-N kernels
+constexpr int min_waves_per_simd() { return NW >= 8 ? NW / 4 : NW; }      // diagnostic: provoke register spilling in the big-N kernels
 #else
-constexpr int min_waves_per_simd() { return ((NW == 2 && NT <= 20) || (NW == 1 && NT > 0 && NT <= 8) || GS) ? 2 : 1; }     // N = 8 (one wavefront): 256 registers without a spill -> eight instances per CU
+constexpr int min_waves_per_simd() { return ((NW == 2 && NT <= 20) || (NW == 1 && NT > 0 && NT <= 8) || GS || NW == 8) ? 2 : 1; }     // N = 8 (one wavefront): 256 registers without a spill -> eight instances per CU; NW = 8: the tail kernel, one workgroup per CU
 #endif
 
-template <int NX, int NT, int NW, bool MF = false, bool GS = false>
+template <int NX, int NT, int NW, bool MF = false, bool GS = false, bool TAIL = false>
 __global__ void __launch_bounds__(64 * NW, (min_waves_per_simd<NT, NW, GS>())) admm_solve_kernel(const DevCfg *__restrict__ cfgp, SolveArgs a) {
     extern __shared__ __align__(16) double smem[];
     int inst = blockIdx.x, entry = -1;
@@ -1665,14 +1843,15 @@ __global__ void __launch_bounds__(64 * NW, (min_waves_per_simd<NT, NW, GS>())) a
         const int n = n_parked;
         entry = blockIdx.x;
         if (entry >= (n < a.pool_cap ? n : a.pool_cap)) return;
-    } else if (inst >= a.B) return;
-    Solver<NX, NT, NW, MF, GS> s(*cfgp, smem);
+        __syncthreads();          // every wavefront has read the count before restore() stores the image over it
+    } else if (TAIL || inst >= a.B) return;
+    Solver<NX, NT, NW, MF, GS, TAIL> s(*cfgp, smem);
     s.run(a, inst, entry);
 }
 
-template <int NX, int NT, int NW, bool MF = false, bool GS = false>
+template <int NX, int NT, int NW, bool MF = false, bool GS = false, bool TAIL = false>
 static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream) {
-    const size_t lds = Solver<NX, NT, NW, MF, GS>::lds_doubles(cfg.N) * sizeof(double);
+    const size_t lds = Solver<NX, NT, NW, MF, GS, TAIL>::lds_doubles(cfg.N) * sizeof(double);
     // The LDS opt-in is a per-function AND per-device attribute: remember it per (instantiation, device ordinal).  Handles on
     // different devices may launch from different threads (lpvmpc.h: thread-safe across handles), hence the atomic mask.
     static std::atomic<uint64_t> attr_mask[4];           // 256 device ordinals
@@ -1681,11 +1860,11 @@ static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveA
     const uint64_t bit = 1ull << (dev & 63);
     std::atomic<uint64_t> &word = attr_mask[(dev >> 6) & 3];
     if (!(word.load(std::memory_order_acquire) & bit)) {
-        hipError_t err = hipFuncSetAttribute((const void *)admm_solve_kernel<NX, NT, NW, MF, GS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t err = hipFuncSetAttribute((const void *)admm_solve_kernel<NX, NT, NW, MF, GS, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (err != hipSuccess) return err;
         word.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((admm_solve_kernel<NX, NT, NW, MF, GS>), dim3(a.resume ? a.pool_cap : a.B), dim3(64 * NW), lds, stream, dcfg, a);
+    hipLaunchKernelGGL((admm_solve_kernel<NX, NT, NW, MF, GS, TAIL>), dim3(a.resume ? a.pool_cap : a.B), dim3(64 * NW), lds, stream, dcfg, a);
     return hipGetLastError();
 }
 
@@ -1703,6 +1882,9 @@ size_t solve_lds_bytes(int kind, int N) {
 // with one wavefront per instance (where instantiated)
 hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream, int kernel_variant) {
     const bool generic = kernel_variant == 1, one_wave = kernel_variant == 2, dpp = kernel_variant == 3;
+    // a resume pass that runs its entries to completion may use the whole-CU tail kernel (SolveArgs::tail); the entries must
+    // have been parked by a kernel with the compile-time-horizon LDS image
+    if (a.resume && a.tail && a.defer_after == 0 && !generic && cfg.kind == 0 && cfg.N == 20) return launch_one<6, 20, 8, false, false, true>(cfg, dcfg, a, stream);
     if (cfg.kind == 0) {
         if (!generic && cfg.N == 20) return one_wave ? launch_one<6, 20, 1>(cfg, dcfg, a, stream)
                                           : (dpp ? launch_one<6, 20, 2>(cfg, dcfg, a, stream) : launch_one<6, 20, 2, true>(cfg, dcfg, a, stream));

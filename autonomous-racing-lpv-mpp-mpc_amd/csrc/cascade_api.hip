@@ -128,6 +128,8 @@ extern "C" int lpvmpc_cascade_init(lpvmpc_handle *h, lpvmpc_handle *plan, int32_
     if (h->cfg.kind != LPVMPC_KIND_CONTROLLER || plan->cfg.kind != LPVMPC_KIND_PLANNER)
         return fail(h, LPVMPC_E_ARG, "lpvmpc_cascade_init: needs a controller handle and a planner handle");
     if (h->cfg.device != plan->cfg.device) return fail(h, LPVMPC_E_ARG, "lpvmpc_cascade_init: the two handles live on different devices");
+    // the cascade's measurement kernel keeps u_old as [B][2]; a handle with steering delay reads it as [B][2 + delay]
+    if (h->cfg.steering_delay != 0) return fail(h, LPVMPC_E_ARG, "lpvmpc_cascade_init: the fleet engines run the reference's steeringDelay = 0 (CMAIN:49)");
     if (!plan->d_Wop) return fail(h, LPVMPC_E_ARG, "lpvmpc_cascade_init: call lpvmpc_handoff_setup on the planner handle first");
     if (plan->ho_M < h->cfg.N) return fail(h, LPVMPC_E_ARG, "lpvmpc_cascade_init: the planner message (%d samples) is shorter than the controller horizon", plan->ho_M);
     if (!plant0 || !cmd0 || !uPred0 || !n_sub || lap0 < 1 || !(dt_sim > 0) || n_sub[0] < 1 || n_sub[1] < 1 || n_sub[2] < 1)

@@ -88,8 +88,8 @@ static int ensure_defer(lpvmpc_handle *h, int B, hipStream_t st) {
     const int stride = (h->cfg.N + 1) * (3 * lpvmpc::kTS + 19 * 8 + 8) + 16 + 64 + 8 + 80 + 64 + lpvmpc::kParkScalars;
     if (h->dpool[0] && h->defer_cur_cap >= cap && h->defer_stride == stride) return LPVMPC_OK;
     if (h->dpool[0]) {      // growing: finish what is parked in the old pools first
-        int rc = lpvmpc_join(h, (void *)(h->defer_stream ? h->defer_stream : st)); if (rc) return rc;
-        HIP_TRY(h, hipStreamSynchronize(h->defer_stream ? h->defer_stream : st));
+        int rc = lpvmpc_join(h, (void *)(h->defer_stream_set ? h->defer_stream : st)); if (rc) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->defer_stream_set ? h->defer_stream : st));
     }
     free_defer(h);
     for (int i = 0; i < 2; ++i) {
@@ -106,7 +106,7 @@ static int ensure_defer(lpvmpc_handle *h, int B, hipStream_t st) {
 static int resume_pass(lpvmpc_handle *h, int budget, hipStream_t st) {
     const int A = h->dcur, Bp = 1 - A;
     SolveArgs a{};
-    a.B = h->defer_cur_cap; a.resume = 1; a.defer_after = budget;
+    a.B = h->defer_cur_cap; a.resume = 1; a.defer_after = budget; a.tail = h->defer_tail;
     a.pool_in = h->dpool[A]; a.pool_in_count = h->dcount[A];
     a.pool = h->dpool[Bp]; a.pool_count = h->dcount[Bp];
     a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride; a.x0_stride = h->nx;
@@ -161,6 +161,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->d_Wop = h->d_FWop = nullptr; h->ho_M = 0; h->cascade = nullptr; h->cascade_owner = nullptr; h->cascade_prefetch = 1;
     h->defer_after = 0; h->defer_budget = 200; h->defer_cap = 0; h->defer_cur_cap = 0; h->defer_stride = 0; h->rv_count = 0;
     h->dpool[0] = h->dpool[1] = nullptr; h->dcount[0] = h->dcount[1] = nullptr; h->dcur = 0; h->defer_stream = nullptr; h->defer_event = nullptr;
+    h->defer_stream_set = false; h->defer_tail = 1;
     h->h_pack_in = h->h_pack_out = h->d_pack_in = h->d_pack_out = nullptr;
     DevCfg &d = h->dev;
     std::memset(&d, 0, sizeof(d));
@@ -205,6 +206,8 @@ extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
     if (h->cl_local) (void)hipFree(h->cl_local);
     if (h->cl_cmd) (void)hipFree(h->cl_cmd);
     if (h->cascade) lpvmpc_cascade_free(h);
+    // a planner handle that a controller's cascade still drives: end that cascade first (it holds a pointer to this handle)
+    if (h->cascade_owner && h->cascade_owner->cascade) lpvmpc_cascade_free(h->cascade_owner);
     if (h->h_pack_in) (void)hipHostFree(h->h_pack_in);
     if (h->h_pack_out) (void)hipHostFree(h->h_pack_out);
     if (h->d_pack_in) (void)hipFree(h->d_pack_in);
@@ -252,6 +255,7 @@ extern "C" int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t val
         if (h->dpool[0]) { int rc = lpvmpc_join(h, (void *)h->defer_stream); if (rc) return rc; HIP_TRY(h, hipStreamSynchronize(h->defer_stream)); }
         free_defer(h); h->defer_cap = value; return LPVMPC_OK;
     }
+    if (std::strcmp(name, "defer_tail") == 0) { h->defer_tail = value != 0 ? 1 : 0; return LPVMPC_OK; }      // both kernels continue the same pool entries
     if (std::strcmp(name, "cascade_prefetch") == 0) { h->cascade_prefetch = value != 0 ? 1 : 0; return LPVMPC_OK; }   // read by lpvmpc_cascade_init
     return fail(h, LPVMPC_E_ARG, "lpvmpc_set_option: unknown option '%s'", name);
 }
@@ -522,11 +526,11 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
         // defer_budget more iterations.  No launch lasts much longer than its budget, so the stream is never held by one slow
         // instance; lpvmpc_join runs the pass that finishes whatever is still parked.
         rc = ensure_defer(h, B, st); if (rc) return rc;
-        if (h->defer_stream && h->defer_stream != st) {            // the pools are ordered by stream: hand them over
+        if (h->defer_stream_set && h->defer_stream != st) {        // the pools are ordered by stream: hand them over
             HIP_TRY(h, hipEventRecord(h->defer_event, h->defer_stream));
             HIP_TRY(h, hipStreamWaitEvent(st, h->defer_event, 0));
         }
-        h->defer_stream = st;
+        h->defer_stream = st; h->defer_stream_set = true;
         a.defer_after = h->defer_after; a.resume = 0; a.pool = h->dpool[h->dcur]; a.pool_count = h->dcount[h->dcur];
         a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride;
         rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
@@ -543,11 +547,11 @@ extern "C" int lpvmpc_join(lpvmpc_handle *h, void *stream) {
     if (!h->dpool[0]) return LPVMPC_OK;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;
-    if (h->defer_stream && h->defer_stream != st) {
+    if (h->defer_stream_set && h->defer_stream != st) {
         HIP_TRY(h, hipEventRecord(h->defer_event, h->defer_stream));
         HIP_TRY(h, hipStreamWaitEvent(st, h->defer_event, 0));
     }
-    h->defer_stream = st;
+    h->defer_stream = st; h->defer_stream_set = true;
     return resume_pass(h, 0, st);                                  // to completion: nothing stays parked
 }
 

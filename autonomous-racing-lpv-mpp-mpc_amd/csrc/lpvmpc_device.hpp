@@ -80,6 +80,9 @@ struct SolveArgs {
     // live at scal + i * 3 * 8 (N + 1) in global memory instead of LDS (they are read at set-up, at the termination checks and by
     // the factorisations, never inside an ADMM iteration), which brings the instance under a third of a CU's LDS; null: in LDS
     double *scal;
+    // resume launches that run to completion (defer_after == 0): 1 = take the whole-CU tail kernel where one exists for the
+    // handle's (kind, N) (lpvmpc_set_option "defer_tail", default on); it continues the same pool entries
+    int tail;
 };
 constexpr int kParkScalars = 16;     // behind the LDS image of a pool entry: c, cinv, rho, iter, to_chk, to_adp, instance index and the
                                      // instance's output pointers (xPred, uPred, status, iters, polish, resid, state) as 64-bit words

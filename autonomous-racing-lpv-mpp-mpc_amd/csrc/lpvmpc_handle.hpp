@@ -54,11 +54,13 @@ struct lpvmpc_handle {
     // parked instances used alternately -- launches park into pool[dcur], the resume pass that follows continues the entries
     // of pool[dcur] and parks what is still unsolved after its budget into the other pool, which becomes dcur
     int defer_after, defer_budget, defer_cap;   // iterations before parking (0 = off); iterations per resume pass; pool entries (0 = default)
+    int defer_tail;                     // option "defer_tail" (default 1): passes that run to completion take the whole-CU tail kernel
     int defer_cur_cap, defer_stride;
     double *dpool[2];
     int32_t *dcount[2];
     int dcur;
-    hipStream_t defer_stream;           // stream of the last deferred call (lpvmpc_join orders against it)
+    hipStream_t defer_stream;           // stream of the last deferred call (lpvmpc_join orders against it); valid iff defer_stream_set
+    bool defer_stream_set;              // (the null stream is a stream like any other: nullptr cannot mean "none yet")
     hipEvent_t defer_event;
     std::vector<hipEvent_t> rv0, rv1;   // event pairs around the resume launches (timing)
     int rv_count;
