@@ -95,7 +95,8 @@ struct Solver {
     static constexpr int kDenseGroups = ((NT + 1) * 8 + 2) / 3;      // groups of three rows
     static constexpr int kDenseRound = 7;                             // block columns per staging round
     static constexpr int kActW = ((NT + 1) * 8 + 63) / 64;            // wavefronts that own elements in the element loops
-    static_assert(!TAIL || (8 * kDenseGroups <= 64 * NW && kActW <= 4), "tail kernel: K^-1 rows / element loops do not fit the workgroup");
+    static constexpr int kBoxT0 = 64 * kActW;                         // update(): first thread of the wavefronts that own the box rows
+    static_assert(!TAIL || (8 * kDenseGroups <= 64 * NW && kActW <= 4 && 2 * kActW < NW), "tail kernel: K^-1 rows / element loops do not fit the workgroup");
     double dm0[kDC], dm1[kDC], dm2[kDC];
     double c, cinv;
     // row weights: ADMM rho classes (OSQP set_rho_vec) or, while polishing, |flag| = 1/delta on active rows
@@ -119,9 +120,9 @@ struct Solver {
         if constexpr (kCacheW) {
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
-                const int e = tid + r * kStride;
+                const int e = tid + r * kStride - (TAIL ? kBoxT0 : 0);      // (tail kernel: the box rows belong to the threads from kBoxT0 on, see update)
                 double w = rho, wi = rinv;
-                if (e < NS * 8) {
+                if (e >= 0 && e < NS * 8) {
                     const double lo = Lo[e], hi = Hi[e];
                     const bool loose = lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling, eq = hi - lo < kRhoTol;
                     w = loose ? kRhoMin : (eq ? rho_eq : rho); wi = loose ? 1.0 / kRhoMin : (eq ? rinv_eq : rinv);
@@ -301,6 +302,11 @@ struct Solver {
         const double acc0 = (r0_ * s0_ + r1_ * s1_) + (r2_ * s2_ + r3_ * s3_);
         const double acc1 = (r4_ * s4_ + r5_ * s5_) + (r6_ * s6_ + r7_ * s7_);
         return k > 0 ? acc0 + acc1 : 0.0;
+    }
+    // an element loop on the wavefronts w0 .. w0 + nw - 1 only
+    template <typename F>
+    __device__ __forceinline__ void eloop(int w0, int nw, F f) const {
+        if (wv >= w0 && wv < w0 + nw) for (int e = opaque(tid) - 64 * w0; e < NS * 8; e += 64 * nw) f(e);
     }
     // (dstD, dstB) = A * src
     __device__ __forceinline__ void A_mul(const double *src, double *dstD, double *dstB) const {
@@ -1227,9 +1233,16 @@ struct Solver {
 
     // (xv, zd/zb, yd/yb) -> residual norms; leaves A x in ZT*, P x in VT, A'y in AT
     __device__ __forceinline__ Res residuals(const double *xv, const double *zd, const double *zb, const double *yd, const double *yb) {
-        A_mul(xv, ZTd, ZTb);
-        P_mul(xv, VT);
-        At_mul(yd, yb, AT);
+        if constexpr (TAIL) {       // the three products side by side on different wavefronts
+            const LaneC lc = lane_consts();
+            eloop(0, kActW, [&](int e) { const int k = e >> 3; ZTd[e] = lc.rmask * (Eid(k, tj) * xv[e] - prev_stage_dot(k, xv)); ZTb[e] = Sb(k, tj) * xv[k * 8 + lc.bvar]; });
+            eloop(kActW, kActW, [&](int e) { VT[e] = P_row<false>(e >> 3, xv); });
+            eloop(2 * kActW, NW - 2 * kActW, [&](int e) { AT[e] = At_elem(e, yd, yb, lc); });
+        } else {
+            A_mul(xv, ZTd, ZTb);
+            P_mul(xv, VT);
+            At_mul(yd, yb, AT);
+        }
         sync();
         Res r = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int e = opaque(tid); e < NS * 8; e += kStride) {
@@ -1377,6 +1390,41 @@ struct Solver {
         const LaneC lc = lane_consts();
         const int bvar = lc.bvar;
         const double rmask = lc.rmask;
+        if constexpr (TAIL) {
+            // The tail kernel has wavefronts to spare: the dynamics rows on the first kActW of them, the box rows and the x update
+            // on the next kActW, side by side (the same arithmetic per element as below)
+            const int t0 = opaque(tid);
+            if (t0 < kBoxT0) {
+                const int e = t0;
+                if (e < NS * 8) {
+                    const int k = e >> 3;
+                    const double xt = XT[e], zd = Zd[e], yd = Yd[e], b = dyn_bound(e), ei = Eid(k, tj);
+                    const double dot = prev_stage_dot(k, XT);
+                    const double ztd = rmask * (ei * xt - dot);
+                    const double zrd = alpha * ztd + oma * zd;
+                    const double znd = b;
+                    const double dyd = rho_eq * (zrd - znd), ynd = yd + dyd;
+                    Yd[e] = ynd; Zd[e] = znd; ZTd[e] = rho_eq * znd - ynd;
+                    if (want_delta) DYd[e] = dyd;
+                }
+            } else {
+                const int e = t0 - kBoxT0;
+                if (e < NS * 8) {
+                    const int k = e >> 3;
+                    const double xt = XT[e], xo = X[e], zb = Zb[e], yb = Yb[e], lo = Lo[e], hi = Hi[e], sb = Sb(k, tj), xv = XT[k * 8 + bvar];
+                    const double w = wbx[0], winv = wbxi[0];
+                    const double zrb = alpha * (sb * xv) + oma * zb;
+                    const double znb = clipd(zrb + winv * yb, lo, hi);
+                    const double dyb = w * (zrb - znb), ynb = yb + dyb;
+                    const double xn = alpha * xt + oma * xo;
+                    Yb[e] = ynb; Zb[e] = znb; ZTb[e] = w * znb - ynb;
+                    X[e] = xn;
+                    if (want_delta) { DYb[e] = dyb; DX[e] = xn - xo; }
+                }
+            }
+            sync();
+            return;
+        }
         auto element = [&](int e, bool cached, double wc, double wic) {
             const int k = e >> 3;
             const double xt = XT[e], xo = X[e];

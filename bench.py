@@ -148,13 +148,23 @@ def main():
                     resid=torch.empty((n, 4), dtype=torch.float64, device=dev), polish=torch.empty(n, dtype=torch.int32, device=dev))
     for e in engines:
         e.reserve(B)
-    outs = [new_outs(B) for _ in range(NBAT)]            # one output set per input batch (a deferred instance writes its results late)
+    # Output sets: a deferred instance writes its results late (lpvmpc.h: the buffers of a deferred call must not be reused while
+    # an instance of it is LPVMPC_PENDING).  A max_iter straggler needs ceil(max_iter / budget) resume passes of its engine, i.e.
+    # that many steps of that engine = S times as many steps overall: the ring of output sets is that long (a multiple of NBAT).
+    if args.defer > 0:
+        passes = -(-4000 // args.defer_budget) if args.defer_budget > 0 else 1
+        NOUT = NBAT * -(-((passes + 2) * S) // NBAT)
+    else:
+        NOUT = NBAT
+    outs = [new_outs(B) for _ in range(NOUT)]
+    out_of = {}                                          # input batch -> output set of its most recent solve
     counter = [0]
 
-    def solve_slot(i, n=B, e=None):
-        """Batch i (inputs and outputs i) on engine / stream e (default i mod S)."""
+    def solve_slot(i, n=B, e=None, o=None):
+        """Batch i (inputs i, output set o, default i) on engine / stream e (default i mod S)."""
         e = i % S if e is None else e
-        o, d = outs[i], ins[i]
+        out_of[i] = i if o is None else o
+        o, d = outs[out_of[i]], ins[i]
         engines[e].solve_dev(n, d["x0"], d["u_prev"], d["vel_ref"], d["curv"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"],
                              o["status"], o["iters"], o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"],
                              stream=streams[e].cuda_stream)
@@ -162,7 +172,7 @@ def main():
     def step():
         j = counter[0]
         counter[0] += 1
-        solve_slot(j % NBAT, e=j % S)
+        solve_slot(j % NBAT, e=j % S, o=j % NOUT)
         return j % NBAT
 
     def fence():
@@ -205,8 +215,9 @@ def main():
             r_ms += ms_; r_n += n_
         e.set_timing(False)
     used = sorted(set(timed_slots))
-    it_slot = {i: outs[i]["iters"].cpu().numpy().astype(np.int64) for i in used}
-    st_slot = {i: outs[i]["status"].cpu().numpy() for i in used}
+    it_slot = {i: outs[out_of[i]]["iters"].cpu().numpy().astype(np.int64) for i in used}
+    st_slot = {i: outs[out_of[i]]["status"].cpu().numpy() for i in used}
+    u0_last = outs[out_of[timed_slots[-1]] if timed_slots else 0]["uPred"][:, 0, :].cpu().numpy()     # (the extras below reuse the output sets)
     m_rows = ((N + 1) * nx + (N + 1) * nx + N * 2) if planner else None
     bytes_slot = {i: algorithmic_bytes(it_slot[i], N=N, nx=nx, m_rows=m_rows)[0] for i in used}
     bytes_iter = algorithmic_bytes(it_slot[used[0]], N=N, nx=nx, m_rows=m_rows)[1]
@@ -226,7 +237,7 @@ def main():
         sync(); t1 = time.perf_counter()
         for j in range(args.steps):
             e = j % S
-            o, d = outs[j % NBAT], ins[0]
+            o, d = outs[j % NOUT], ins[0]
             engines[e].solve_dev(B, d["x0"], d["u_prev"], d["vel_ref"], d["curv"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"],
                                  o["status"], o["iters"], o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"],
                                  stream=streams[e].cuda_stream)
@@ -291,13 +302,15 @@ def main():
             engines[0].solve(one["x0"], one["u_prev"], one["vel_ref"], one["curv_s"], one["u_old"], one["max_ey"], one["cf_new"], one["lap"])
             lat1.append((time.perf_counter() - t1) * 1e3)
         extras["p50_single_solve_latency_ms"] = float(np.median(lat1[5:]))
+        if not planner:
+            extras["lone_instance_iteration_us"] = lone_iteration_us(w, local_rank, dev, args.kernel_variant)
 
     from lpvmpc.distributed import reduce_stats, gather_results
     elapsed, agg = reduce_stats(elapsed, [iters_timed, solved_timed, bytes_timed], device=dev)
     # the one collective of the path, after the timed region: first input, status and iteration count of every
     # instance of one batch per rank (B x 4 words per rank over RCCL)
     last = timed_slots[-1] if timed_slots else 0
-    g_u0, g_status, g_iters = gather_results(outs[last]["uPred"][:, 0, :].cpu().numpy(), st_slot[last], it_slot[last], B * world, device=dev)
+    g_u0, g_status, g_iters = gather_results(u0_last, st_slot[last], it_slot[last], B * world, device=dev)
     assert g_u0.shape == (B * world, 2) and g_iters.shape == (B * world,)
 
     if rank == 0:
@@ -327,9 +340,10 @@ def main():
                             "distinct_batches_timed": len(used), "batch_seeds": "step j solves batch j mod %d = seed %d + (j mod %d) + 1000 rank" % (NBAT, 1 if planner else 0, NBAT),
                             "mean_admm_iters": agg[0] / total,
                             "max_admm_iters_rank0": int(max(it_slot[i].max() for i in used)),
-                            # an instance is a serial chain of ADMM iterations (2.4 us each with a CU to itself, 3.3 us on a full
-                            # GPU: DESIGN.md section 5), so the timed region cannot end sooner than its slowest instance does
-                            "slowest_instance_floor_ms": int(max(it_slot[i].max() for i in used)) * (3.7e-3 if planner else 2.4e-3),
+                            # an instance is a serial chain of ADMM iterations, so the timed region cannot end sooner than its slowest
+                            # instance does: iterations x the time of one iteration of an instance that has a CU to itself (measured in
+                            # this run where the extras ran: config.lone_instance_iteration_us; else the figures of DESIGN.md section 5)
+                            "slowest_instance_floor_ms": slowest_floor_ms(int(max(it_slot[i].max() for i in used)), planner, args.defer, extras),
                             "timed_region_ms": elapsed * 1e3,
                             "solved_fraction": agg[1] / total}, **extras),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -364,6 +378,51 @@ def main():
         e.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def slowest_floor_ms(max_iters, planner, defer, extras):
+    """Lower bound of any timed region that contains an instance of max_iters iterations."""
+    lone = extras.get("lone_instance_iteration_us") or {}
+    main_us = lone.get("solve_kernel", 3.7 if planner else 2.4)
+    if planner or defer <= 0 or "tail_kernel" not in lone:
+        return max_iters * main_us * 1e-3
+    kp = -(-defer // 25) * 25
+    return (min(max_iters, kp) * main_us + max(0, max_iters - kp) * lone["tail_kernel"]) * 1e-3
+
+
+def lone_iteration_us(w, local_rank, dev, kernel_variant):
+    """Time of one ADMM iteration of ONE instance alone on the GPU (nothing else running): the solve kernel, and the whole-CU
+    tail kernel that finishes parked stragglers.  Measured by differencing two runs of the same instance with termination
+    switched off (max_iter 1100 and 2100; adaptive rho and polish off)."""
+    import numpy as np
+    import torch
+    from lpvmpc import workloads
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a[:1])).to(dev)
+    ins = dict(x0=t(w["x0"]), u_prev=t(w["u_prev"]), vel=t(w["vel_ref"]), curv=t(w["curv_s"]), u_old=t(w["u_old"]))
+    o = dict(xPred=torch.empty((1, w["N"] + 1, 6), dtype=torch.float64, device=dev), uPred=torch.empty((1, w["N"], 2), dtype=torch.float64, device=dev),
+             status=torch.empty(1, dtype=torch.int32, device=dev), iters=torch.empty(1, dtype=torch.int32, device=dev),
+             resid=torch.empty((1, 4), dtype=torch.float64, device=dev), polish=torch.empty(1, dtype=torch.int32, device=dev))
+    out = {}
+    for name, defer in (("solve_kernel", 0), ("tail_kernel", 100)):
+        ts = {}
+        for mi in (1100, 2100):
+            e = workloads.make_solver(w, device=local_rank, max_iter=mi, adaptive_rho=0, polish=0, eps_abs=1e-30, eps_rel=1e-30,
+                                      eps_prim_inf=1e-30, eps_dual_inf=1e-30)
+            e.set_option("kernel_variant", kernel_variant); e.reserve(1)
+            e.set_option("defer_after", defer); e.set_option("defer_budget", 0)
+            best = 1e9
+            for _ in range(4):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                e.solve_dev(1, ins["x0"], ins["u_prev"], ins["vel"], ins["curv"], ins["u_old"], None, o["xPred"], o["uPred"], o["status"], o["iters"],
+                            o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"], stream=0)
+                if defer:
+                    e.join(0)
+                torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+            assert int(o["iters"].cpu()[0]) == mi
+            ts[mi] = best
+            e.close()
+        out[name] = (ts[2100] - ts[1100]) / 1000 * 1e6
+    return out
 
 
 def load_pmc(B, planner):
