@@ -344,6 +344,30 @@ def _stack_list(L, shape, name):
 
 
 class _DropInBase(object):
+    # ---- the assembled QP, as the reference leaves it on the object (CTRL:79,108-110; PLAN:108) -----------------------------
+    # The device path never forms these matrices; they are built on the host (qp_matrices.py) from the data of the last
+    # solve() the first time one of them is read, and dropped by the next solve().
+    _qp_cache = None
+    _qp_inputs = None
+
+    def _qp(self):
+        if self._qp_cache is None:
+            if self._qp_inputs is None:
+                raise AttributeError("the QP matrices exist after the first solve()")
+            self._qp_cache = self._assemble_qp(**self._qp_inputs)
+        return self._qp_cache
+
+    def qp_matrices(self):
+        """(P, q, A, l, u) of the last solve in the form the reference hands to OSQP (CTRL:303-308: inequality rows first;
+        PLAN:200-202: equality rows first), dense float64."""
+        m = self._qp()
+        return m["P"], m["q"], m["A"], m["l"], m["u"]
+
+    E = property(lambda self: self._qp()["E"])
+    L = property(lambda self: self._qp()["L"])
+    Eu = property(lambda self: self._qp()["Eu"])
+    q = property(lambda self: self._qp()["q"])
+
     def _finish(self, out, start):
         nx, N = self.n_states, self.N
         self.status_val = int(out["status"][0])
@@ -399,6 +423,33 @@ class PathFollowingLPV_MPC(_DropInBase):
         self._eng = BatchedSolver("controller", N, dt, self.Q, self.R, self.dR, track=map.PointAndTangent,
                                   params=p, device=device, steering_delay=int(steeringDelay), **settings)
 
+    # CTRL:108-110 leaves G, E, L, Eu, M, q on the object; F, b exist from the constructor on (CTRL:79)
+    G = property(lambda self: self._qp()["G"])
+    M = property(lambda self: self._qp()["M"])
+
+    def _bounds(self):
+        c = self._eng.cfg
+        return dict(vx_min=c.ctrl_vx_min, delta_max=c.ctrl_delta_max, a_max=c.ctrl_a_max, a_min_abs=c.ctrl_a_min_abs)
+
+    @property
+    def F(self):
+        return self._Fb()[0]
+
+    @property
+    def b(self):
+        return self._Fb()[1]
+
+    def _Fb(self):
+        if getattr(self, "_Fb_cache", None) is None:
+            from . import qp_matrices
+            self._Fb_cache = qp_matrices.controller_inequalities(self.N, self.n, self.d, self.max_vel, **self._bounds())
+        return self._Fb_cache
+
+    def _assemble_qp(self, **kw):
+        from . import qp_matrices
+        return qp_matrices.controller_qp(self.Q, self.R, self.dR, self.N, self.A, self.B, self.C, max_vel=self.max_vel,
+                                         bounds=self._bounds(), **kw)
+
     def solve(self, x0, Last_xPredicted, uPred, NN_LPV_MPC, vel_ref, A_L, B_L, C_L, first_it):
         """CTRL:89-162.  Results in .xPred (N+1,6), .uPred (N,2), .LinPoints; returns None."""
         start = datetime.datetime.now()
@@ -419,6 +470,9 @@ class PathFollowingLPV_MPC(_DropInBase):
         d = int(self.steeringDelay)
         # CTRL:395 (uOld) followed by the pinned commands OldSteering[1 .. delay] of CTRL:523
         u_old = np.array([[self.OldSteering[0], self.OldAccelera[0]] + [float(v) for v in self.OldSteering[1:1 + d]]], dtype=np.float64)
+        self._qp_cache = None
+        self._qp_inputs = dict(x0=np.array(x0, dtype=np.float64).reshape(6), u_old=u_old[0, :2].copy(), vel_ref=vfull.copy(),
+                               steer_hist=tuple(u_old[0, 2:]))
         self.linearizationTime = datetime.datetime.now() - start
         start = datetime.datetime.now()
         out = self._eng.solve_AB(np.asarray(x0, float).reshape(1, 6), A[None], Bm[None], vfull[None], u_old)
@@ -465,6 +519,17 @@ class LPV_MPC_Planner(_DropInBase):
         self._eng = BatchedSolver("planner", N, dt, self.Q, self.R, self.dR, L_cf=self.L_cf,
                                   track=map.PointAndTangent, params=p, device=device, **settings)
 
+    Aeq = property(lambda self: self._qp()["Aeq"])                      # PLAN:108
+
+    def _assemble_qp(self, **kw):
+        from . import qp_matrices
+        c = self._eng.cfg
+        xlo, xhi = np.array(c.plan_xmin[:]), np.array(c.plan_xmax[:])
+        xlo[0], xhi[0] = self.min_vel, self.max_vel                       # PLAN:176-177
+        xlo[3], xhi[3] = -kw["max_ey"], kw["max_ey"]
+        return qp_matrices.planner_qp(self.Q, self.R, self.dR, self.L_cf, self.N, self.A, self.B, self.C, min_vel=self.min_vel,
+                                      max_vel=self.max_vel, xbox=(xlo, xhi), ubox=(np.array(c.plan_umin[:]), np.array(c.plan_umax[:])), **kw)
+
     def solve(self, x0, Last_xPredicted, uPred, A_LPV, B_LPV, C_LPV, first_it, max_ey):
         """PLAN:86-236."""
         start = datetime.datetime.now()
@@ -482,6 +547,8 @@ class LPV_MPC_Planner(_DropInBase):
         self.B = [Bm[i] for i in range(N)]
         self.C = [np.zeros((5, 1)) for _ in range(N)]
         u_old = np.array([[self.OldSteering[0], self.OldAccelera[0]]], dtype=np.float64)   # PLAN:114 (quirk Q3)
+        self._qp_cache = None
+        self._qp_inputs = dict(x0=np.array(x0, dtype=np.float64).reshape(5), u_old=u_old[0].copy(), max_ey=float(max_ey))
         out = self._eng.solve_AB(np.asarray(x0, float).reshape(1, 5), A[None], Bm[None], None, u_old,
                                  max_ey=float(max_ey))
         self._finish(out, start)

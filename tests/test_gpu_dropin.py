@@ -36,6 +36,14 @@ def test_controller_closed_loop_trace():
         assert np.max(np.abs(c.xPred - g["ctrl_xPred"][tick])) <= TOL, tick
         assert np.max(np.abs(c.uPred - g["ctrl_uPred"][tick])) <= TOL, tick
         assert np.array_equal(c.LinPoints[:-1], c.xPred[1:]) and np.array_equal(c.LinPoints[-1], c.xPred[-1])
+        if tick in (0, 12):
+            # the QP the reference leaves on the object (CTRL:79,108-110), assembled on the host on first access: the returned
+            # point satisfies its equalities and inequalities, and G carries this tick's stage blocks
+            z = np.concatenate((c.xPred.reshape(-1), c.uPred.reshape(-1)))
+            x0_used = st if tick == 0 else S[0, :]
+            assert np.max(np.abs(c.G @ z - (c.E @ x0_used + c.L[:, 0]))) <= 1e-6 and np.max(c.F @ z - c.b) <= 1e-6
+            assert np.array_equal(c.G[6:12, 0:6], -c.A[0]) and np.array_equal(c.G[6:12, 126:128], -c.B[0])
+            assert c.M.shape == (166, 166) and c.q.shape == (166,) and not c.Eu.any()
         cmd = np.array(c.uPred[0, :]); st = np.array(c.xPred[1, :])
     assert hasattr(c, "solverTime") and hasattr(c, "linearizationTime")
 
