@@ -1664,10 +1664,14 @@ struct Solver {
 #ifdef LPVMPC_STAMPS
             tlast = __builtin_amdgcn_s_memtime();
 #endif
+            // (the two markers bracket the per-iteration code in the kept assembly: tools/check_kernel_resources.py counts the
+            // scratch accesses and SGPR-spill lane moves between them)
+            asm volatile("; LPVMPC_HOT_BEGIN");
             build_rhs(sigma);
             STAMP(0);
             if constexpr (TAIL) { dense_apply(); STAMP(1); } else kkt_solve();
             update(alpha, checked);         // delta_x / delta_y are only read by the infeasibility tests
+            asm volatile("; LPVMPC_HOT_END");
             STAMP(3);
             if (checked || adapt) {
                 R = residuals(X, Zd, Zb, Yd, Yb);

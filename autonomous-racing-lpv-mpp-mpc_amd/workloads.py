@@ -68,6 +68,13 @@ def planner_batch(B, N=30, seed=1, shape="L_shape"):
                 cf_new=60.0, lap=1)
 
 
+def shard_batch(w, lo, hi):
+    """Instances [lo, hi) of a workload dict (the per-instance arrays are sliced, everything else is shared)."""
+    import numpy as np
+    n = w["x0"].shape[0]
+    return {k: (v[lo:hi] if isinstance(v, np.ndarray) and k != "track" and v.ndim >= 1 and v.shape[0] == n else v) for k, v in w.items()}
+
+
 def make_solver(w, device=0, **settings):
     from .api import BatchedSolver
     return BatchedSolver(w["kind"], w["N"], w["dt"], w["Q"], w["R"], w["dR"], L_cf=w["L_cf"], track=w["track"],

@@ -71,6 +71,9 @@ def main():
                          "instances, single-solve latency): what the profiling passes use")
     ap.add_argument("--kernel-variant", type=int, default=0,
                     help="diagnostic: lpvmpc_set_option(kernel_variant) on every engine (0 = default; 3 = the DPP two-wavefront kernel)")
+    ap.add_argument("--dump-results", default="",
+                    help="rank 0 writes the gathered (u0, status, iters) of the closing all-gather to this .npz (tests compare them with "
+                         "single-GPU solves of the same instances)")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise the launcher, the sharding and the collectives with the gloo backend and no device work "
                          "(CPU test of the N > 1 path; the printed line carries \"dry_run\": true and no measurement)")
@@ -114,8 +117,7 @@ def main():
         try:
             return (bench_cascade if args.workload == "cfg5" else bench_mixed)(args, rank, local_rank, world, dev)
         finally:
-            if world > 1:
-                dist.destroy_process_group()
+            finish(world)
     planner = args.workload == "cfg3"
     if planner and args.batch == BATCH:
         args.batch = 4096                                  # configs[2]: 4096 planner instances per GPU
@@ -312,6 +314,9 @@ def main():
     last = timed_slots[-1] if timed_slots else 0
     g_u0, g_status, g_iters = gather_results(u0_last, st_slot[last], it_slot[last], B * world, device=dev)
     assert g_u0.shape == (B * world, 2) and g_iters.shape == (B * world,)
+    if rank == 0 and args.dump_results:
+        np.savez(args.dump_results, u0=g_u0, status=g_status, iters=g_iters, batch=B, world=world,
+                 seeds=np.array([(1 if planner else 0) + last + 1000 * r for r in range(world)]))
 
     if rank == 0:
         total = B * world * args.steps
@@ -376,7 +381,15 @@ def main():
 
     for e in engines:
         e.close()
+    finish(world)
+
+
+def finish(world):
+    """End of a rank: nobody tears the process group down while another rank is still busy (rank 0 runs the CPU baseline after
+    the timed region and prints last), so every rank waits at one more barrier first."""
     if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -480,7 +493,7 @@ def dry_run(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    total = {"cfg2": args.batch * world, "cfg3": args.batch * world, "cfg4": 65536, "cfg5": 8192}[args.workload]
+    total = {"cfg2": args.batch * world, "cfg3": args.batch * world, "cfg4": args.batch * world if args.batch != BATCH else 65536, "cfg5": 8192}[args.workload]
     a, b = shard_range(total, rank, world)
     n = b - a
     u0 = np.stack([np.arange(a, b, dtype=np.float64), -np.arange(a, b, dtype=np.float64)], axis=1)      # stand-in results
@@ -515,17 +528,23 @@ def usable_cores():
 
 
 def bench_mixed(args, rank, local_rank, world, dev):
-    """configs[3] shape: B instances per GPU, half LPV-MPC controller (cfg2 distribution) and half LPV-MPP planner (cfg3
-    distribution on the L-shape track), both N = 20, seed 2; a step solves one such mixed batch (the two halves on two
-    streams), steps are pipelined over --streams stream pairs.  value = solves/s over both kinds."""
+    """configs[3] shape: ONE global batch of 65536 instances (--batch B: B per GPU), half LPV-MPC controller (cfg2 distribution)
+    and half LPV-MPP planner (cfg3 distribution on the L-shape track), both N = 20, seed 2, split contiguously over the ranks
+    (lpvmpc.distributed.shard_range: every rank builds the same global batch and keeps its slice of each half; no data-path
+    collective); a step solves the rank's share (the two halves on two streams), steps are pipelined over --streams stream
+    pairs.  value = solves/s over both kinds and all ranks."""
     import numpy as np
     import torch
     import torch.distributed as dist
     from lpvmpc import workloads
-    from lpvmpc.distributed import reduce_stats
-    B = args.batch if args.batch != BATCH else max(2, 65536 // world)
-    Bh = B // 2
-    ws = [workloads.controller_batch(Bh, N=20, seed=2 + 1000 * rank), workloads.planner_batch(Bh, N=20, seed=2 + 1000 * rank)]
+    from lpvmpc.distributed import reduce_stats, shard_range, gather_results
+    total = args.batch * world if args.batch != BATCH else 65536
+    half = total // 2
+    lo, hi = shard_range(half, rank, world)
+    Bh = hi - lo
+    B = 2 * Bh
+    ws = [workloads.shard_batch(workloads.controller_batch(half, N=20, seed=2), lo, hi),
+          workloads.shard_batch(workloads.planner_batch(half, N=20, seed=2), lo, hi)]
     t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     dev_in = [{k: t(w[k]) for k in ("x0", "u_prev", "vel_ref", "curv_s", "u_old", "max_ey")} for w in ws]
     S = max(1, min(args.streams, 8))                      # 8192 instances per launch fill the GPU: a few pairs in flight are enough
@@ -575,17 +594,24 @@ def bench_mixed(args, rank, local_rank, world, dev):
     its = [lanes[0][i][1]["iters"].cpu().numpy().astype(np.int64) for i in range(2)]
     sts = [lanes[0][i][1]["status"].cpu().numpy() for i in range(2)]
     elapsed, agg = reduce_stats(elapsed, [float(its[0].sum()), float(its[1].sum()), float((sts[0] == 1).sum() + (sts[1] == 1).sum())], device=dev)
+    # the one collective, after the timed region: (u0, status, iters) of every instance of the global batch, in instance order
+    gathered = [gather_results(lanes[0][i][1]["uPred"][:, 0, :].cpu().numpy(), sts[i], its[i], half, device=dev) for i in range(2)]
+    assert all(g[0].shape == (half, 2) for g in gathered)
+    if rank == 0 and args.dump_results:
+        np.savez(args.dump_results, ctrl_u0=gathered[0][0], ctrl_status=gathered[0][1], ctrl_iters=gathered[0][2],
+                 plan_u0=gathered[1][0], plan_status=gathered[1][1], plan_iters=gathered[1][2], half=half, world=world, seed=2)
     if rank == 0:
         bl_c, _ = algorithmic_bytes(its[0])
         bl_p, bi_p = algorithmic_bytes(its[1], N=20, nx=5, m_rows=21 * 5 + 21 * 5 + 20 * 2)
         k_avg_s = kms[1] / max(kn[1], 1) * 1e-3
-        out = {"metric": "MPC solves/sec (mixed planner + controller, N=20)", "value": 2 * Bh * world * args.steps / elapsed, "unit": "solves/s",
+        out = {"metric": "MPC solves/sec (mixed planner + controller, N=20)", "value": 2 * half * args.steps / elapsed, "unit": "solves/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                "scaling": "strong" if args.batch == BATCH else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "configs[3]: %d instances per GPU, half LPV-MPC controller (oval), half LPV-MPP planner (L-shape), N=20, "
-                                      "OSQP defaults + polish, cold start" % (2 * Bh), "batch_per_gpu": 2 * Bh, "horizon": 20,
-                          "mean_admm_iters_controller": agg[0] / (Bh * world), "mean_admm_iters_planner": agg[1] / (Bh * world),
-                          "solved_fraction": agg[2] / (2 * Bh * world), "stream_pairs": S,
+               "config": {"workload": "configs[3]: one global batch of %d instances split contiguously over the GPUs (%d on rank 0), half LPV-MPC "
+                                      "controller (oval), half LPV-MPP planner (L-shape), N=20, OSQP defaults + polish, cold start" % (total, 2 * Bh),
+                          "global_instances": total, "shard_rank0": [lo, hi], "batch_per_gpu": 2 * Bh, "horizon": 20,
+                          "mean_admm_iters_controller": agg[0] / half, "mean_admm_iters_planner": agg[1] / half,
+                          "solved_fraction": agg[2] / (2 * half), "stream_pairs": S,
                           "controller_kernel_avg_ms": kms[0] / max(kn[0], 1)},
                "roofline": {"bound": "hbm", "achieved": bl_p / k_avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bl_p / k_avg_s / 1e9 / HBM_PEAK_GBS,
                             "traffic": None, "kernel": "admm_solve_kernel<5, 20, 2, MFMA sweeps>", "kernel_avg_ms": kms[1] / max(kn[1], 1), "launches": kn[1],

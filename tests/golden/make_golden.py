@@ -14,7 +14,10 @@ Captured (all float64):
   * oracle solutions with their KKT-certified optimum            -> solution pins
 Nothing of the reference's source text is stored: only inputs and numeric outputs.
 
-Usage:  python tests/golden/make_golden.py        (needs /root/reference; NOT run on the GPU box)
+Usage:  python tests/golden/make_golden.py [--out DIR] [handoff | delay]   (needs /root/reference; NOT run on the GPU box)
+
+Every file written is also entered in MANIFEST.json (its keys, with shape and dtype): tests/test_oracle_golden.py fails when a
+committed fixture's key set differs from what this generator writes.
 """
 import os
 import shutil
@@ -28,6 +31,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = HERE        # --out DIR: write there instead (to compare a fresh set with the committed one)
 sys.path.insert(0, ROOT)
 REF = "/root/reference/workspace/src/barc/src"
 
@@ -184,13 +188,35 @@ def plan_case(PLAN, mp, N, dt, x0, SS, u_prev, max_ey):
                 xPred=np.array(p.xPred), uPred=np.array(p.uPred), LinPoints=np.array(p.LinPoints))
 
 
+MANIFEST = {}
+
+
+def save_npz(filename, arrays):
+    """Write one fixture and record its key set (name -> [shape, dtype]) for MANIFEST.json."""
+    np.savez_compressed(os.path.join(OUT, filename), **arrays)
+    MANIFEST[filename] = {k: [list(np.asarray(v).shape), str(np.asarray(v).dtype)] for k, v in sorted(arrays.items())}
+
+
+def write_manifest():
+    """Merge this run's entries into MANIFEST.json (a partial regeneration keeps the other files' entries)."""
+    import json
+    path = os.path.join(OUT, "MANIFEST.json")
+    old = {}
+    if os.path.exists(path):
+        old = json.load(open(path))
+    elif os.path.exists(os.path.join(HERE, "MANIFEST.json")):
+        old = json.load(open(os.path.join(HERE, "MANIFEST.json")))
+    old.update(MANIFEST)
+    json.dump(old, open(path, "w"), indent=0, sort_keys=True)
+
+
 def save_cases(name, cases):
     flat = {}
     for i, c in enumerate(cases):
         for k, v in c.items():
             flat["c%02d_%s" % (i, k)] = np.asarray(v)
     flat["n_cases"] = np.array(len(cases))
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), **flat)
+    save_npz(name + ".npz", flat)
     print("wrote %s.npz (%d cases)" % (name, len(cases)))
 
 
@@ -274,7 +300,7 @@ def gen_handoff(CTRL, PLAN, TRACK, UTIL):
         s = s0 + ((vx * np.cos(epsi) - vy * np.sin(epsi)) / (1 - ey * cv)) * (1.0 / 30)
         bfe_out.append([s, ex, ey, epsi])
     ho.update(bfe_in=bfe_in, bfe_out=np.array(bfe_out))
-    np.savez_compressed(os.path.join(HERE, "handoff.npz"), **ho)
+    save_npz("handoff.npz", ho)
     print("wrote handoff.npz")
 
     # ---- (2) cascade: lap-0 approach to the start line, lap event, then planner + Controller_TT + plant ----
@@ -369,14 +395,28 @@ def gen_handoff(CTRL, PLAN, TRACK, UTIL):
     cas.update({"ctrl_" + k: np.array(v) for k, v in tr.items()})
     cas.update({"plan_" + k: np.array([r[k] for r in node.log]) for k in ("xPred", "uPred", "refs", "iters", "status", "SS_out")})
     cas.update(table=table)
-    np.savez_compressed(os.path.join(HERE, "cascade.npz"), **cas)
+    save_npz("cascade.npz", cas)
     print("wrote cascade.npz")
 
 
 def main():
+    global OUT
     warnings.simplefilter("ignore")
+    if "--out" in sys.argv:
+        i = sys.argv.index("--out"); OUT = os.path.abspath(sys.argv[i + 1]); del sys.argv[i:i + 2]
+        os.makedirs(OUT, exist_ok=True)
     CTRL, PLAN, TRACK, UTIL, tmp = import_reference()
     try:
+        try:
+            generate(CTRL, PLAN, TRACK, UTIL)
+        finally:
+            write_manifest()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def generate(CTRL, PLAN, TRACK, UTIL):
+    if True:
         if "handoff" in sys.argv[1:]:                       # regenerate only handoff.npz / cascade.npz
             gen_handoff(CTRL, PLAN, TRACK, UTIL)
             return
@@ -407,7 +447,7 @@ def main():
             tracks[shape + "_halfWidth"] = np.array(mp.halfWidth)
             tracks[shape + "_s"] = ss
             tracks[shape + "_curv"] = np.array([UTIL.Curvature(s, mp.PointAndTangent) for s in ss])
-        np.savez_compressed(os.path.join(HERE, "tracks.npz"), **tracks)
+        save_npz("tracks.npz", tracks)
         print("wrote tracks.npz")
 
         oval = make_map(TRACK, "oval")
@@ -483,7 +523,7 @@ def main():
         seed.update(plan_x0=px0, plan_xx=pxx, plan_uu=puu, plan_A=stackL(p.A), plan_B=stackL(p.B),
                     plan_P=cap["P"], plan_q=cap["q"], plan_Aqp=cap["A"], plan_l=cap["l"], plan_u=cap["u"],
                     plan_xPred=np.array(p.xPred), plan_uPred=np.array(p.uPred))
-        np.savez_compressed(os.path.join(HERE, "seed_mode.npz"), **seed)
+        save_npz("seed_mode.npz", seed)
         print("wrote seed_mode.npz")
 
         # ---------------- closed-loop recursions (20 ticks) ----------------
@@ -533,7 +573,7 @@ def main():
             SS[0] = SS[1]
             tx.append(np.array(p.xPred)); tu.append(np.array(p.uPred)); tss.append(SS.copy())
         cl.update(plan_xPred=np.array(tx), plan_uPred=np.array(tu), plan_SS=np.array(tss))
-        np.savez_compressed(os.path.join(HERE, "closed_loop.npz"), **cl)
+        save_npz("closed_loop.npz", cl)
         print("wrote closed_loop.npz")
 
         # ---------------- plant model + coordinate transforms ----------------
@@ -592,11 +632,9 @@ def main():
             for _ in range(7):
                 sim.f([cmd[1], cmd[0]])                     # u = [motor, servo]  (vehicleSimulator.py:330)
         pt.update(cl_plant=np.array(tr_plant), cl_local=np.array(tr_local), cl_cmd=np.array(tr_cmd), cl_iter=np.array(tr_iter))
-        np.savez_compressed(os.path.join(HERE, "plant_and_transforms.npz"), **pt)
+        save_npz("plant_and_transforms.npz", pt)
         print("wrote plant_and_transforms.npz")
         gen_handoff(CTRL, PLAN, TRACK, UTIL)
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -99,7 +99,7 @@ def test_cascade_matches_reference_trace():
     termination check the trajectories agree to round-off (strict phase: 1e-5 on states, 1e-4 on commands / references).
     Once a planner QP sits so close to the threshold that the two float64 implementations stop one check (25
     iterations) apart, the two runs carry solutions that differ at the eps level; from there only a loose tolerance is
-    meaningful.  The strict phase has to cover at least the first 30 planner ticks."""
+    meaningful.  The strict phase has to cover the observed 51 controller ticks (34 planner ticks)."""
     c, out = run_trace(0, 60)
     strict = dict(plant=0.0, local=0.0, cmd=0.0, refs=0.0); loose = dict(strict)
     split = None
@@ -118,7 +118,9 @@ def test_cascade_matches_reference_trace():
         w["cmd"] = max(w["cmd"], float(np.max(np.abs(after["cmd"][0] - c["ctrl_cmd"][k]))))
         w["refs"] = max(w["refs"], float(np.max(np.abs(after["refs"][0] - c["plan_refs"][j]))))
     print("cascade trace: strict phase until (controller tick, planner tick) =", split, strict, "after:", loose)
-    assert split is None or split[1] >= 30
+    # observed: the first planner QP that stops one check apart belongs to controller tick 51 (planner tick 34); a strict
+    # phase shorter than that is a regression of the solver arithmetic, not round-off
+    assert split is None or (split[0] >= 51 and split[1] >= 34), split
     assert strict["plant"] <= 1e-5 and strict["local"] <= 1e-5 and strict["cmd"] <= 1e-4 and strict["refs"] <= 1e-4
     assert max(loose.values()) <= 2e-2
 

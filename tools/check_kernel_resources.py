@@ -11,6 +11,40 @@ import re
 import sys
 
 
+def hot_path(path):
+    """Per kernel: what sits between the `; LPVMPC_HOT_BEGIN` / `; LPVMPC_HOT_END` markers the solve kernel puts around the
+    code of one ADMM iteration -- scratch accesses (VGPR spills), v_readlane / v_writelane on the VGPRs that hold spilled
+    SGPRs (the registers v_writelane targets anywhere in the kernel), and the instruction count.  The region is taken in text
+    order, so blocks the compiler laid out in between are included: the figure is an upper bound."""
+    out, name, body = {}, None, []
+    for ln in open(path):
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            name, body = m.group(1), []
+            continue
+        if name is None:
+            continue
+        body.append(ln)
+        if ln.startswith(".Lfunc_end"):
+            spill_regs = set(re.findall(r"v_writelane_b32\s+(v\d+)", "".join(body)))
+            hot, n_ins, scratch, lanes = False, 0, 0, 0
+            for b in body:
+                if "LPVMPC_HOT_BEGIN" in b:
+                    hot = True
+                elif "LPVMPC_HOT_END" in b:
+                    hot = False
+                elif hot and b.startswith("\t") and not b.strip().startswith((".", ";")):
+                    n_ins += 1
+                    op = b.split()[0]
+                    scratch += op.startswith("scratch_")
+                    if op in ("v_readlane_b32", "v_writelane_b32") and re.search(r"\b(v\d+)\b", b.split(None, 1)[1]) and \
+                            set(re.findall(r"\bv\d+\b", b)) & spill_regs:
+                        lanes += 1
+            out[name] = dict(instructions=n_ins, scratch=scratch, spill_lane_moves=lanes)
+            name = None
+    return out
+
+
 def kernels(path):
     out, cur = [], None
     for ln in open(path):
@@ -33,15 +67,18 @@ def kernels(path):
 
 if __name__ == "__main__":
     path, args = sys.argv[1], sys.argv[2:]
-    allow, pats = {}, []
+    allow, pats, hot_lanes_max = {}, [], None
     while args:
         a = args.pop(0)
         if a == "--allow":
             name, _, lim = args.pop(0).partition("=")
             allow[name] = int(lim)
+        elif a == "--hot-lane-moves":           # largest number of SGPR-spill lane moves tolerated between the hot-path markers
+            hot_lanes_max = int(args.pop(0))
         else:
             pats.append(a)
     bad = 0
+    hot = hot_path(path)
     for k in kernels(path):
         if pats and not any(p in k["name"] for p in pats):
             continue
@@ -51,4 +88,10 @@ if __name__ == "__main__":
         print("%s %-70s vgpr %3d  vgpr spills %2d  scratch %3d B  (sgpr spills %d)" % (
             "SPILL" if flag else ("allow" if spills or scratch else "ok   "), k["name"][:70], k.get("vgpr_count", -1), spills, scratch, k.get("sgpr_spill_count", 0)))
         bad += flag
+        h = hot.get(k["name"])
+        if h and h["instructions"]:
+            hflag = h["scratch"] > 0 or (hot_lanes_max is not None and h["spill_lane_moves"] > hot_lanes_max)
+            print("      per-iteration code (between the markers): %d instructions, %d scratch accesses, %d SGPR-spill lane moves%s"
+                  % (h["instructions"], h["scratch"], h["spill_lane_moves"], "  <-- FAIL" if hflag else ""))
+            bad += hflag
     sys.exit(1 if bad else 0)
