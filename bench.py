@@ -353,8 +353,10 @@ def main():
                             "solved_fraction": agg[1] / total}, **extras),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc.get("traffic_bytes_per_launch"), "traffic_source": pmc.get("source"),
+                         "traffic": pmc.get("traffic_bytes_per_launch"), "traffic_source": pmc.get("traffic_source") or pmc.get("source"),
                          "valu": pmc.get("valu"), "valu_source": pmc.get("source") if pmc.get("valu") else None,
+                         # the same counters for the configuration that is timed here (main launches of the deferral mode)
+                         "valu_timed": pmc.get("valu_timed"),
                          "kernel": "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, (", equilibration vectors in global memory (3 instances per CU)" if args.kernel_variant == 0 and args.defer == 0 else "")
                                                                             if planner else ("" if args.kernel_variant == 3 else ", MFMA sweeps")),
                          "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
@@ -444,13 +446,28 @@ def load_pmc(B, planner):
     the output next to the numbers."""
     if planner or B != BATCH:
         return {}
-    for name in ("r02_pmc.json",):
+    for name in ("r03_pmc.json", "r02_pmc.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
             continue
         if pm.get("batch") == B:
             pm["source"] = "profiles/%s (%s); collected separately, not measured in this run" % (name, pm.get("command", "rocprofv3 --pmc"))
+            t = (pm.get("timed") or {}).get("main")
+            if t and t.get("valu"):
+                # main launches of the timed configuration (deferral 100 / 100): traffic and VALU issue of a launch that parks its
+                # stragglers instead of waiting for them
+                if t.get("traffic_bytes_per_launch"):
+                    pm["traffic_bytes_per_launch"] = t["traffic_bytes_per_launch"]
+                    pm["traffic_source"] = "profiles/%s, section timed.main: FETCH_SIZE x 2 + WRITE_SIZE (separate --pmc passes) of the main launches of %s" % (name, pm["timed"].get("command", ""))
+                v = t["valu"]
+                pm["valu_timed"] = {"issue_cycles": v["issue_cycles"], "frac": v["frac"], "launch_cycles": v["launch_cycles"],
+                                    "wave_instr_per_launch": v["wave_instr_per_launch"], "kernel_ns_under_pmc": t.get("kernel_ns_under_pmc"),
+                                    "active_share_of_wave_cycles": v.get("active_share_of_wave_cycles"),
+                                    "wait_share_of_wave_cycles": v.get("wait_share_of_wave_cycles"),
+                                    "source": "profiles/%s, section timed.main (%s): %d main launches, each alone on the GPU while its counters "
+                                              "are read" % (name, pm["timed"].get("command", ""), t.get("launches_averaged", 0))}
+            pm.pop("timed", None); pm.pop("sq_per_launch", None)
             return pm
     return {}
 
