@@ -109,5 +109,11 @@ def test_device_assembly_has_no_copy_in_front_of_an_exec_restore(ffi):
         fh.write("_Zk:\n.LBB0_1:\n\tv_mov_b32_e32 v200, v188\n\ts_mov_b64 s[74:75], s[70:71]\n\ts_or_b64 exec, exec, s[12:13]\n\tds_write_b64 v1, v[2:3]\n")
     try:
         assert len(chk.scan(bad)) == 1
+        # ... and does not mistake the tail of a guarded region opened inside the block (default for all lanes, narrowed mask,
+        # copy for the lanes of the region, restore) for it
+        with open(bad, "w") as fh:
+            fh.write("_Zk:\n.LBB0_1:\n\tv_mov_b32_e32 v33, 0x58\n\ts_and_saveexec_b64 s[12:13], s[20:21]\n\tds_read_b64 v[30:31], v233\n"
+                     "\tv_mov_b32_e32 v33, v234\n\ts_or_b64 exec, exec, s[12:13]\n\tds_write_b64 v1, v[2:3]\n")
+        assert chk.scan(bad) == []
     finally:
         os.remove(bad)

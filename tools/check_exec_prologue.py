@@ -65,7 +65,14 @@ def scan(path, window=8):
                     # stores and v_writelane (exec-independent SGPR spills) in front of the mask restore are normally the
                     # legitimate tail of the branch that falls through into the join block
                     pre = []
+                    # a mask-narrowing instruction between the label and the restore opens a NEW guarded region inside this block
+                    # (if-then without else: `v_mov v33, default; s_and_saveexec; v_mov v33, v234; s_or_b64 exec`): copies behind
+                    # it belong to that region's lanes by construction, the other lanes keep the value set in front of it
+                    opened = [i_ for i_, b_ in enumerate(body[:k]) if re.match(r"s_(and|andn2|xor|or)_saveexec_b64|s_and_b64\s+exec,|s_andn2_b64\s+exec,|s_mov_b64\s+exec,", b_)]
+                    first_open = opened[0] if opened else k
                     for idx, b in enumerate(body[:k]):
+                        if idx > first_open:
+                            continue
                         if not re.match(r"(v_mov_b32_e32\s+v\d+,\s*v\d+$|v_mov_b64_e32\s+v\[[\d:]+\],\s*v\[|v_accvgpr_(read|write)_b32)", b):
                             continue
                         # a copy whose destination is consumed again before the mask restore is a temporary of the branch
