@@ -140,7 +140,7 @@ int lpvmpc_last_error_code(void);
  * points, "defer_budget" 0) use the whole-CU tail kernel where one exists for the handle (controller, N = 20): a 512-thread
  * workgroup per instance that applies K^-1 as a dense matrix held in registers, 1.65x faster per iteration for an instance that
  * has the GPU to itself.  Statuses, iteration counts and polish flags equal the other kernel's; solutions agree to round-off
- * (1e-8 polished, 1e-6 for an un-polished iterate; observed 2e-10), so bit-identity with the plain call holds with 0 only. */
+ * (1e-7 polished, 1e-6 for an un-polished iterate; observed 1.4e-8 / 7e-10 over 196 608 instances), so bit-identity with the plain call holds with 0 only. */
 int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value);
 /* Straggler deferral (see "defer_after"): enqueues on `stream` (a hipStream_t; ordered behind the stream of the handle's last
  * deferred call if it is another one) the resume pass that runs every parked instance to completion.  No-op without deferral. */

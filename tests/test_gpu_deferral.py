@@ -4,7 +4,7 @@ lpvmpc_join finishes what is left.  Nothing about the results may change: status
 every word of xPred / uPred are BIT-IDENTICAL to the plain call (a restored instance re-factors K from its saved state, a pure
 function of it) -- as long as the same kernel continues it ("defer_tail" 0).  By default the pass that runs the parked instances to
 completion is the whole-CU tail kernel, which applies K^-1 as a dense matrix: same statuses, iteration counts and polish flags,
-solutions equal to round-off (the tests at the end)."""
+solutions equal to round-off (the tests at the end; tests/diagnostics/tail_sweep.py: 196 608 instances)."""
 import numpy as np
 import pytest
 
@@ -164,8 +164,9 @@ def test_host_array_call_with_deferral_returns_finished_results():
 
 
 # ---- the whole-CU tail kernel (default for the passes that run to completion) ---------------------------------------------
-def _close_to(got, ref, tol_polished=1e-8, tol_iterate=1e-6):
-    """Same decisions, solutions equal to round-off: a polished solution is recomputed from the active set (1e-8), an ADMM iterate
+def _close_to(got, ref, tol_polished=1e-7, tol_iterate=1e-6):
+    """Same decisions, solutions equal to round-off: a polished solution is recomputed from the active set by two different
+    factorisations of the 1/delta-weighted system (cond ~ 3e9: 2e-8 per solve; 1e-7 here, 1.4e-8 the largest seen over 196 608 instances), an ADMM iterate
     carries the K^-1 round-off of up to 4000 iterations (1e-6 relative to the largest entry; observed 1e-10)."""
     for k in ("status", "iters", "polish"):
         assert np.array_equal(got[k], ref[k]), (k, np.nonzero(got[k] != ref[k])[0][:8])
