@@ -237,3 +237,52 @@ def test_tail_kernel_max_iter_instances_against_the_oracle():
             assert np.max(np.abs(got["uPred"][b] - uP)) <= tol and np.max(np.abs(got["xPred"][b] - xP)) <= tol * max(1.0, np.max(np.abs(xP)))
             n_max_iter += int(r.info.iter >= 3900)
     assert n_max_iter >= 2          # seed 16: 3900 iterations, seed 19: OSQP's max_iter = 4000
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+def test_tail_kernel_continues_entries_parked_by_the_other_compile_time_kernels(variant):
+    """The one-wavefront (variant 2) and the DPP two-wavefront kernel (variant 3) park the same LDS image as the MFMA kernel: the
+    tail kernel finishes their entries too (the run-time-horizon kernel, variant 1, keeps its own resume path: bit-identical)."""
+    import torch
+    from lpvmpc import workloads
+    B = 512
+    w = workloads.controller_batch(B, N=20, seed=3)
+    plain = workloads.make_solver(w); plain.set_option("kernel_variant", variant); plain.reserve(B)
+    _, o = _dev_call(torch, plain, w, B, False); torch.cuda.synchronize(); ref = _host(o); plain.close()
+    assert np.sum(ref["iters"] > 100) >= 3
+    eng = workloads.make_solver(w); eng.set_option("kernel_variant", variant); eng.reserve(B)
+    eng.set_option("defer_after", 100); eng.set_option("defer_budget", 100)
+    _, o = _dev_call(torch, eng, w, B, False)
+    eng.join(0); torch.cuda.synchronize()
+    _close_to(_host(o), ref)
+    eng.set_option("kernel_variant", 1)                       # variant 1 parks another image: resumed by its own kernel, bit-identical
+    plain = workloads.make_solver(w); plain.set_option("kernel_variant", 1); plain.reserve(B)
+    _, o1 = _dev_call(torch, plain, w, B, False); torch.cuda.synchronize(); ref1 = _host(o1); plain.close()
+    _, o = _dev_call(torch, eng, w, B, False)
+    eng.join(0); torch.cuda.synchronize()
+    _same(_host(o), ref1)
+    eng.close()
+
+
+def test_tail_kernel_with_steering_delay_rows():
+    """steeringDelay = 2 (CTRL:518-527): the pinned-steering rows are a seventh box row on the first two stages; the tail kernel
+    carries them through its right-hand side, update and factorisation like the other kernels."""
+    import torch
+    from lpvmpc import workloads
+    B = 1024
+    w = workloads.controller_batch(B, N=20, seed=3)
+    rng = np.random.default_rng(11)
+    w = dict(w, u_old=np.concatenate((w["u_old"], rng.normal(0, 0.08, (B, 2))), axis=1))      # [OldSteering[0], OldAccelera[0], OldSteering[1..2]]
+    outs = {}
+    for tail in (None, 1):
+        eng = workloads.make_solver(w, steering_delay=2); eng.reserve(B)
+        if tail is not None:
+            eng.set_option("defer_after", 100); eng.set_option("defer_budget", 100)
+        _, o = _dev_call(torch, eng, w, B, False)
+        eng.join(0); torch.cuda.synchronize()
+        outs[tail] = _host(o); eng.close()
+    assert np.sum(outs[None]["iters"] > 100) >= 4
+    _close_to(outs[1], outs[None])
+    # the pinned rows are honoured as OSQP honours them (polish regularises active rows with delta = 1e-6: violation = delta x multiplier)
+    pol = outs[1]["polish"] == 1
+    assert pol.sum() > 900 and np.median(np.abs(outs[1]["uPred"][pol, :2, 0] - w["u_old"][pol, 2:4])) < 1e-9
