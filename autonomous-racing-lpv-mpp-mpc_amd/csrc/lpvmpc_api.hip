@@ -161,7 +161,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->d_Wop = h->d_FWop = nullptr; h->ho_M = 0; h->cascade = nullptr; h->cascade_owner = nullptr; h->cascade_prefetch = 1;
     h->defer_after = 0; h->defer_budget = 200; h->defer_cap = 0; h->defer_cur_cap = 0; h->defer_stride = 0; h->rv_count = 0;
     h->dpool[0] = h->dpool[1] = nullptr; h->dcount[0] = h->dcount[1] = nullptr; h->dcur = 0; h->defer_stream = nullptr; h->defer_event = nullptr;
-    h->defer_stream_set = false; h->defer_tail = 1;
+    h->defer_stream_set = false; h->defer_tail = 1; h->defer_skip_pass = false;
     h->h_pack_in = h->h_pack_out = h->d_pack_in = h->d_pack_out = nullptr;
     DevCfg &d = h->dev;
     std::memset(&d, 0, sizeof(d));
@@ -246,7 +246,7 @@ extern "C" int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t val
         h->defer_after = value; return LPVMPC_OK;
     }
     if (std::strcmp(name, "defer_budget") == 0) {
-        if (value < 0) return fail(h, LPVMPC_E_ARG, "defer_budget must be >= 0 (iterations per resume pass; 0 = every pass runs to completion)");
+        if (value < -1) return fail(h, LPVMPC_E_ARG, "defer_budget must be >= -1 (iterations per resume pass; 0 = every pass runs to completion; -1 = no pass behind a call: parked instances wait for lpvmpc_join)");
         h->defer_budget = value; return LPVMPC_OK;
     }
     if (std::strcmp(name, "defer_pool") == 0) {
@@ -534,7 +534,9 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
         a.defer_after = h->defer_after; a.resume = 0; a.pool = h->dpool[h->dcur]; a.pool_count = h->dcount[h->dcur];
         a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride;
         rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
-        rc = resume_pass(h, h->defer_budget, st); if (rc) return rc;
+        // the bounded pass behind the call -- unless the caller joins right away (budget -1, and the synchronous host-array entry
+        // point): then the closing pass (the tail kernel) takes the parked instances straight from this launch
+        if (h->defer_budget >= 0 && !h->defer_skip_pass) { rc = resume_pass(h, h->defer_budget, st); if (rc) return rc; }
     } else {
         rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
     }
@@ -596,8 +598,10 @@ extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0,
     int32_t *o_st = (int32_t *)io.out(status, h->d_status, b * 4), *o_it = (int32_t *)io.out(iters, h->d_iters, b * 4);
     double *o_res = (double *)io.out(resid, h->d_resid, b * 4 * 8);
     int32_t *o_pol = (int32_t *)io.out(polish, h->d_polish, b * 4);
+    h->defer_skip_pass = true;
     rc = lpvmpc_solve_batch_dev(h, B, (const double *)p_x0, (const double *)p_up, (const double *)p_vel, (const double *)p_curv,
                                 (const double *)p_uold, (const double *)p_mey, cf_new, lap, o_x, o_u, o_st, o_it, o_res, o_pol, (void *)st);
+    h->defer_skip_pass = false;
     if (rc) return rc;
     if (h->defer_after > 0) { rc = lpvmpc_join(h, (void *)st); if (rc) return rc; }      // a synchronous call returns finished instances only
     return io.flush_out();

@@ -55,6 +55,7 @@ struct lpvmpc_handle {
     // of pool[dcur] and parks what is still unsolved after its budget into the other pool, which becomes dcur
     int defer_after, defer_budget, defer_cap;   // iterations before parking (0 = off); iterations per resume pass; pool entries (0 = default)
     int defer_tail;                     // option "defer_tail" (default 1): passes that run to completion take the whole-CU tail kernel
+    bool defer_skip_pass;               // transient: the synchronous entry point joins at once, no bounded pass in between
     int defer_cur_cap, defer_stride;
     double *dpool[2];
     int32_t *dcount[2];

@@ -252,7 +252,12 @@ def main():
             solve_slot(j % NBAT, e=0)
         sync()
         extras["single_stream_solves_per_s_per_gpu"] = B * n_serial / (time.perf_counter() - t1)
-        # latency of one synchronous batch: every distinct batch once (p50 over batches), and the seed-0 batch alone
+        # latency of one synchronous batch: every distinct batch once (p50 over batches), and the seed-0 batch alone.  A caller that
+        # joins after every call has no use for the bounded pass in between: defer_budget -1 for these legs (the closing pass, i.e. the
+        # tail kernel, takes the parked instances straight from the batch's launch)
+        if args.defer > 0:
+            for e in engines:
+                e.set_option("defer_budget", -1)
         lat = []
         for i in range(NBAT):
             sync(); t1 = time.perf_counter(); solve_slot(i); sync()
@@ -264,6 +269,9 @@ def main():
             sync(); t1 = time.perf_counter(); solve_slot(0); sync()
             l0.append((time.perf_counter() - t1) * 1e3)
         extras["seed0_batch_latency_ms"] = float(np.median(l0))
+        if args.defer > 0:
+            for e in engines:
+                e.set_option("defer_budget", args.defer_budget)
         # isolated launches of the seed-0 batch (nothing else on the GPU): the per-launch kernel time without neighbours
         engines[0].set_timing(True)
         for _ in range(5):

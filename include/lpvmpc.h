@@ -134,6 +134,8 @@ int lpvmpc_last_error_code(void);
  * enqueues the pass that finishes whatever is still parked, so work behind it in `stream` sees complete outputs.  Until then
  * the output buffers of the deferred calls must stay valid and must not be reused for other data.  The synchronous host-array
  * call lpvmpc_solve_batch joins by itself before it copies the outputs back (it never returns LPVMPC_PENDING).
+ * "defer_budget" -1: no pass behind a deferred call at all; the parked instances wait for lpvmpc_join (what a caller that joins
+ * after every call wants: one batch, then the tail kernel; lpvmpc_solve_batch does this by itself).
  * "defer_pool" (entries, 0 = max(64, B / 8), default): capacity of each of the two pools; instances that find the pool full
  * are not parked (they finish inside the launch that holds them).
  * "defer_tail" (0 | 1, default 1): the passes that run parked instances to completion (lpvmpc_join, the synchronous entry

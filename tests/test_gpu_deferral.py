@@ -192,10 +192,13 @@ def test_tail_kernel_finishes_parked_stragglers(seed):
     plain = workloads.make_solver(w); plain.reserve(B)
     _, o = _dev_call(torch, plain, w, B, False); torch.cuda.synchronize(); ref = _host(o); plain.close()
     assert ref["iters"].max() >= 2400
-    for budget in (100, 0):
+    for budget in (100, 0, -1):                    # -1: no pass behind the call, the join's tail pass takes everything
         eng = workloads.make_solver(w); eng.reserve(B)
         eng.set_option("defer_after", 100); eng.set_option("defer_budget", budget)
         _, o = _dev_call(torch, eng, w, B, False)
+        if budget == -1:
+            torch.cuda.synchronize()
+            assert np.sum(_host(o)["status"] == -11) == np.sum(ref["iters"] > 100)       # everything unsolved at 100 is still parked
         eng.join(0); torch.cuda.synchronize()
         got = _host(o)
         _close_to(got, ref)
