@@ -233,7 +233,23 @@ def test_cascade_bad_arguments():
         plan.cascade_init(ctrl, args[0], args[1], np.zeros((1, 40, 2)))
     with pytest.raises(lpvmpc.LpvMpcError):
         ctrl.cascade_tick(1)                                # not initialised
-    ctrl.close(); plan.close()
+    # a controller handle with steering delay reads u_old as [B][2 + delay]; the cascade's measurement kernel writes [B][2]:
+    # refused, as lpvmpc_cl_init refuses it (the reference runs steeringDelay = 0, CMAIN:49)
+    from lpvmpc import workloads as W_
+    Qr, Rr, dRr = W_.CTRL_TUNINGS["race"]
+    delayed = lpvmpc.BatchedSolver("controller", 20, 1 / 30.0, Qr, Rr, dRr, track=mp.PointAndTangent, steering_delay=1)
+    with pytest.raises(lpvmpc.LpvMpcError) as e:
+        delayed.cascade_init(plan, *args)
+    assert "steeringDelay" in str(e.value)
+    delayed.close()
+    # destroy order: the planner handle may go first (its destroy ends the cascade that points at it); the controller handle
+    # is usable and destroyable afterwards
+    ctrl.cascade_init(plan, *args, half_width=mp.halfWidth, slack=mp.slack, plan_max_ey=0.2)
+    ctrl.cascade_tick(2)
+    plan.close()
+    with pytest.raises(lpvmpc.LpvMpcError):
+        ctrl.cascade_tick(1)                                # the cascade went with its planner
+    ctrl.close()
 
 
 def test_cascade_attrition_matches_the_oracle_cascade():

@@ -289,3 +289,26 @@ def test_tail_kernel_with_steering_delay_rows():
     # the pinned rows are honoured as OSQP honours them (polish regularises active rows with delta = 1e-6: violation = delta x multiplier)
     pol = outs[1]["polish"] == 1
     assert pol.sum() > 900 and np.median(np.abs(outs[1]["uPred"][pol, :2, 0] - w["u_old"][pol, 2:4])) < 1e-9
+
+
+def test_deferred_call_on_the_null_stream_then_another_stream():
+    """The null stream is a stream like any other: a deferred call on stream 0 followed -- without a synchronisation -- by a
+    deferred call and the join on another stream is ordered by the handle's event hand-over (the pools are not touched by the
+    second stream's launches while the first stream's resume pass still writes them)."""
+    import torch
+    from lpvmpc import workloads
+    B = 1024
+    w = workloads.controller_batch(B, N=20, seed=3)
+    plain = workloads.make_solver(w); plain.reserve(B)
+    _, o = _dev_call(torch, plain, w, B, False); torch.cuda.synchronize(); ref = _host(o); plain.close()
+    eng = workloads.make_solver(w); eng.reserve(B)
+    eng.set_option("defer_after", 100); eng.set_option("defer_budget", 100); eng.set_option("defer_tail", 0)
+    st = torch.cuda.Stream()
+    keep = []
+    for rep in range(3):
+        keep.append(_dev_call(torch, eng, w, B, False))                      # stream 0 (the null stream)
+        keep.append(_dev_call(torch, eng, w, B, False, stream=st))           # straight on to another stream: no synchronisation
+    eng.join(st.cuda_stream); torch.cuda.synchronize()
+    for _, o in keep:
+        _same(_host(o), ref)
+    eng.close()
