@@ -1936,7 +1936,9 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
     const bool generic = kernel_variant == 1, one_wave = kernel_variant == 2, dpp = kernel_variant == 3;
     // a resume pass that runs its entries to completion may use the whole-CU tail kernel (SolveArgs::tail); the entries must
     // have been parked by a kernel with the compile-time-horizon LDS image
-    if (a.resume && a.tail && a.defer_after == 0 && !generic && cfg.kind == 0 && cfg.N == 20) return launch_one<6, 20, 8, false, false, true>(cfg, dcfg, a, stream);
+    // (controller and planner at N = 20: 168 unknowns either way, K^-1 fits the register file of a CU; 248 / 328 at N = 30 / 40 do not)
+    if (a.resume && a.tail && a.defer_after == 0 && !generic && cfg.N == 20)
+        return cfg.kind == 0 ? launch_one<6, 20, 8, false, false, true>(cfg, dcfg, a, stream) : launch_one<5, 20, 8, false, false, true>(cfg, dcfg, a, stream);
     if (cfg.kind == 0) {
         if (!generic && cfg.N == 20) return one_wave ? launch_one<6, 20, 1>(cfg, dcfg, a, stream)
                                           : (dpp ? launch_one<6, 20, 2>(cfg, dcfg, a, stream) : launch_one<6, 20, 2, true>(cfg, dcfg, a, stream));

@@ -578,6 +578,8 @@ def bench_mixed(args, rank, local_rank, world, dev):
         pair = []
         for w, nx in zip(ws, (6, 5)):
             e = workloads.make_solver(w, device=local_rank); e.reserve(Bh)
+            if args.defer > 0:          # (extra: straggler deferral on this workload too; both N = 20 kernels have the tail kernel)
+                e.set_option("defer_after", args.defer); e.set_option("defer_budget", args.defer_budget); e.set_option("defer_pool", args.defer_pool)
             o = dict(xPred=torch.empty((Bh, 21, nx), dtype=torch.float64, device=dev), uPred=torch.empty((Bh, 20, 2), dtype=torch.float64, device=dev),
                      status=torch.empty(Bh, dtype=torch.int32, device=dev), iters=torch.empty(Bh, dtype=torch.int32, device=dev),
                      resid=torch.empty((Bh, 4), dtype=torch.float64, device=dev), polish=torch.empty(Bh, dtype=torch.int32, device=dev))
@@ -592,6 +594,10 @@ def bench_mixed(args, rank, local_rank, world, dev):
                         o["iters"], o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"], stream=st.cuda_stream)
 
     def fence():
+        if args.defer > 0:
+            for pair in lanes:
+                for e, _, st in pair:
+                    e.join(st.cuda_stream)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -139,7 +139,7 @@ int lpvmpc_last_error_code(void);
  * "defer_pool" (entries, 0 = max(64, B / 8), default): capacity of each of the two pools; instances that find the pool full
  * are not parked (they finish inside the launch that holds them).
  * "defer_tail" (0 | 1, default 1): the passes that run parked instances to completion (lpvmpc_join, the synchronous entry
- * points, "defer_budget" 0) use the whole-CU tail kernel where one exists for the handle (controller, N = 20): a 512-thread
+ * points, "defer_budget" 0) use the whole-CU tail kernel where one exists for the handle (controller or planner, N = 20): a 512-thread
  * workgroup per instance that applies K^-1 as a dense matrix held in registers, 1.65x faster per iteration for an instance that
  * has the GPU to itself.  Statuses, iteration counts and polish flags equal the other kernel's; solutions agree to round-off
  * (1e-7 polished, 1e-6 for an un-polished iterate; observed 1.4e-8 / 7e-10 over 196 608 instances), so bit-identity with the plain call holds with 0 only. */

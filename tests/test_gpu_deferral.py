@@ -312,3 +312,26 @@ def test_deferred_call_on_the_null_stream_then_another_stream():
     for _, o in keep:
         _same(_host(o), ref)
     eng.close()
+
+
+def test_tail_kernel_for_the_planner_at_n20():
+    """The planner at N = 20 (configs[3]'s planner half: mean 640 iterations, a fifth at max_iter) has the same 168 unknowns:
+    its parked instances are finished by the tail kernel too.  Against the plain launch: statuses, iteration counts and polish
+    flags equal; solutions as close as two kernels get on this nearly-LP problem (polished 1e-7; an un-polished iterate after up to
+    4000 iterations 1e-5, the tolerance of the kernel-variant cross-check)."""
+    import torch
+    from lpvmpc import workloads
+    B = 1024
+    w = workloads.planner_batch(B, N=20, seed=2)
+    plain = workloads.make_solver(w); plain.reserve(B)
+    _, o = _dev_call(torch, plain, w, B, True); torch.cuda.synchronize(); ref = _host(o); plain.close()
+    assert np.sum(ref["iters"] > 300) > 100 and ref["iters"].max() == 4000
+    eng = workloads.make_solver(w); eng.reserve(B)
+    eng.set_option("defer_after", 300); eng.set_option("defer_budget", -1); eng.set_option("defer_pool", 1024)
+    _, o = _dev_call(torch, eng, w, B, True)
+    eng.join(0); torch.cuda.synchronize()
+    got = _host(o)
+    ne = np.nonzero((got["status"] != ref["status"]) | (got["iters"] != ref["iters"]) | (got["polish"] != ref["polish"]))[0]
+    print("planner N=20 tail: %d parked, %d decisions differ" % (int((ref["iters"] > 300).sum()), len(ne)), got["status"][ne][:8], ref["status"][ne][:8], got["iters"][ne][:8], ref["iters"][ne][:8])
+    _close_to(got, ref, tol_polished=1e-7, tol_iterate=1e-5)
+    eng.close()
