@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from lpvmpc import _ffi
-_ffi.LIB_PATH = os.path.join(os.path.dirname(_ffi.LIB_PATH), "liblpvmpc_stamps.so")
+_ffi.LIB_PATH = os.path.join(os.path.dirname(_ffi.LIB_PATH), os.environ.get("LPVMPC_STAMPS_LIB", "liblpvmpc_stamps.so"))
 from lpvmpc import workloads
 for B in (256, 1024):
     w = workloads.controller_batch(B, N=20, seed=0)
