@@ -50,6 +50,7 @@ struct Solver {
     static constexpr bool kFixN = (NT > 0);         // horizon known at compile time
     static constexpr bool kReg = kFixN && !TAIL;    // factor tiles in registers
     static constexpr bool kTwo = (NW == 2);         // two wavefronts per instance: two-sided ("twisted") elimination
+    static constexpr bool kRing = !TAIL && NT == 20 && NW == 2;     // may park into the long-runner ring: the kernels whose image the tail kernel continues
     static constexpr bool kMf = MF;                 // the two sweeps run on the matrix cores (v_mfma_f64_4x4x4_4b_f64), see mf_forward
     static_assert(!MF || (NW == 2 && NT > 0), "the MFMA sweeps are written for the two-wavefront compile-time-horizon kernels");
     static_assert(TAIL || NW == 1 || (NW == 2 && NT >= 16 && NT % 2 == 0), "two wavefronts need an even compile-time horizon >= 16");
@@ -180,10 +181,10 @@ struct Solver {
         tlane = 8 * dgroup(lj) + li;
     }
     // the part of the LDS block that a pool entry carries (try_park / restore): everything up to and including SINK
-    static __host__ __device__ size_t image_doubles(int N) {
+    static constexpr __host__ __device__ size_t image_doubles(int N) {
         return (size_t)(N + 1) * ((kFixN ? 1 : 3) * kTS + (GS ? 16 : 19) * 8 + 8) + 16 + 64 + 8 + 80 + 64;
     }
-    static __host__ __device__ size_t lds_doubles(int N) {
+    static constexpr __host__ __device__ size_t lds_doubles(int N) {
         return image_doubles(N) + (TAIL ? (size_t)(N + 1) * (2 * kTS + kDenseRound * 64) + 96 + NW * 128 : 0);
     }
 
@@ -1500,22 +1501,59 @@ struct Solver {
     struct Outs { double *xPred, *uPred; int32_t *status, *iters, *polish; double *resid, *state; };
     __device__ __forceinline__ Outs outs_of(const SolveArgs &a, int entry) const {
         if (entry < 0) return Outs{a.xPred, a.uPred, a.status, a.iters, a.polish, a.resid, a.state};
-        const unsigned long long *pw = reinterpret_cast<const unsigned long long *>(a.pool_in + (size_t)entry * a.pool_stride + image_doubles(N) + 8);
-        auto word = [&](int i) {
-            const unsigned long long v = pw[i];
+        auto uni = [](unsigned long long v) {        // (uniform: scalar registers)
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
             return ((unsigned long long)hi << 32) | lo;
         };
-        return Outs{(double *)word(0), (double *)word(1), (int32_t *)word(2), (int32_t *)word(3), (int32_t *)word(4), (double *)word(5), (double *)word(6)};
+        if constexpr (TAIL) {
+            // a ring entry is released as soon as it has been restored: its output pointers were copied to RT[64..70] (restore).
+            // (two separate paths: a pointer that may be LDS or global becomes a flat access, and RT lies beyond the first 64 KB)
+            if (a.ring_drain) {
+                const unsigned long long *pl = reinterpret_cast<const unsigned long long *>(RT + 64);
+                return Outs{(double *)uni(pl[0]), (double *)uni(pl[1]), (int32_t *)uni(pl[2]), (int32_t *)uni(pl[3]), (int32_t *)uni(pl[4]), (double *)uni(pl[5]), (double *)uni(pl[6])};
+            }
+        }
+        const unsigned long long *pw = reinterpret_cast<const unsigned long long *>(a.pool_in + (size_t)entry * a.pool_stride + image_doubles(N) + 8);
+        return Outs{(double *)uni(pw[0]), (double *)uni(pw[1]), (int32_t *)uni(pw[2]), (int32_t *)uni(pw[3]), (int32_t *)uni(pw[4]), (double *)uni(pw[5]), (double *)uni(pw[6])};
     }
-    __device__ __forceinline__ bool try_park(const SolveArgs &a, int entry, int inst, int iter, int to_chk, int to_adp) {
-        if (tid == 0) RED[79] = (double)atomicAdd(a.pool_count, 1);
-        sync();
-        const int slot = (int)RED[79];
-        sync();
-        if (slot >= a.pool_cap) return false;                    // pool full: this instance simply goes on here
+    __device__ __forceinline__ bool try_park(const SolveArgs &a, int entry, int inst, int iter, int to_chk, int to_adp, bool long_runner) {
+        // long-runner lane: an instance that has come this far -- and, where the launch asks for it, whose residuals of the last two
+        // termination checks predict many more iterations (long_runner) -- goes to the lane's ring when a slot is free (the drain
+        // launch on the lane's reserved CUs finishes it with the tail kernel); otherwise, and below promote_after, into the pool
+        int ring_slot = -1;
+        if constexpr (kRing) {
+            if (a.ring != nullptr && iter >= a.promote_after && long_runner) {
+                if (wv == 0) {      // one load per lane and a ballot instead of a serial walk (a device-scope round trip per slot)
+                    int s_ = -1;
+                    for (int base = 0; base < a.ring_cap && s_ < 0; base += 64) {
+                        const int idx = base + lane;
+                        const int st = idx < a.ring_cap ? __hip_atomic_load(a.ring_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
+                        unsigned long long free_ = __ballot(st == 0);
+                        while (free_ != 0 && s_ < 0) {
+                            const int c_ = __ffsll((long long)free_) - 1;
+                            free_ &= free_ - 1;
+                            int got = 0;
+                            if (lane == 0) got = atomicCAS(a.ring_state + base + c_, 0, 1) == 0 ? 1 : 0;
+                            if (__builtin_amdgcn_readfirstlane(got)) s_ = base + c_;
+                        }
+                    }
+                    if (lane == 0) RED[79] = (double)s_;
+                }
+                sync();
+                ring_slot = (int)RED[79];
+                sync();
+            }
+        }
+        int slot = 0;
+        if (ring_slot < 0) {
+            if (tid == 0) RED[79] = (double)atomicAdd(a.pool_count, 1);
+            sync();
+            slot = (int)RED[79];
+            sync();
+            if (slot >= a.pool_cap) return false;                    // pool full: this instance simply goes on here
+        }
         const int n = (int)image_doubles(N);
-        double *dst = a.pool + (size_t)slot * a.pool_stride;
+        double *dst = ring_slot >= 0 ? a.ring + (size_t)ring_slot * a.pool_stride : a.pool + (size_t)slot * a.pool_stride;
         for (int i = tid; i < n; i += kStride) dst[i] = tA[i];          // tA is the base of the LDS block
         if (tid == 0) {
             double *sc = dst + n;
@@ -1525,8 +1563,14 @@ struct Solver {
             pw[0] = (unsigned long long)o.xPred; pw[1] = (unsigned long long)o.uPred; pw[2] = (unsigned long long)o.status;
             pw[3] = (unsigned long long)o.iters; pw[4] = (unsigned long long)o.polish; pw[5] = (unsigned long long)o.resid;
             pw[6] = (unsigned long long)o.state;
+            pw[7] = a.cfg_word;                        // the handle's configuration block (the lane's ring is shared by handles)
             if (o.status) o.status[inst] = LPVMPC_PENDING_;
             if (o.iters) o.iters[inst] = iter;
+        }
+        if (ring_slot >= 0) {      // publish: every thread's stores are visible device-wide before the entry reads "ready"
+            __threadfence();
+            sync();
+            if (tid == 0) { atomicExch(a.ring_state + ring_slot, kCtrl ? 2 : 4); atomicAdd(a.ring_state + a.ring_cap, 1); }      // (ready, by model; the word behind the states counts the promotions)
         }
         return true;
     }
@@ -1541,6 +1585,15 @@ struct Solver {
         iter = (int)sc[3]; to_chk = (int)sc[4]; to_adp = (int)sc[5];
         const int inst = __builtin_amdgcn_readfirstlane((int)sc[6]);
         pol = false;
+        if constexpr (TAIL) {
+            if (a.ring_drain) {     // everything the entry holds is on chip now (output pointers: RT[64..70]): the slot is free again
+                if (tid < 7) reinterpret_cast<unsigned long long *>(RT + 64)[tid] = reinterpret_cast<const unsigned long long *>(sc + 8)[tid];
+                __threadfence();
+                sync();
+                if (tid == 0) atomicExch(a.ring_state + entry, 0);
+                return inst;
+            }
+        }
         sync();
         return inst;
     }
@@ -1683,7 +1736,23 @@ struct Solver {
                 }
                 recompute_w();              // the residual evaluation used ZT* as scratch (and rho may have changed)
                 // straggler deferral: unsolved at this check and past the budget -> park and end the workgroup (block-uniform)
-                if (checked && defer_after > 0 && iter >= defer_after && iter < max_iter && try_park(a, entry, inst, iter, to_chk, to_adp)) return;
+                bool long_runner = true;
+                if constexpr (kRing) {
+                    // progress of this instance for the lane's promotion rule: m = how far the worse residual is above its tolerance, kept
+                    // in a spare word of the image (beq[14]) from one termination check to the next; two checks 25 iterations apart give the
+                    // rate, m -> 1 the iterations still to go.  Scheduling only: no result depends on it.
+                    if (checked && a.ring != nullptr && a.promote_remaining > 0) {
+                        const double m_now = fmax(R.pri / (cfg.eps_abs + cfg.eps_rel * R.nAxz), R.dua / (cfg.eps_abs + cfg.eps_rel * R.nPAq));
+                        const double m_prev = beq[14];
+                        sync();
+                        if (tid == 0) beq[14] = m_now;
+                        if (m_prev > m_now && m_now > 1.0) {
+                            const float rem = (float)chk_every * __log2f((float)m_now) / __log2f((float)(m_prev / m_now));
+                            long_runner = rem >= (float)a.promote_remaining;
+                        } else long_runner = m_prev > 0.0 && m_now > 1.0;       // no progress between the two checks (or the first check: unknown)
+                    }
+                }
+                if (checked && defer_after > 0 && iter >= defer_after && iter < max_iter && try_park(a, entry, inst, iter, to_chk, to_adp, long_runner)) return;
             }
         }
         if (iter > max_iter) iter = max_iter;
@@ -1917,6 +1986,97 @@ static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveA
         word.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL((admm_solve_kernel<NX, NT, NW, MF, GS, TAIL>), dim3(a.resume ? a.pool_cap : a.B), dim3(64 * NW), lds, stream, dcfg, a);
+    return hipGetLastError();
+}
+
+// Drain launch of the long-runner lane: the tail kernel on the lane's ring (entries of every handle attached to the lane; an
+// entry names its handle's configuration block).  Every workgroup claims a ready entry OF ITS KIND (ring state 2: controller,
+// 4: planner -- one kernel per model, each with its own register allocation), runs it to completion and looks again.
+// A workgroup that finds nothing ready stays -- polling, on a CU that is reserved for this launch anyway -- for as long as an
+// entry is being written or a sibling is still busy, so that an entry promoted while one long instance keeps the launch alive is
+// picked up at once instead of waiting for the next drain launch behind it in the stream; it ends when nothing of its kind is
+// ready, nothing is being written and no sibling holds an entry (entries are finite and every claim is released: the grid
+// drains).  Words behind the states: [cap] promotions so far (diagnostic), [cap + 1] workgroups that hold an entry.
+// one claimed entry, restored and run to completion: a function of its own (not inlined into the claim loop), so that the solver
+// gets the register allocation of the stand-alone tail kernel instead of sharing it with the loop around it
+#ifdef LPVMPC_LANE_INLINE
+#define LPVMPC_DRAIN_ATTR __forceinline__
+#else
+#define LPVMPC_DRAIN_ATTR __noinline__
+#endif
+template <int NX>
+__device__ LPVMPC_DRAIN_ATTR void ring_drain_entry(const SolveArgs &a, int entry) {
+    extern __shared__ __align__(16) double smem[];
+    using Tail = Solver<NX, 20, 8, false, false, true>;
+    constexpr int kImg = (int)Tail::image_doubles(20);
+    const unsigned long long cw = reinterpret_cast<const unsigned long long *>(a.ring + (size_t)entry * a.pool_stride + kImg + 8)[7];
+    const unsigned cw_lo = __builtin_amdgcn_readfirstlane((unsigned)cw), cw_hi = __builtin_amdgcn_readfirstlane((unsigned)(cw >> 32));      // (uniform: scalar registers)
+    const DevCfg *cfgp = reinterpret_cast<const DevCfg *>(((unsigned long long)cw_hi << 32) | cw_lo);
+    Tail s(*cfgp, smem);
+    s.run(a, 0, entry);
+}
+
+template <int NX>
+__global__ void __launch_bounds__(512, 2) ring_drain_kernel(SolveArgs a) {
+    extern __shared__ __align__(16) double smem[];
+    constexpr int kReady = NX == 6 ? 2 : 4;
+    int32_t *const busy = a.ring_state + a.ring_cap + 1;
+    // The loop is uniform over the workgroup: wavefront 0 makes ONE pass over the ring per trip and publishes the outcome -- an entry,
+    // -1 (leave) or -2 (nothing yet, look again) -- and every wavefront takes the same branch behind the barrier.  (A polling loop
+    // inside the `threadIdx.x == 0` branch is not an option: the compiler turned that shape into a barrier inside a divergent
+    // loop, the other lanes of wavefront 0 ran ahead of lane 0 and read the slot before it was written -- found with rocgdb.)
+    for (;;) {
+        int &claimed = *reinterpret_cast<int *>(smem);
+        if (threadIdx.x < 64) {     // wavefront 0: one load per lane and a ballot per 64 slots
+            const int ln = threadIdx.x;
+            int s_ = -1;
+            bool pending = false;
+            for (int base = 0; base < a.ring_cap && s_ < 0; base += 64) {
+                const int idx = base + ln;
+                const int st = idx < a.ring_cap ? __hip_atomic_load(a.ring_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                unsigned long long ready = __ballot(st == kReady);
+                pending |= __ballot(st == 1 || st == kReady) != 0;
+                while (ready != 0 && s_ < 0) {
+                    const int c_ = __ffsll((long long)ready) - 1;
+                    ready &= ready - 1;
+                    int got = 0;
+                    if (ln == 0) got = atomicCAS(a.ring_state + base + c_, kReady, 3) == kReady ? 1 : 0;
+                    if (__builtin_amdgcn_readfirstlane(got)) s_ = base + c_;
+                }
+            }
+            if (ln == 0) {
+                if (s_ >= 0) { atomicAdd(busy, 1); __threadfence(); }
+                else if (pending || __hip_atomic_load(busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_ = -2;
+                claimed = s_;
+            }
+        }
+        __syncthreads();
+        const int entry = claimed;
+        __syncthreads();              // every wavefront has read the slot before restore() stores the image over it
+        if (entry == -1) return;
+        if (entry == -2) { __builtin_amdgcn_s_sleep(127); continue; }
+        ring_drain_entry<NX>(a, entry);
+        __syncthreads();
+        if (threadIdx.x == 0) { __threadfence(); atomicSub(busy, 1); }
+    }
+}
+
+hipError_t launch_ring_drain(int kind, const SolveArgs &a, int workgroups, hipStream_t stream) {
+    if (!a.ring || !a.ring_drain || a.pool_in != a.ring || workgroups < 1) return hipErrorInvalidValue;
+    const size_t lds = Solver<6, 20, 8, false, false, true>::lds_doubles(20) * sizeof(double);       // (the same for NX = 5)
+    static std::atomic<uint64_t> attr_mask[2][4];
+    int dev = 0;
+    { hipError_t err = hipGetDevice(&dev); if (err != hipSuccess) return err; }
+    const uint64_t bit = 1ull << (dev & 63);
+    std::atomic<uint64_t> &word = attr_mask[kind == 0 ? 0 : 1][(dev >> 6) & 3];
+    if (!(word.load(std::memory_order_acquire) & bit)) {
+        hipError_t err = kind == 0 ? hipFuncSetAttribute((const void *)ring_drain_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                                   : hipFuncSetAttribute((const void *)ring_drain_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (err != hipSuccess) return err;
+        word.fetch_or(bit, std::memory_order_release);
+    }
+    if (kind == 0) hipLaunchKernelGGL(ring_drain_kernel<6>, dim3(workgroups), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL(ring_drain_kernel<5>, dim3(workgroups), dim3(512), lds, stream, a);
     return hipGetLastError();
 }
 

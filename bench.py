@@ -65,6 +65,16 @@ def main():
                          "long as its slowest instance); default: 100 for the headline workload, 0 otherwise")
     ap.add_argument("--defer-budget", type=int, default=100, help="iterations per resume pass of the straggler deferral (0 = to completion)")
     ap.add_argument("--defer-pool", type=int, default=0, help="entries of each of the two pools of parked instances (0 = max(64, B / 8))")
+    ap.add_argument("--lane-cus", type=int, default=-1,
+                    help="long-runner lane (lpvmpc_lane_create): CUs taken out of the step streams' CU masks and reserved for the whole-CU tail "
+                         "kernel, which finishes there -- beside the step launches -- the stragglers that are still unsolved after "
+                         "--promote-after iterations; a multiple of 8; 0 = no lane (stragglers wait for the closing passes); default: 8 for the "
+                         "headline workload with deferral, else 0")
+    ap.add_argument("--promote-after", type=int, default=200, help="iterations after which a parked instance is promoted to the lane's ring")
+    ap.add_argument("--promote-remaining", type=int, default=400,
+                    help="promote only the instances whose residuals at the last two termination checks predict at least this many more "
+                         "iterations (0 = everything that is still unsolved after --promote-after)")
+    ap.add_argument("--lane-ring", type=int, default=64, help="entries of the lane's ring (a full ring leaves an instance with the bounded passes)")
     ap.add_argument("--fleet-groups", type=int, default=4, help="cfg5: independent sub-fleets (engine pairs) the vehicles are cut into")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs outside the timed region (serial steps, batch latencies, one launch of all distinct "
@@ -82,6 +92,8 @@ def main():
         args.defer = 100 if args.workload == "cfg2" else 0
     if args.streams <= 0:
         args.streams = 4 if args.defer > 0 else 64          # with deferral no launch is long: a few streams fill the GPU
+    if args.lane_cus < 0:
+        args.lane_cus = 8 if (args.workload == "cfg2" and args.defer > 0) else 0
 
     # --gpus N given to a plain `python bench.py`: become the launcher.  Nothing has touched the GPU yet (torch is not
     # even imported), the children are fresh processes (never an exec of a process that initialised HIP).
@@ -141,7 +153,15 @@ def main():
         e.set_option("defer_pool", args.defer_pool)
         e.set_option("defer_after", args.defer)
         e.set_option("defer_budget", args.defer_budget)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    lane = None
+    if args.lane_cus > 0 and args.defer > 0 and not planner:
+        # the step streams are the lane's (masked to the CUs it did not reserve); every engine gets a ring on the lane
+        lane = lpvmpc.Lane(device=local_rank, reserved_cus=args.lane_cus, step_streams=S, ring_entries=args.lane_ring)
+        streams = [RawStream(p) for p in lane.step_streams]
+        for e in engines:
+            e.attach_lane(lane, promote_after=args.promote_after, promote_remaining=args.promote_remaining)
+    else:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
 
     def new_outs(n):
         return dict(xPred=torch.empty((n, N + 1, nx), dtype=torch.float64, device=dev),
@@ -349,7 +369,12 @@ def main():
                                          "oval, racing tuning, OSQP defaults + polish, cold start" % B) if not planner else
                                         ("configs[2]: batch=%d LPV-MPP planner solves per GPU (velocity-max cost), N=30, "
                                          "L-shape track, OSQP defaults + polish, cold start" % B),
-                            "batch_per_gpu": B, "horizon": N, "nx": nx, "nu": 2, "streams": S, "defer_after": args.defer,
+                            "batch_per_gpu": B, "horizon": N, "nx": nx, "nu": 2, "streams": S, "defer_after": args.defer, "defer_budget": args.defer_budget,
+                            "lane": ({"reserved_cus": args.lane_cus, "promote_after": args.promote_after, "promote_remaining": args.promote_remaining,
+                                      "ring_entries": args.lane_ring, "drain_launches": sum(e.lane_drain_count() for e in engines),
+                                      "promoted_instances": lane.promoted_count(),
+                                      "note": "step streams masked to the other CUs (hipExtStreamCreateWithCUMask); promoted stragglers are "
+                                              "finished on the reserved CUs by the whole-CU tail kernel while the steps go on"} if lane else None),
                             "distinct_batches_timed": len(used), "batch_seeds": "step j solves batch j mod %d = seed %d + (j mod %d) + 1000 rank" % (NBAT, 1 if planner else 0, NBAT),
                             "mean_admm_iters": agg[0] / total,
                             "max_admm_iters_rank0": int(max(it_slot[i].max() for i in used)),
@@ -391,7 +416,15 @@ def main():
 
     for e in engines:
         e.close()
+    if lane is not None:
+        lane.close()
     finish(world)
+
+
+class RawStream:
+    """A HIP stream that is not torch's (the lane's CU-masked streams): only its handle is needed here."""
+    def __init__(self, ptr):
+        self.cuda_stream = ptr
 
 
 def finish(world):

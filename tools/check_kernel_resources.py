@@ -67,12 +67,18 @@ def kernels(path):
 
 if __name__ == "__main__":
     path, args = sys.argv[1], sys.argv[2:]
-    allow, pats, hot_lanes_max = {}, [], None
+    allow, pats, hot_lanes_max, hot_allow, hot_scratch = {}, [], None, {}, {}
     while args:
         a = args.pop(0)
         if a == "--allow":
             name, _, lim = args.pop(0).partition("=")
             allow[name] = int(lim)
+        elif a == "--hot-lane-allow":           # name-substring=count: a kernel outside the benchmarked set that may carry more lane moves
+            name, _, lim = args.pop(0).partition("=")
+            hot_allow[name] = int(lim)
+        elif a == "--hot-scratch-allow":        # name-substring=count: scratch RELOADS tolerated between the markers (loop-invariant values)
+            name, _, lim = args.pop(0).partition("=")
+            hot_scratch[name] = int(lim)
         elif a == "--hot-lane-moves":           # largest number of SGPR-spill lane moves tolerated between the hot-path markers
             hot_lanes_max = int(args.pop(0))
         else:
@@ -90,7 +96,8 @@ if __name__ == "__main__":
         bad += flag
         h = hot.get(k["name"])
         if h and h["instructions"]:
-            hflag = h["scratch"] > 0 or (hot_lanes_max is not None and h["spill_lane_moves"] > hot_lanes_max)
+            lanes_max = max([v for n, v in hot_allow.items() if n in k["name"]] or [hot_lanes_max if hot_lanes_max is not None else 1 << 30])
+            hflag = h["scratch"] > max([v for n, v in hot_scratch.items() if n in k["name"]] or [0]) or h["spill_lane_moves"] > lanes_max
             print("      per-iteration code (between the markers): %d instructions, %d scratch accesses, %d SGPR-spill lane moves%s"
                   % (h["instructions"], h["scratch"], h["spill_lane_moves"], "  <-- FAIL" if hflag else ""))
             bad += hflag
