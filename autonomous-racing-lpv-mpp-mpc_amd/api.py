@@ -58,6 +58,17 @@ class Lane:
     def promoted_count(self):
         return int(self._lib.lpvmpc_lane_promoted_count(self._l))
 
+    def trace(self, max_records=1024):
+        """Records of the entries the drain launches finished: columns parked_at, restored_at, finished_at (seconds on the device's
+        100 MHz clock), iterations at the hand-over, final iteration count."""
+        out = np.zeros((int(max_records), 5))
+        n = int(self._lib.lpvmpc_lane_trace(self._l, ptr(out), int(max_records)))
+        if n < 0:
+            raise LpvMpcError(n, "lpvmpc_lane_trace failed")
+        out = out[:n].copy()
+        out[:, :3] *= 1e-8
+        return out
+
     def close(self):
         """Destroy the lane (after the solvers attached to it have been closed or detached)."""
         if getattr(self, "_l", None):
@@ -158,10 +169,11 @@ class BatchedSolver:
         outputs of the deferred calls are complete for work enqueued on ``stream`` afterwards."""
         self._chk(self._lib.lpvmpc_join(self._h, C.c_void_p(int(stream))))
 
-    def attach_lane(self, lane, promote_after=200, promote_remaining=0):
+    def attach_lane(self, lane, promote_after=200, promote_remaining=0, promote_hard=0):
         """Attach to (``lane=None``: detach from) a long-runner :class:`Lane`; needs the straggler deferral ("defer_after").
-        ``promote_remaining`` > 0 promotes only the instances predicted to need at least that many more iterations."""
-        self._chk(self._lib.lpvmpc_lane_attach(self._h, lane._l if lane is not None else None, int(promote_after), int(promote_remaining)))
+        ``promote_remaining`` > 0 promotes only the instances predicted to need at least that many more iterations,
+        ``promote_hard`` > 0 everything that reaches that many iterations."""
+        self._chk(self._lib.lpvmpc_lane_attach(self._h, lane._l if lane is not None else None, int(promote_after), int(promote_remaining), int(promote_hard)))
 
     def lane_drain_count(self):
         return int(self._lib.lpvmpc_lane_drain_count(self._h))
@@ -338,6 +350,14 @@ class BatchedSolver:
                                                 ptr(o["lap"]), ptr(o["lap_tick"]), ptr(o.get("refs")), ptr(o.get("plan_xPred")),
                                                 ptr(o["plan_iters"]), ptr(o["plan_status"]), ptr(o["ticks"])))
         return o
+
+    def cascade_alive_ticks(self):
+        """Controller ticks each vehicle of the cascade has entered with a finite plant state ([B] int32)."""
+        if self._cas is None:
+            raise LpvMpcError(_ffi.E_ARG, "cascade_alive_ticks: call cascade_init first")
+        out = np.empty(self._cas[0], np.int32)
+        self._chk(self._lib.lpvmpc_cascade_alive_ticks(self._h, ptr(out)))
+        return out
 
     # -- device-pointer entry point (torch tensors or raw integers) -----------------------------------
     def solve_dev(self, B, x0, u_prev, vel_ref, curv_s, u_old, max_ey, xPred, uPred, status=None, iters=None,

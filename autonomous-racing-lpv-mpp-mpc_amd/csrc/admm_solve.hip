@@ -184,6 +184,8 @@ struct Solver {
     static constexpr __host__ __device__ size_t image_doubles(int N) {
         return (size_t)(N + 1) * ((kFixN ? 1 : 3) * kTS + (GS ? 16 : 19) * 8 + 8) + 16 + 64 + 8 + 80 + 64;
     }
+    // offset (doubles) of the tail kernel's RT area in the LDS block (ring_drain_kernel reads the trace words an entry leaves there)
+    static constexpr __host__ __device__ size_t rt_offset(int N) { return image_doubles(N) + (size_t)(N + 1) * 2 * kTS; }
     static constexpr __host__ __device__ size_t lds_doubles(int N) {
         return image_doubles(N) + (TAIL ? (size_t)(N + 1) * (2 * kTS + kDenseRound * 64) + 96 + NW * 128 : 0);
     }
@@ -1522,7 +1524,7 @@ struct Solver {
         // launch on the lane's reserved CUs finishes it with the tail kernel); otherwise, and below promote_after, into the pool
         int ring_slot = -1;
         if constexpr (kRing) {
-            if (a.ring != nullptr && iter >= a.promote_after && long_runner) {
+            if (a.ring != nullptr && iter >= a.promote_after && (long_runner || (a.promote_hard > 0 && iter >= a.promote_hard))) {
                 if (wv == 0) {      // one load per lane and a ballot instead of a serial walk (a device-scope round trip per slot)
                     int s_ = -1;
                     for (int base = 0; base < a.ring_cap && s_ < 0; base += 64) {
@@ -1558,6 +1560,7 @@ struct Solver {
         if (tid == 0) {
             double *sc = dst + n;
             sc[0] = c; sc[1] = cinv; sc[2] = rho; sc[3] = (double)iter; sc[4] = (double)to_chk; sc[5] = (double)to_adp; sc[6] = (double)inst;
+            sc[7] = (double)__builtin_amdgcn_s_memrealtime();      // when it was parked (100 MHz device clock): the lane's trace
             const Outs o = outs_of(a, entry);
             unsigned long long *pw = reinterpret_cast<unsigned long long *>(sc + 8);
             pw[0] = (unsigned long long)o.xPred; pw[1] = (unsigned long long)o.uPred; pw[2] = (unsigned long long)o.status;
@@ -1588,6 +1591,7 @@ struct Solver {
         if constexpr (TAIL) {
             if (a.ring_drain) {     // everything the entry holds is on chip now (output pointers: RT[64..70]): the slot is free again
                 if (tid < 7) reinterpret_cast<unsigned long long *>(RT + 64)[tid] = reinterpret_cast<const unsigned long long *>(sc + 8)[tid];
+                if (tid == 7) { RT[72] = sc[3]; RT[74] = sc[7]; RT[75] = (double)__builtin_amdgcn_s_memrealtime(); }      // trace: iterations so far, promoted at, restored at
                 __threadfence();
                 sync();
                 if (tid == 0) atomicExch(a.ring_state + entry, 0);
@@ -1809,6 +1813,7 @@ struct Solver {
             return;
         }
 #endif
+        if constexpr (TAIL) { if (tid == 0 && a.ring_drain) RT[73] = (double)iter; }
         if (tid == 0) {
             if (o_.status) o_.status[inst] = status;
             if (o_.iters) o_.iters[inst] = iter;
@@ -1992,21 +1997,29 @@ static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveA
 // Drain launch of the long-runner lane: the tail kernel on the lane's ring (entries of every handle attached to the lane; an
 // entry names its handle's configuration block).  Every workgroup claims a ready entry OF ITS KIND (ring state 2: controller,
 // 4: planner -- one kernel per model, each with its own register allocation), runs it to completion and looks again.
-// A workgroup that finds nothing ready stays -- polling, on a CU that is reserved for this launch anyway -- for as long as an
-// entry is being written or a sibling is still busy, so that an entry promoted while one long instance keeps the launch alive is
-// picked up at once instead of waiting for the next drain launch behind it in the stream; it ends when nothing of its kind is
-// ready, nothing is being written and no sibling holds an entry (entries are finite and every claim is released: the grid
-// drains).  Words behind the states: [cap] promotions so far (diagnostic), [cap + 1] workgroups that hold an entry.
+// The launch is LONG-LIVED: a workgroup that finds nothing ready stays -- polling every few microseconds, on a CU that is
+// reserved for it anyway -- so that an entry promoted at any time during a burst of calls is picked up at once, with no launch,
+// event or barrier packet per call.  It ends when nothing is ready, being written or being worked on AND either the host has
+// asked for it (lpvmpc_join writes the stop word behind the handle's last pass) or every deferred call enqueued so far has
+// completed on the device (the host counts enqueued calls in a word of mapped host memory, a one-thread kernel behind each
+// call's last launch counts completed ones: while they differ, work that may promote is still in flight -- also when the host
+// enqueued a whole burst in a millisecond and went to wait); a bound on the polling trips (~0.5 s) is the safety net.
+// Words behind the states: [cap] promotions so far (diagnostic), [cap + 1] workgroups that hold an entry, [cap + 2] stop,
+// [cap + 3] trace records, [cap + 4] completed calls.
+constexpr int kDrainIdleTrips = 100000;     // ~0.5 s of polling trips (a sleep of ~3.4 us and one pass over the ring each): the safety net, never the normal way out
 // one claimed entry, restored and run to completion: a function of its own (not inlined into the claim loop), so that the solver
 // gets the register allocation of the stand-alone tail kernel instead of sharing it with the loop around it
-#ifdef LPVMPC_LANE_INLINE
-#define LPVMPC_DRAIN_ATTR __forceinline__
-#else
+#ifdef LPVMPC_LANE_NOINLINE
 #define LPVMPC_DRAIN_ATTR __noinline__
+#else
+#define LPVMPC_DRAIN_ATTR __forceinline__     // (out of line, the LDS base is a run-time value: the update phase alone costs 800 cycles more per iteration)
 #endif
+// (the LDS block arrives as an LDS-typed pointer: a function that names the kernel's dynamic LDS itself looks its base up in a
+// table -- a scalar load and a wait in front of every phase of the iteration)
+typedef __attribute__((address_space(3))) double lds_double;
 template <int NX>
-__device__ LPVMPC_DRAIN_ATTR void ring_drain_entry(const SolveArgs &a, int entry) {
-    extern __shared__ __align__(16) double smem[];
+__device__ LPVMPC_DRAIN_ATTR void ring_drain_entry(const SolveArgs &a, int entry, lds_double *lds) {
+    double *const smem = (double *)lds;
     using Tail = Solver<NX, 20, 8, false, false, true>;
     constexpr int kImg = (int)Tail::image_doubles(20);
     const unsigned long long cw = reinterpret_cast<const unsigned long long *>(a.ring + (size_t)entry * a.pool_stride + kImg + 8)[7];
@@ -2020,7 +2033,8 @@ template <int NX>
 __global__ void __launch_bounds__(512, 2) ring_drain_kernel(SolveArgs a) {
     extern __shared__ __align__(16) double smem[];
     constexpr int kReady = NX == 6 ? 2 : 4;
-    int32_t *const busy = a.ring_state + a.ring_cap + 1;
+    int32_t *const busy = a.ring_state + a.ring_cap + 1, *const stop = a.ring_state + a.ring_cap + 2, *const calls_done = a.ring_state + a.ring_cap + 4;
+    int idle_trips = 0;         // polling trips since this workgroup last saw work anywhere in the launch (uniform: a scalar register)
     // The loop is uniform over the workgroup: wavefront 0 makes ONE pass over the ring per trip and publishes the outcome -- an entry,
     // -1 (leave) or -2 (nothing yet, look again) -- and every wavefront takes the same branch behind the barrier.  (A polling loop
     // inside the `threadIdx.x == 0` branch is not an option: the compiler turned that shape into a barrier inside a divergent
@@ -2046,7 +2060,16 @@ __global__ void __launch_bounds__(512, 2) ring_drain_kernel(SolveArgs a) {
             }
             if (ln == 0) {
                 if (s_ >= 0) { atomicAdd(busy, 1); __threadfence(); }
-                else if (pending || __hip_atomic_load(busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_ = -2;
+                else {
+                    const bool work = pending || __hip_atomic_load(busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    // nothing to do here: leave when the host asks for it (lpvmpc_join), or when every deferred call the host has enqueued
+                    // so far (a word in host memory, written at enqueue time) has completed on the device (counted behind its last launch)
+                    // -- nothing can be promoted any more until the next call, which finds the tail stream idle and launches a drain again
+                    const bool asked = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    const bool quiet = a.calls_enqueued == nullptr ||
+                                       __hip_atomic_load(a.calls_enqueued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == __hip_atomic_load(calls_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_ = work ? -3 : ((asked || quiet || idle_trips > kDrainIdleTrips) ? -1 : -2);       // -3: look again, the launch is busy
+                }
                 claimed = s_;
             }
         }
@@ -2054,11 +2077,25 @@ __global__ void __launch_bounds__(512, 2) ring_drain_kernel(SolveArgs a) {
         const int entry = claimed;
         __syncthreads();              // every wavefront has read the slot before restore() stores the image over it
         if (entry == -1) return;
-        if (entry == -2) { __builtin_amdgcn_s_sleep(127); continue; }
-        ring_drain_entry<NX>(a, entry);
+        if (entry < 0) { idle_trips = entry == -2 ? idle_trips + 1 : 0; __builtin_amdgcn_s_sleep(127); continue; }
+        idle_trips = 0;
+        ring_drain_entry<NX>(a, entry, (lds_double *)smem);
         __syncthreads();
-        if (threadIdx.x == 0) { __threadfence(); atomicSub(busy, 1); }
+        if (threadIdx.x == 0) {
+            if (a.trace != nullptr && a.trace_cap > 0) {      // {parked at, restored at, finished at} (100 MHz ticks), iterations at the hand-over, final count
+                const double *rt = smem + Solver<NX, 20, 8, false, false, true>::rt_offset(20);
+                double *rec = a.trace + 5 * (size_t)(atomicAdd(a.ring_state + a.ring_cap + 3, 1) % a.trace_cap);
+                rec[0] = rt[74]; rec[1] = rt[75]; rec[2] = (double)__builtin_amdgcn_s_memrealtime(); rec[3] = rt[72]; rec[4] = rt[73];
+            }
+            __threadfence(); atomicSub(busy, 1);
+        }
     }
+}
+
+__global__ void lane_call_done_kernel(int32_t *calls_done) { atomicAdd(calls_done, 1); }
+hipError_t launch_lane_call_done(int32_t *calls_done, hipStream_t stream) {
+    hipLaunchKernelGGL(lane_call_done_kernel, dim3(1), dim3(1), 0, stream, calls_done);
+    return hipGetLastError();
 }
 
 hipError_t launch_ring_drain(int kind, const SolveArgs &a, int workgroups, hipStream_t stream) {

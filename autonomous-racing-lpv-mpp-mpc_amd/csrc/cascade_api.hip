@@ -16,6 +16,7 @@ struct lpvmpc_cascade {
     double hw, slack, dt_sim, mu_sim;
     double *plant, *cmd, *local, *ref0, *SSc;       // [B][8], [B][2], [B][6], [B][3], [B]
     int32_t *lap, *lap_tick;                        // [B]
+    int32_t *alive_ticks;                           // [B] controller ticks entered with a finite plant state
     double *refs, *sig, *SSp, *pose, *px0;          // planner side: [2][B][5][M] (message j in buffer j % 2), [B][5][Np], [B][Np+1], [B][3], [B][5]
     hipStream_t s_ctrl, s_plan;                     // the two nodes run on their own streams
     hipEvent_t ev_plan;                             // planner tick done (planner stream) -> controller stream waits
@@ -109,7 +110,7 @@ extern "C" int lpvmpc_handoff_batch(lpvmpc_handle *h, int32_t B, const double *x
 void lpvmpc_cascade_free(lpvmpc_handle *h) {
     lpvmpc_cascade *c = h->cascade;
     if (!c) return;
-    void *ptrs[] = {c->plant, c->cmd, c->local, c->ref0, c->SSc, c->lap, c->lap_tick, c->refs, c->sig, c->SSp, c->pose, c->px0};
+    void *ptrs[] = {c->plant, c->cmd, c->local, c->ref0, c->SSc, c->lap, c->lap_tick, c->alive_ticks, c->refs, c->sig, c->SSp, c->pose, c->px0};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->ev_ctrl) (void)hipEventDestroy(c->ev_ctrl);
@@ -148,7 +149,7 @@ extern "C" int lpvmpc_cascade_init(lpvmpc_handle *h, lpvmpc_handle *plan, int32_
     const size_t b = B, N = h->cfg.N, Np = plan->cfg.N, M = c->M;
 #define ALLOC(p, n) HIP_TRY(h, hipMalloc((void **)&(p), (n)))
     ALLOC(c->plant, b * 8 * 8); ALLOC(c->cmd, b * 2 * 8); ALLOC(c->local, b * 6 * 8); ALLOC(c->ref0, b * 3 * 8); ALLOC(c->SSc, b * 8);
-    ALLOC(c->lap, b * 4); ALLOC(c->lap_tick, b * 4);
+    ALLOC(c->lap, b * 4); ALLOC(c->lap_tick, b * 4); ALLOC(c->alive_ticks, b * 4);
     ALLOC(c->refs, 2 * b * 5 * M * 8); ALLOC(c->sig, b * 5 * Np * 8); ALLOC(c->SSp, b * (Np + 1) * 8); ALLOC(c->pose, b * 3 * 8); ALLOC(c->px0, b * 5 * 8);
 #undef ALLOC
     HIP_TRY(h, hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
@@ -160,6 +161,7 @@ extern "C" int lpvmpc_cascade_init(lpvmpc_handle *h, lpvmpc_handle *plan, int32_
     std::vector<int32_t> laps(b, lap0);
     H2D(c->lap, laps.data(), b * 4);
     HIP_TRY(h, hipMemsetAsync(c->lap_tick, 0, b * 4, st));
+    HIP_TRY(h, hipMemsetAsync(c->alive_ticks, 0, b * 4, st));
     HIP_TRY(h, hipMemsetAsync(c->SSc, 0, b * 8, st));                            // SS = 0 at the lap event (CMAIN:258,271)
     HIP_TRY(h, hipMemsetAsync(c->SSp, 0, b * (Np + 1) * 8, st));                 // planner: SS = 0, Xlast = Ylast = Thetalast = 0 (PMAIN:72-74,124)
     HIP_TRY(h, hipMemsetAsync(c->pose, 0, b * 3 * 8, st));
@@ -218,7 +220,7 @@ extern "C" int lpvmpc_cascade_tick(lpvmpc_handle *h, int32_t n_ticks) {
         const int latch = c->index == 0;
         c->index = c->index == 0 ? 1 : 0;
         HIP_TRY(h, lpvmpc::launch_tt_measure(h->d_cfg, B, c->M, k, c->plant, c->cmd, refs, latch, h->d_vel, h->d_curv, c->ref0, c->lap,
-                                             c->lap_tick, c->SSc, c->local, h->d_uold, st));
+                                             c->lap_tick, c->SSc, c->local, h->d_uold, c->alive_ticks, st));
         HIP_TRY(h, hipEventRecord(c->ev_ctrl, st));
         if (c->prefetch && first_reader) {                                       // message j has its first reader: every reader of j - 1 is enqueued,
             HIP_TRY(h, hipStreamWaitEvent(sp, c->ev_ctrl, 0));                   // so planner tick j + 1 may overwrite that buffer and run beside
@@ -261,5 +263,15 @@ extern "C" int lpvmpc_cascade_read(lpvmpc_handle *h, double *plant, double *loca
     if (plan_status) D2H(plan_status, p->d_status, B * 4);
     HIP_TRY(h, hipStreamSynchronize(st));
     if (ticks) { ticks[0] = c->ctrl_ticks; ticks[1] = c->plan_ticks; }
+    return LPVMPC_OK;
+}
+
+extern "C" int lpvmpc_cascade_alive_ticks(lpvmpc_handle *h, int32_t *alive_ticks) {
+    if (!h || !h->cascade || !alive_ticks) return fail(h, LPVMPC_E_ARG, "lpvmpc_cascade_alive_ticks: call lpvmpc_cascade_init first");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    lpvmpc_cascade *c = h->cascade;
+    HIP_TRY(h, hipStreamSynchronize(c->s_plan));
+    HIP_TRY(h, hipStreamSynchronize(c->s_ctrl));
+    HIP_TRY(h, hipMemcpy(alive_ticks, c->alive_ticks, (size_t)c->B * 4, hipMemcpyDeviceToHost));
     return LPVMPC_OK;
 }

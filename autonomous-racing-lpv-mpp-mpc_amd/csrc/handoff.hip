@@ -229,12 +229,17 @@ __global__ void __launch_bounds__(64) tt_measure_kernel(const DevCfg *__restrict
                                                         const double *__restrict__ cmd, const double *__restrict__ refs, int latch,
                                                         double *__restrict__ vel, double *__restrict__ curv, double *__restrict__ ref0,
                                                         int32_t *__restrict__ lap, int32_t *__restrict__ lap_tick, double *__restrict__ SS,
-                                                        double *__restrict__ local_state, double *__restrict__ u_old) {
+                                                        double *__restrict__ local_state, double *__restrict__ u_old, int32_t *__restrict__ alive_ticks) {
     const DevCfg &c = *cp;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int N = c.N;
     const double *p = plant + (size_t)b * 8;
+    if (alive_ticks) {      // controller ticks this vehicle has entered with a finite plant state (a lost vehicle carries NaN and costs nothing)
+        bool fin = true;
+        for (int i = 0; i < 8; ++i) fin = fin && __builtin_isfinite(p[i]);
+        if (fin) alive_ticks[b] += 1;
+    }
     if (latch) {
         const double *r = refs + (size_t)b * 5 * M;
         for (int i = 0; i < N; ++i) { vel[(size_t)b * (N + 1) + i] = r[3 * M + i]; curv[(size_t)b * N + i] = r[4 * M + i]; }
@@ -272,9 +277,9 @@ hipError_t launch_plan_first(const DevCfg *dcfg, int B, const double *plant, dou
 }
 hipError_t launch_tt_measure(const DevCfg *dcfg, int B, int M, int tick, const double *plant, const double *cmd, const double *refs, int latch,
                              double *vel, double *curv, double *ref0, int32_t *lap, int32_t *lap_tick, double *SS, double *local_state,
-                             double *u_old, hipStream_t s) {
+                             double *u_old, int32_t *alive_ticks, hipStream_t s) {
     hipLaunchKernelGGL(tt_measure_kernel, LPVMPC_GRID(B), 0, s, dcfg, B, M, tick, plant, cmd, refs, latch, vel, curv, ref0, lap, lap_tick, SS,
-                       local_state, u_old);
+                       local_state, u_old, alive_ticks);
     return hipGetLastError();
 }
 

@@ -70,6 +70,7 @@ static void free_ws(lpvmpc_handle *h) {
     h->cap = 0;
 }
 
+static const int kLaneTrace = 1024;      // records of finished ring entries kept per lane (lpvmpc_lane_trace)
 static const int kEventRing = 1024;      // event pairs kept by lpvmpc_set_timing (main launches, and separately resume passes)
 extern "C" int lpvmpc_join(lpvmpc_handle *h, void *stream);
 // ---- straggler deferral: the two pools ---------------------------------------------------------------------------------
@@ -108,31 +109,52 @@ static bool lane_active(const lpvmpc_handle *h) { return h->lane && h->force_gen
 static void ring_args(const lpvmpc_handle *h, SolveArgs &a) {
     if (!lane_active(h)) return;
     a.ring = h->lane->ring; a.ring_state = h->lane->ring_state; a.ring_cap = h->lane->ring_cap; a.promote_after = h->promote_after;
-    a.cfg_word = (unsigned long long)h->d_cfg; a.promote_remaining = h->promote_remaining;
+    a.cfg_word = (unsigned long long)h->d_cfg; a.promote_remaining = h->promote_remaining; a.promote_hard = h->promote_hard;
 }
-// drain launch on the lane's tail stream, ordered behind everything enqueued on `st` so far
-static int lane_drain(lpvmpc_handle *h, hipStream_t st) {
-    lpvmpc_lane *ln = h->lane;
-    if (!lane_active(h)) return LPVMPC_OK;
-    std::lock_guard<std::mutex> g(ln->mu);
-    HIP_TRY(h, hipEventRecord(h->lane_event, st));
-    HIP_TRY(h, hipStreamWaitEvent(ln->tail, h->lane_event, 0));
+static int drain_launch(lpvmpc_handle *h, lpvmpc_lane *ln) {
     SolveArgs a{};
     a.resume = 1; a.tail = 1; a.defer_after = 0; a.x0_stride = h->nx;
     a.pool_in = ln->ring; a.pool_stride = ln->stride; a.pool_cap = ln->ring_cap;
     a.ring = ln->ring; a.ring_state = ln->ring_state; a.ring_cap = ln->ring_cap; a.ring_drain = 1;
-    a.cfg_word = (unsigned long long)h->d_cfg;       // (diagnostic builds compare it with the entries' own)
+    a.trace = ln->trace; a.trace_cap = kLaneTrace; a.calls_enqueued = ln->d_enq;
     HIP_TRY(h, lpvmpc::launch_ring_drain(h->cfg.kind, a, ln->reserved, ln->tail));
-    h->lane_used = true; h->lane_drains++;
+    h->lane_drains++;
     return LPVMPC_OK;
 }
-// the caller's stream waits for the drain launches enqueued so far (lpvmpc_join)
+// Behind a deferred call: make sure a long-lived drain launch of this handle's model is on the lane's tail stream.  It polls the
+// ring, so nothing orders it behind the call (entries are published with device-scope fences); the first call of a burst
+// launches it; it leaves when lpvmpc_join asks for it or when every enqueued call has completed and the ring is empty.  (One launch, event and barrier packet per call -- the first design -- cost 50 us each
+// on the one tail stream and piled up behind the burst.)
+static int lane_drain(lpvmpc_handle *h, hipStream_t st) {
+    lpvmpc_lane *ln = h->lane;
+    if (!lane_active(h)) return LPVMPC_OK;
+    (void)st;
+    std::lock_guard<std::mutex> g(ln->mu);
+    const int k = h->cfg.kind == LPVMPC_KIND_CONTROLLER ? 0 : 1;
+    // a drain leaves when every call enqueued so far has completed: an idle tail stream means none is alive
+    const bool idle = hipStreamQuery(ln->tail) == hipSuccess;
+    if (idle) ln->drain_active[0] = ln->drain_active[1] = false;
+    if (!ln->drain_active[0] && !ln->drain_active[1]) HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(ln->ring_state + ln->ring_cap + 2), 0, 1, ln->tail));    // new burst: clear the stop word (behind the last drain)
+    if (!ln->drain_active[k]) {
+        int rc = drain_launch(h, ln); if (rc) return rc;
+        ln->drain_active[k] = true;
+    }
+    h->lane_used = true;
+    return LPVMPC_OK;
+}
+// lpvmpc_join: behind the handle's last pass on `st` the long-lived drain is asked to stop, one more drain launch -- ordered
+// behind `st` -- takes whatever the ring still holds (also when the long-lived one has given up meanwhile), and `st` waits for it
 static int lane_join(lpvmpc_handle *h, hipStream_t st) {
     lpvmpc_lane *ln = h->lane;
     if (!ln || !h->lane_used) return LPVMPC_OK;
     std::lock_guard<std::mutex> g(ln->mu);
+    HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(ln->ring_state + ln->ring_cap + 2), 1, 1, st));
+    HIP_TRY(h, hipEventRecord(h->lane_event, st));
+    HIP_TRY(h, hipStreamWaitEvent(ln->tail, h->lane_event, 0));
+    int rc = drain_launch(h, ln); if (rc) return rc;
     HIP_TRY(h, hipEventRecord(ln->tail_ev, ln->tail));
     HIP_TRY(h, hipStreamWaitEvent(st, ln->tail_ev, 0));
+    ln->drain_active[0] = ln->drain_active[1] = false;
     h->lane_used = false;
     return LPVMPC_OK;
 }
@@ -198,7 +220,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->defer_after = 0; h->defer_budget = 200; h->defer_cap = 0; h->defer_cur_cap = 0; h->defer_stride = 0; h->rv_count = 0;
     h->dpool[0] = h->dpool[1] = nullptr; h->dcount[0] = h->dcount[1] = nullptr; h->dcur = 0; h->defer_stream = nullptr; h->defer_event = nullptr;
     h->defer_stream_set = false; h->defer_tail = 1; h->defer_skip_pass = false;
-    h->lane = nullptr; h->promote_after = 0; h->promote_remaining = 0; h->lane_event = nullptr; h->lane_used = false; h->lane_drains = 0;
+    h->lane = nullptr; h->promote_after = 0; h->promote_remaining = 0; h->promote_hard = 0; h->lane_event = nullptr; h->lane_used = false; h->lane_drains = 0;
     h->h_pack_in = h->h_pack_out = h->d_pack_in = h->d_pack_out = nullptr;
     DevCfg &d = h->dev;
     std::memset(&d, 0, sizeof(d));
@@ -564,6 +586,8 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
         // defer_budget more iterations.  No launch lasts much longer than its budget, so the stream is never held by one slow
         // instance; lpvmpc_join runs the pass that finishes whatever is still parked.
         rc = ensure_defer(h, B, st); if (rc) return rc;
+        const bool laned = lane_active(h) && !h->defer_skip_pass;
+        if (laned) { std::lock_guard<std::mutex> g(h->lane->mu); __atomic_add_fetch(h->lane->h_enq, 1, __ATOMIC_SEQ_CST); }      // (before the call's first launch: a drain never sees "all done" while this call is on its way)
         if (h->defer_stream_set && h->defer_stream != st) {        // the pools are ordered by stream: hand them over
             HIP_TRY(h, hipEventRecord(h->defer_event, h->defer_stream));
             HIP_TRY(h, hipStreamWaitEvent(st, h->defer_event, 0));
@@ -571,13 +595,16 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
         h->defer_stream = st; h->defer_stream_set = true;
         a.defer_after = h->defer_after; a.resume = 0; a.pool = h->dpool[h->dcur]; a.pool_count = h->dcount[h->dcur];
         a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride;
-        if (h->lane && !h->defer_skip_pass && h->promote_after <= ((h->defer_after + 24) / 25) * 25) ring_args(h, a);     // (promotion straight from the call's own launch)
+        if (laned && h->promote_after <= ((h->defer_after + 24) / 25) * 25) ring_args(h, a);     // (promotion straight from the call's own launch)
         rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
         // the bounded pass behind the call -- unless the caller joins right away (budget -1, and the synchronous host-array entry
         // point): then the closing pass (the tail kernel) takes the parked instances straight from this launch
         if (h->defer_budget >= 0 && !h->defer_skip_pass) { rc = resume_pass(h, h->defer_budget, st); if (rc) return rc; }
         // long-runner lane: whatever this call's launches promoted is finished on the lane's reserved CUs, beside the step streams
-        if (h->lane && !h->defer_skip_pass) { rc = lane_drain(h, st); if (rc) return rc; }
+        if (laned) {
+            HIP_TRY(h, lpvmpc::launch_lane_call_done(h->lane->ring_state + h->lane->ring_cap + 4, st));
+            rc = lane_drain(h, st); if (rc) return rc;
+        }
     } else {
         rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
     }
@@ -669,8 +696,9 @@ extern "C" lpvmpc_lane *lpvmpc_lane_create(int32_t device, int32_t reserved_cus,
     if (hipSetDevice(device) != hipSuccess) { fail(nullptr, LPVMPC_E_HIP, "hipSetDevice(%d) failed", device); return nullptr; }
     lpvmpc_lane *ln = new (std::nothrow) lpvmpc_lane();
     if (!ln) { fail(nullptr, LPVMPC_E_NOMEM, "out of host memory"); return nullptr; }
-    ln->device = device; ln->reserved = reserved_cus; ln->tail = nullptr; ln->tail_ev = nullptr; ln->ring = nullptr; ln->ring_state = nullptr;
+    ln->device = device; ln->reserved = reserved_cus; ln->tail = nullptr; ln->tail_ev = nullptr; ln->ring = nullptr; ln->ring_state = nullptr; ln->trace = nullptr; ln->h_enq = nullptr; ln->d_enq = nullptr;
     ln->ring_cap = ring_entries; ln->stride = entry_stride_for(20);
+    ln->drain_active[0] = ln->drain_active[1] = false;
     const int words = (ncu + 31) / 32;
     std::vector<uint32_t> mres(words, 0), mcomp(words, 0);
     for (int i = 0; i < ncu; ++i) (i < reserved_cus ? mres : mcomp)[i / 32] |= 1u << (i % 32);
@@ -680,7 +708,10 @@ extern "C" lpvmpc_lane *lpvmpc_lane_create(int32_t device, int32_t reserved_cus,
         ok = hipExtStreamCreateWithCUMask(&s, words, mcomp.data()) == hipSuccess;
         if (s) ln->step.push_back(s);
     }
+    ok = ok && hipHostMalloc((void **)&ln->h_enq, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void **)&ln->d_enq, ln->h_enq, 0) == hipSuccess;
+    if (ok) *ln->h_enq = 0;
     ok = ok && hipMalloc((void **)&ln->ring, (size_t)ring_entries * ln->stride * 8) == hipSuccess
+            && hipMalloc((void **)&ln->trace, (size_t)kLaneTrace * 5 * 8) == hipSuccess && hipMemset(ln->trace, 0, (size_t)kLaneTrace * 5 * 8) == hipSuccess
             && hipMalloc((void **)&ln->ring_state, (size_t)(ring_entries + 2) * 4 + 256) == hipSuccess         // (+ room for the diagnostic words of LPVMPC_LANE_DEBUG builds)
             && hipMemset(ln->ring_state, 0, (size_t)(ring_entries + 2) * 4 + 256) == hipSuccess;
     if (!ok) { fail(nullptr, LPVMPC_E_HIP, "lpvmpc_lane_create: creating the CU-masked streams / the ring failed: %s", hipGetErrorString(hipGetLastError())); lpvmpc_lane_destroy(ln); return nullptr; }
@@ -690,12 +721,15 @@ extern "C" lpvmpc_lane *lpvmpc_lane_create(int32_t device, int32_t reserved_cus,
 extern "C" void lpvmpc_lane_destroy(lpvmpc_lane *ln) {
     if (!ln) return;
     (void)hipSetDevice(ln->device);
+    if (ln->ring_state) { const int32_t one = 1; (void)hipMemcpy(ln->ring_state + ln->ring_cap + 2, &one, 4, hipMemcpyHostToDevice); }     // a drain that is still polling leaves
     (void)hipDeviceSynchronize();
     if (ln->tail) (void)hipStreamDestroy(ln->tail);
     for (hipStream_t s : ln->step) (void)hipStreamDestroy(s);
     if (ln->tail_ev) (void)hipEventDestroy(ln->tail_ev);
     if (ln->ring) (void)hipFree(ln->ring);
     if (ln->ring_state) (void)hipFree(ln->ring_state);
+    if (ln->trace) (void)hipFree(ln->trace);
+    if (ln->h_enq) (void)hipHostFree(ln->h_enq);
     delete ln;
 }
 
@@ -703,7 +737,7 @@ extern "C" void *lpvmpc_lane_step_stream(lpvmpc_lane *ln, int32_t i) {
     return (ln && i >= 0 && (size_t)i < ln->step.size()) ? (void *)ln->step[i] : nullptr;
 }
 
-extern "C" int lpvmpc_lane_attach(lpvmpc_handle *h, lpvmpc_lane *ln, int32_t promote_after, int32_t promote_remaining) {
+extern "C" int lpvmpc_lane_attach(lpvmpc_handle *h, lpvmpc_lane *ln, int32_t promote_after, int32_t promote_remaining, int32_t promote_hard) {
     if (!h) return fail(nullptr, LPVMPC_E_ARG, "lpvmpc_lane_attach: handle is NULL");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     // whatever is parked or promoted under the old attachment is finished first
@@ -715,9 +749,9 @@ extern "C" int lpvmpc_lane_attach(lpvmpc_handle *h, lpvmpc_lane *ln, int32_t pro
     if (!ln) { h->lane = nullptr; return LPVMPC_OK; }
     if (ln->device != h->cfg.device) return fail(h, LPVMPC_E_ARG, "lpvmpc_lane_attach: the lane belongs to device %d, the handle to device %d", ln->device, h->cfg.device);
     if (h->cfg.N != 20) return fail(h, LPVMPC_E_ARG, "lpvmpc_lane_attach: the tail kernel that drains a lane exists for N = 20 (controller and planner); this handle has N = %d", h->cfg.N);
-    if (promote_after < 25 || promote_remaining < 0) return fail(h, LPVMPC_E_ARG, "lpvmpc_lane_attach: promote_after >= 25 (iterations), promote_remaining >= 0");
+    if (promote_after < 25 || promote_remaining < 0 || promote_hard < 0) return fail(h, LPVMPC_E_ARG, "lpvmpc_lane_attach: promote_after >= 25 (iterations), promote_remaining >= 0, promote_hard >= 0");
     if (!h->lane_event) HIP_TRY(h, hipEventCreateWithFlags(&h->lane_event, hipEventDisableTiming));
-    h->lane = ln; h->promote_after = promote_after; h->promote_remaining = promote_remaining; h->lane_used = false;
+    h->lane = ln; h->promote_after = promote_after; h->promote_remaining = promote_remaining; h->promote_hard = promote_hard; h->lane_used = false;
     return LPVMPC_OK;
 }
 
@@ -726,6 +760,14 @@ extern "C" int lpvmpc_lane_debug_words(lpvmpc_lane *ln, unsigned long long *out2
     if (!ln || !out20) return LPVMPC_E_ARG;
     if (hipSetDevice(ln->device) != hipSuccess || hipMemcpy(out20, ln->ring_state + ln->ring_cap + 2, 160, hipMemcpyDeviceToHost) != hipSuccess) return LPVMPC_E_HIP;
     return LPVMPC_OK;
+}
+extern "C" int lpvmpc_lane_trace(lpvmpc_lane *ln, double *records, int32_t max_records) {
+    if (!ln || !records || max_records < 0) return LPVMPC_E_ARG;
+    int32_t n = 0;
+    if (hipSetDevice(ln->device) != hipSuccess || hipMemcpy(&n, ln->ring_state + ln->ring_cap + 3, 4, hipMemcpyDeviceToHost) != hipSuccess) return LPVMPC_E_HIP;
+    const int m = n < kLaneTrace ? n : kLaneTrace, k = m < max_records ? m : max_records;
+    if (k > 0 && hipMemcpy(records, ln->trace, (size_t)k * 5 * 8, hipMemcpyDeviceToHost) != hipSuccess) return LPVMPC_E_HIP;
+    return k;
 }
 extern "C" int lpvmpc_lane_promoted_count(lpvmpc_lane *ln) {
     if (!ln) return 0;

@@ -91,6 +91,10 @@ struct SolveArgs {
     int32_t *ring_state;
     int ring_cap, promote_after, ring_drain;
     int promote_remaining;           // > 0: promote only what the residuals of the last two checks predict to need at least that many more iterations
+    int promote_hard;                // > 0: at this many iterations an instance is promoted whatever the prediction says
+    const int32_t *calls_enqueued;   // drain launches: deferred calls the host has enqueued so far (mapped host memory), or null
+    double *trace;                   // drain launches: [trace_cap][5] records of the entries they finished (lpvmpc_lane_trace), or null
+    int trace_cap;
     unsigned long long cfg_word;     // the launching handle's device configuration block (recorded in the entries it parks)
 };
 constexpr int kParkScalars = 16;     // behind the LDS image of a pool entry: c, cinv, rho, iter, to_chk, to_adp, instance index and the
@@ -103,6 +107,7 @@ size_t solve_lds_bytes(int kind, int N);
 hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream, int force_generic);
 // drain launch of the long-runner lane (tail kernel over the lane's ring; controller / planner entries at N = 20): `workgroups` = the lane's reserved CUs
 hipError_t launch_ring_drain(int kind, const SolveArgs &a, int workgroups, hipStream_t stream);
+hipError_t launch_lane_call_done(int32_t *calls_done, hipStream_t stream);      // behind a deferred call's last launch: one more call has completed
 hipError_t launch_lpv(const DevCfg &cfg, const DevCfg *dcfg, int B, const double *x0, const double *u_prev, const double *vel_ref,
                       const double *curv_s, double cf_new, int lap, double *states, double *AB, hipStream_t stream);
 hipError_t launch_abc(const DevCfg &cfg, const DevCfg *dcfg, int B, const double *xlast, const double *delta, double *AB, hipStream_t stream);
@@ -129,6 +134,6 @@ hipError_t launch_plan_first(const DevCfg *dcfg, int B, const double *plant, dou
                              double *x0, double *xlast, double *delta, hipStream_t s);
 hipError_t launch_tt_measure(const DevCfg *dcfg, int B, int M, int tick, const double *plant, const double *cmd, const double *refs, int latch,
                              double *vel, double *curv, double *ref0, int32_t *lap, int32_t *lap_tick, double *SS, double *local_state,
-                             double *u_old, hipStream_t s);
+                             double *u_old, int32_t *alive_ticks, hipStream_t s);
 
 }  // namespace lpvmpc

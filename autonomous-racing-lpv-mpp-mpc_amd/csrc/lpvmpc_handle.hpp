@@ -29,6 +29,9 @@ struct lpvmpc_lane {
     double *ring;                             // [ring_cap][stride]: promoted stragglers of every attached handle
     int32_t *ring_state;                      // [ring_cap] 0 free, 1 being written, 2 / 4 ready (controller / planner), 3 taken; [cap] promotions, [cap + 1] busy workgroups
     int ring_cap, stride;
+    int32_t *h_enq, *d_enq;                   // deferred calls enqueued so far by the attached handles: a word of mapped host memory and its device address
+    double *trace;                            // [kLaneTrace][5]: the entries the drain launches finished (diagnostic, cyclic)
+    bool drain_active[2];                     // a long-lived drain launch (controller / planner kernel) has been put on the tail stream since the last join
     std::mutex mu;                            // handles of one lane may be driven from different threads
 };
 
@@ -84,7 +87,7 @@ struct lpvmpc_handle {
     int rv_count;
     // long-runner lane (lpvmpc_lane_attach): launches of this handle promote into the lane's ring
     lpvmpc_lane *lane;
-    int promote_after, promote_remaining;
+    int promote_after, promote_remaining, promote_hard;
     hipEvent_t lane_event;              // orders a drain launch behind the pass that may have filled the ring
     bool lane_used;                     // drain launches of this handle since its last join
     int lane_drains;                    // drain launches so far (diagnostic)

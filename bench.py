@@ -68,12 +68,13 @@ def main():
     ap.add_argument("--lane-cus", type=int, default=-1,
                     help="long-runner lane (lpvmpc_lane_create): CUs taken out of the step streams' CU masks and reserved for the whole-CU tail "
                          "kernel, which finishes there -- beside the step launches -- the stragglers that are still unsolved after "
-                         "--promote-after iterations; a multiple of 8; 0 = no lane (stragglers wait for the closing passes); default: 8 for the "
-                         "headline workload with deferral, else 0")
+                         "--promote-after iterations; a multiple of 8; 0 = no lane (stragglers wait for the closing passes; the default: a 1024-instance "
+                         "batch is exactly one residency of the 256 CUs, so every reserved CU turns each step into a two-wave launch)")
     ap.add_argument("--promote-after", type=int, default=200, help="iterations after which a parked instance is promoted to the lane's ring")
     ap.add_argument("--promote-remaining", type=int, default=400,
                     help="promote only the instances whose residuals at the last two termination checks predict at least this many more "
                          "iterations (0 = everything that is still unsolved after --promote-after)")
+    ap.add_argument("--promote-hard", type=int, default=300, help="iterations from which an instance is promoted whatever the prediction says (0 = none)")
     ap.add_argument("--lane-ring", type=int, default=64, help="entries of the lane's ring (a full ring leaves an instance with the bounded passes)")
     ap.add_argument("--fleet-groups", type=int, default=4, help="cfg5: independent sub-fleets (engine pairs) the vehicles are cut into")
     ap.add_argument("--no-extras", action="store_true",
@@ -93,7 +94,7 @@ def main():
     if args.streams <= 0:
         args.streams = 4 if args.defer > 0 else 64          # with deferral no launch is long: a few streams fill the GPU
     if args.lane_cus < 0:
-        args.lane_cus = 8 if (args.workload == "cfg2" and args.defer > 0) else 0
+        args.lane_cus = 0          # measured (profiles/r04_lane_ab.txt): taking CUs from the step launches costs this workload more than the early tail start gains
 
     # --gpus N given to a plain `python bench.py`: become the launcher.  Nothing has touched the GPU yet (torch is not
     # even imported), the children are fresh processes (never an exec of a process that initialised HIP).
@@ -159,7 +160,7 @@ def main():
         lane = lpvmpc.Lane(device=local_rank, reserved_cus=args.lane_cus, step_streams=S, ring_entries=args.lane_ring)
         streams = [RawStream(p) for p in lane.step_streams]
         for e in engines:
-            e.attach_lane(lane, promote_after=args.promote_after, promote_remaining=args.promote_remaining)
+            e.attach_lane(lane, promote_after=args.promote_after, promote_remaining=args.promote_remaining, promote_hard=args.promote_hard)
     else:
         streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
 
@@ -370,9 +371,9 @@ def main():
                                         ("configs[2]: batch=%d LPV-MPP planner solves per GPU (velocity-max cost), N=30, "
                                          "L-shape track, OSQP defaults + polish, cold start" % B),
                             "batch_per_gpu": B, "horizon": N, "nx": nx, "nu": 2, "streams": S, "defer_after": args.defer, "defer_budget": args.defer_budget,
-                            "lane": ({"reserved_cus": args.lane_cus, "promote_after": args.promote_after, "promote_remaining": args.promote_remaining,
+                            "lane": ({"reserved_cus": args.lane_cus, "promote_after": args.promote_after, "promote_remaining": args.promote_remaining, "promote_hard": args.promote_hard,
                                       "ring_entries": args.lane_ring, "drain_launches": sum(e.lane_drain_count() for e in engines),
-                                      "promoted_instances": lane.promoted_count(),
+                                      "promoted_instances": lane.promoted_count(), "trace": lane_trace_summary(lane),
                                       "note": "step streams masked to the other CUs (hipExtStreamCreateWithCUMask); promoted stragglers are "
                                               "finished on the reserved CUs by the whole-CU tail kernel while the steps go on"} if lane else None),
                             "distinct_batches_timed": len(used), "batch_seeds": "step j solves batch j mod %d = seed %d + (j mod %d) + 1000 rank" % (NBAT, 1 if planner else 0, NBAT),
@@ -419,6 +420,23 @@ def main():
     if lane is not None:
         lane.close()
     finish(world)
+
+
+def lane_trace_summary(lane):
+    """What the lane's drain launches did with the promoted instances (lpvmpc_lane_trace): how long an entry waited for a reserved
+    CU and the five longest ones (times in ms; `at` = parked, relative to the first record's parking)."""
+    import numpy as np
+    tr = lane.trace()
+    if len(tr) == 0:
+        return None
+    wait = (tr[:, 1] - tr[:, 0]) * 1e3
+    run = (tr[:, 2] - tr[:, 1]) * 1e3
+    t0 = tr[:, 0].min()
+    top = np.argsort(-tr[:, 4])[:5]
+    return {"records": int(len(tr)), "wait_ms_p50": float(np.median(wait)), "wait_ms_max": float(wait.max()),
+            "cu_ms_total": float(run.sum()),
+            "longest": [{"at": round(float((tr[i, 0] - t0) * 1e3), 3), "from_iter": int(tr[i, 3]), "iters": int(tr[i, 4]), "wait_ms": round(float(wait[i]), 3),
+                         "run_ms": round(float(run[i]), 3), "us_per_iter": round(float(run[i] * 1e3 / max(tr[i, 4] - tr[i, 3], 1)), 3)} for i in top]}
 
 
 class RawStream:

@@ -176,12 +176,18 @@ void *lpvmpc_lane_step_stream(lpvmpc_lane *lane, int32_t i);
  * residuals at the last two termination checks -- the rate at which the worse of primal / dual residual over tolerance falls
  * -- predict at least that many more iterations; the others stay with the bounded passes, which serve the many
  * few-hundred-iteration instances at four per CU where the tail kernel gives each a whole CU.  A scheduling rule: no result
- * depends on it.  lane = NULL detaches.  Finishes whatever the handle has parked first. */
-int lpvmpc_lane_attach(lpvmpc_handle *h, lpvmpc_lane *lane, int32_t promote_after, int32_t promote_remaining);
+ * depends on it.  promote_hard (iterations, 0 = none): from here on an instance is promoted whatever the prediction says (the
+ * residuals of the instances that run to max_iter do not fall steadily: the prediction misses some of them).  lane = NULL
+ * detaches.  Finishes whatever the handle has parked first. */
+int lpvmpc_lane_attach(lpvmpc_handle *h, lpvmpc_lane *lane, int32_t promote_after, int32_t promote_remaining, int32_t promote_hard);
 /* drain launches of this handle so far (diagnostic). */
 int lpvmpc_lane_drain_count(const lpvmpc_handle *h);
 /* instances promoted into the lane's ring so far (reads a device counter: synchronises with the device). */
 int lpvmpc_lane_promoted_count(lpvmpc_lane *lane);
+/* Diagnostic: the entries the lane's drain launches have finished so far (the first 1024), five doubles each -- parked at, restored
+ * on a reserved CU at, finished at (ticks of the device's 100 MHz clock), ADMM iterations at the hand-over, final iteration
+ * count.  Returns the number of records written (<= max_records) or a negative LPVMPC_E_* code; synchronises with the device. */
+int lpvmpc_lane_trace(lpvmpc_lane *lane, double *records, int32_t max_records);
 
 /* Pre-size the device workspace for batches up to B (otherwise grown on demand). */
 int lpvmpc_reserve(lpvmpc_handle *h, int32_t B);
@@ -360,6 +366,10 @@ int lpvmpc_cascade_tick(lpvmpc_handle *ctrl, int32_t n_ticks);
 int lpvmpc_cascade_read(lpvmpc_handle *ctrl, double *plant, double *local_state, double *cmd, int32_t *ctrl_iters,
                         int32_t *ctrl_status, int32_t *lap, int32_t *lap_tick, double *refs, double *plan_xPred,
                         int32_t *plan_iters, int32_t *plan_status, int32_t *ticks);
+/* alive_ticks [B]: controller ticks each vehicle has entered with a finite plant state since lpvmpc_cascade_init (a vehicle whose
+ * planner QP went primal infeasible carries NaN from then on and costs no iterations: the sum over the fleet is the number of
+ * vehicle-ticks that did work).  Synchronises like lpvmpc_cascade_read. */
+int lpvmpc_cascade_alive_ticks(lpvmpc_handle *ctrl, int32_t *alive_ticks);
 
 #ifdef __cplusplus
 }
