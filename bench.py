@@ -57,6 +57,12 @@ def main():
                          "planner, N=20; cfg5 = configs[4]: planner + controller + plant cascade, a step is one 30 Hz "
                          "controller tick of --batch vehicles per GPU (default 8192 / gpus) -- extra measurements, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="headline workload on N > 1 GPUs: weak = every rank runs --steps steps of its own batches (the default, what the "
+                         "driver's scaling run measures); strong = the --steps steps (batches j mod 32, the same seeds whatever N) are cut "
+                         "contiguously over the ranks with lpvmpc.distributed.shard_range, value = batch x steps / time")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short legs of configs[2], [3] and [4] that the one-GPU headline run appends under config.other_workloads")
     ap.add_argument("--defer", type=int, default=-1,
                     help="straggler deferral (lpvmpc_set_option defer_after): an instance still unsolved after this many ADMM "
                          "iterations is parked and continued, --defer-budget iterations at a time, by the resume pass that follows "
@@ -120,6 +126,9 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let --gpus spawn them)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # The CPU baseline (oracle port on the host cores, rank 0 only) runs BEFORE the process group exists: it needs no device, and
+    # the other ranks then wait for the rendezvous instead of spinning in an RCCL barrier beside sixteen busy host threads.
+    cpu = early_cpu_baseline(args, world) if (rank == 0 and not args.no_cpu_baseline) else None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -128,7 +137,15 @@ def main():
 
     if args.workload in ("cfg5", "cfg4"):
         try:
-            return (bench_cascade if args.workload == "cfg5" else bench_mixed)(args, rank, local_rank, world, dev)
+            out = (bench_cascade if args.workload == "cfg5" else bench_mixed)(args, rank, local_rank, world, dev)
+            if rank == 0:
+                if cpu is not None:
+                    out["cpu_baseline"] = cpu
+                out["config"].update(rank_info(world, local_rank, dev))
+                print(json.dumps(out), flush=True)
+            else:
+                rank_info(world, local_rank, dev)
+            return
         finally:
             finish(world)
     planner = args.workload == "cfg3"
@@ -143,7 +160,12 @@ def main():
     S = max(1, args.streams)
     NBAT = max(S, 32)                                   # distinct input batches (seeds) the steps cycle through
     make = workloads.planner_batch if planner else workloads.controller_batch
-    ws = [make(B, N=N, seed=(1 if planner else 0) + i + 1000 * rank) for i in range(NBAT)]
+    strong = args.scaling == "strong" and world > 1
+    # strong scaling: ONE sequence of steps (batch j mod 32, the seeds of the one-GPU run) cut contiguously over the ranks
+    from lpvmpc.distributed import shard_range
+    my_steps = list(range(*shard_range(args.steps, rank, world))) if strong else list(range(args.steps))
+    my_warm = list(range(*shard_range(args.warmup, rank, world))) if strong else list(range(args.warmup))
+    ws = [make(B, N=N, seed=(1 if planner else 0) + i + (0 if strong else 1000 * rank)) for i in range(NBAT)]
     w = ws[0]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     ins = [dict(x0=t(wi["x0"]), u_prev=t(wi["u_prev"]), curv=t(wi["curv_s"]), u_old=t(wi["u_old"]),
@@ -192,11 +214,13 @@ def main():
                              o["status"], o["iters"], o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"],
                              stream=streams[e].cuda_stream)
 
-    def step():
+    def step(jg=None):
+        """One step: batch jg mod NBAT (jg = the step's global index; default: this rank's running count) on the next engine."""
         j = counter[0]
         counter[0] += 1
-        solve_slot(j % NBAT, e=j % S, o=j % NOUT)
-        return j % NBAT
+        b = (j if jg is None else jg) % NBAT
+        solve_slot(b, e=j % S, o=j % NOUT)
+        return b
 
     def fence():
         if args.defer > 0:                       # finish what the straggler deferral still holds: part of the work being timed
@@ -219,13 +243,13 @@ def main():
     for i in range(S):
         solve_slot(i, 1)
     sync()
-    for _ in range(args.warmup):
-        step()
+    for j in my_warm:
+        step(j)
     for e in engines:
         e.set_timing(True)            # HIP events on the launch stream around every solve-kernel launch
     fence()
     t0 = time.perf_counter()
-    timed_slots = [step() for _ in range(args.steps)]
+    timed_slots = [step(args.warmup + j) for j in my_steps]      # (global index: the warm-up steps come first in the sequence)
     fence()
     elapsed = time.perf_counter() - t0
     k_ms = k_n = 0
@@ -283,6 +307,7 @@ def main():
         for i in range(NBAT):
             sync(); t1 = time.perf_counter(); solve_slot(i); sync()
             lat.append((time.perf_counter() - t1) * 1e3)
+        extras["latency_legs_defer_budget"] = -1 if args.defer > 0 else None      # (the timed region above runs with --defer-budget; these legs join after every batch)
         extras["p50_batch_latency_ms"] = float(np.median(lat))
         extras["max_batch_latency_ms"] = float(np.max(lat))
         l0 = []
@@ -341,6 +366,7 @@ def main():
     # the one collective of the path, after the timed region: first input, status and iteration count of every
     # instance of one batch per rank (B x 4 words per rank over RCCL)
     last = timed_slots[-1] if timed_slots else 0
+    info = rank_info(world, local_rank, dev)
     g_u0, g_status, g_iters = gather_results(u0_last, st_slot[last], it_slot[last], B * world, device=dev)
     assert g_u0.shape == (B * world, 2) and g_iters.shape == (B * world,)
     if rank == 0 and args.dump_results:
@@ -348,9 +374,9 @@ def main():
                  seeds=np.array([(1 if planner else 0) + last + 1000 * r for r in range(world)]))
 
     if rank == 0:
-        total = B * world * args.steps
+        total = B * args.steps * (1 if strong else world)
         k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
-        bytes_launch = main_bytes_timed / max(args.steps, 1)    # mean algorithmic bytes of a timed launch on the step's stream (rank 0)
+        bytes_launch = main_bytes_timed / max(len(my_steps), 1)    # mean algorithmic bytes of a timed launch on the step's stream (rank 0)
         achieved = bytes_launch / k_avg_s / 1e9 if k_n else float("nan")
         pmc = load_pmc(B, planner)
         out = {
@@ -362,7 +388,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -384,13 +410,17 @@ def main():
                             # this run where the extras ran: config.lone_instance_iteration_us; else the figures of DESIGN.md section 5)
                             "slowest_instance_floor_ms": slowest_floor_ms(int(max(it_slot[i].max() for i in used)), planner, args.defer, extras),
                             "timed_region_ms": elapsed * 1e3,
-                            "solved_fraction": agg[1] / total}, **extras),
+                            "solved_fraction": agg[1] / total}, **info, **extras),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc.get("traffic_bytes_per_launch"), "traffic_source": pmc.get("traffic_source") or pmc.get("source"),
                          "valu": pmc.get("valu"), "valu_source": pmc.get("source") if pmc.get("valu") else None,
                          # the same counters for the configuration that is timed here (main launches of the deferral mode)
                          "valu_timed": pmc.get("valu_timed"),
+                         # the contract bound is HBM; what limits the kernel in practice is vector-instruction issue: its state
+                         # lives in LDS and registers, the counter traffic is a hundredth of the algorithmic bytes
+                         "limiter": "valu_issue", "limiter_frac": (pmc.get("valu_timed") or {}).get("frac"),
+                         "pmc_build": pmc.get("build"), "pmc_matches_build": pmc_matches_build(pmc),
                          "kernel": "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, (", equilibration vectors in global memory (3 instances per CU)" if args.kernel_variant == 0 and args.defer == 0 else "")
                                                                             if planner else ("" if args.kernel_variant == 3 else ", MFMA sweeps")),
                          "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
@@ -401,7 +431,7 @@ def main():
                                                       "continue the parked instances %d iterations at a time (a few workgroups each).  "
                                                       "algorithmic_bytes_per_launch and frac count only the iterations the main launch runs (an "
                                                       "instance's first %d); aggregate_* count all" % (args.defer, args.defer_budget, Kp),
-                                              "algorithmic_bytes_per_batch_all_iterations": bytes_timed / max(args.steps, 1)} if args.defer > 0 else None),
+                                              "algorithmic_bytes_per_batch_all_iterations": bytes_timed / max(len(my_steps), 1)} if args.defer > 0 else None),
                          "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_admm_iteration": bytes_iter,
                          "aggregate_algorithmic_GBps": agg[2] / elapsed / 1e9,
                          "aggregate_frac_per_gpu": bytes_timed / elapsed / 1e9 / HBM_PEAK_GBS,
@@ -411,8 +441,14 @@ def main():
                                  "(a launch lasts as long as its slowest instance); aggregate_frac_per_gpu = all timed "
                                  "launches' bytes / wall time; config.isolated_seed0_launch is one launch alone on the GPU"},
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, planner=planner)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if world == 1 and not planner and not args.no_extras and not args.no_other_workloads:
+            # the other single-GPU configurations of BASELINE.json, short legs after the timed region (their own engines and streams)
+            for e in engines:
+                e.close()
+            engines = []
+            out["config"]["other_workloads"] = other_workloads(args, rank, local_rank, world, dev)
         print(json.dumps(out), flush=True)
 
     for e in engines:
@@ -420,6 +456,135 @@ def main():
     if lane is not None:
         lane.close()
     finish(world)
+
+
+def rank_info(world, local_rank, dev):
+    """Who took part: size of the RCCL process group as torch.distributed reports it and every rank's device name (collective:
+    called on every rank)."""
+    import torch
+    import torch.distributed as dist
+    name = torch.cuda.get_device_name(local_rank)
+    names = [name]
+    if world > 1:
+        names = [None] * world
+        dist.all_gather_object(names, name)
+    return {"rccl_world": dist.get_world_size() if world > 1 else 1, "devices": names}
+
+
+def lib_sha256():
+    import hashlib
+    try:
+        from lpvmpc import _ffi
+        return hashlib.sha256(open(_ffi.LIB_PATH, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
+def pmc_matches_build(pmc):
+    """True when the committed counter file was collected with the liblpvmpc.so that is loaded now (tools/pmc_summary.py records
+    its sha256), False when it names another build, None when the file carries no build record."""
+    b = (pmc or {}).get("build") or {}
+    return (b.get("liblpvmpc_sha256") == lib_sha256()) if b.get("liblpvmpc_sha256") else None
+
+
+def early_cpu_baseline(args, world):
+    """cpu_baseline of the selected workload (rank 0, before any process group exists; numpy + the oracle only)."""
+    import numpy as np
+    from lpvmpc import workloads
+    if args.workload == "cfg5":
+        import lpvmpc
+        c = np.load(os.path.join(ROOT, "tests", "golden", "cascade.npz"))
+        return cpu_baseline_cascade(c, lpvmpc.Map("L_shape", 0.2), workloads)
+    if args.workload == "cfg4":
+        from lpvmpc.distributed import shard_range
+        total = args.batch * world if args.batch != BATCH else 65536
+        lo, hi = shard_range(total // 2, 0, world)
+        ws = [workloads.shard_batch(workloads.controller_batch(total // 2, N=20, seed=2), lo, hi),
+              workloads.shard_batch(workloads.planner_batch(total // 2, N=20, seed=2), lo, hi)]
+        return cpu_baseline_mixed(ws, hi - lo)
+    planner = args.workload == "cfg3"
+    B = 4096 if (planner and args.batch == BATCH) else args.batch
+    make = workloads.planner_batch if planner else workloads.controller_batch
+    return cpu_baseline(make(B, N=30 if planner else HORIZON, seed=1 if planner else 0), planner=planner)
+
+
+def other_workloads(args, rank, local_rank, world, dev):
+    """Short legs of configs[2] (planner N = 30, 4096 instances), configs[3] (one GPU's 8192 of the mixed batch) and configs[4]
+    (8192 vehicles, 60 controller ticks of the cascade) behind the headline's timed region: value, roofline fraction of the
+    dominant kernel, its mean launch time and the iteration means, the same code paths as --workload cfg3 / cfg4 / cfg5."""
+    import copy
+    res = {}
+    legs = (("configs[2]", dict(workload="cfg3", batch=4096, steps=2, warmup=1, streams=2, defer=0, lane_cus=0)),
+            ("configs[3]", dict(workload="cfg4", batch=8192, steps=2, warmup=1, streams=2, defer=0, lane_cus=0)),
+            ("configs[4]", dict(workload="cfg5", batch=8192, steps=60, warmup=2, defer=0, lane_cus=0)))
+    for name, kw in legs:
+        a = copy.copy(args)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        a.no_cpu_baseline = True; a.no_extras = True; a.dump_results = ""
+        t1 = time.perf_counter()
+        try:
+            o = {"cfg3": bench_planner_leg, "cfg4": bench_mixed, "cfg5": bench_cascade}[a.workload](a, rank, local_rank, world, dev)
+        except Exception as exc:                    # a leg must not take the headline line with it
+            res[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            continue
+        r = o["roofline"]
+        res[name] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "steps": o["steps"], "warmup": o["warmup"], "ms_per_step": o["ms_per_step"],
+                     "frac": r.get("frac"), "kernel": r.get("kernel"), "kernel_avg_ms": r.get("kernel_avg_ms"), "launches": r.get("launches"),
+                     "workload": o["config"]["workload"], "leg_wall_s": time.perf_counter() - t1}
+        for k in ("mean_admm_iters", "mean_admm_iters_controller", "mean_admm_iters_planner", "solved_fraction", "alive_fraction", "real_time_factor",
+                  "all_vehicles_ticks_per_s", "planner_mean_admm_iters"):
+            if k in o["config"]:
+                res[name][k] = o["config"][k]
+    return res
+
+
+def bench_planner_leg(args, rank, local_rank, world, dev):
+    """configs[2] in short: args.steps steps of one 4096-instance planner batch (N = 30, L-shape, seed 1) on args.streams streams."""
+    import numpy as np
+    import torch
+    from lpvmpc import workloads
+    B, N, nx = args.batch, 30, 5
+    w = workloads.planner_batch(B, N=N, seed=1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = dict(x0=t(w["x0"]), u_prev=t(w["u_prev"]), curv=t(w["curv_s"]), u_old=t(w["u_old"]), max_ey=t(w["max_ey"]))
+    S = max(1, args.streams)
+    engines = [workloads.make_solver(w, device=local_rank) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    outs = [dict(xPred=torch.empty((B, N + 1, nx), dtype=torch.float64, device=dev), uPred=torch.empty((B, N, 2), dtype=torch.float64, device=dev),
+                 status=torch.empty(B, dtype=torch.int32, device=dev), iters=torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(S)]
+    for e in engines:
+        e.reserve(B)
+
+    def step(j):
+        e, o = engines[j % S], outs[j % S]
+        e.solve_dev(B, d["x0"], d["u_prev"], None, d["curv"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"], o["status"], o["iters"], None, None,
+                    cf_new=w["cf_new"], lap=w["lap"], stream=streams[j % S].cuda_stream)
+    for j in range(args.warmup):
+        step(j)
+    torch.cuda.synchronize()
+    for e in engines:
+        e.set_timing(True)
+    t0 = time.perf_counter()
+    for j in range(args.steps):
+        step(j)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kms = kn = 0
+    for e in engines:
+        ms_, n_ = e.kernel_time_stats(); kms += ms_; kn += n_
+    it = outs[0]["iters"].cpu().numpy().astype(np.int64); stt = outs[0]["status"].cpu().numpy()
+    bl, bi = algorithmic_bytes(it, N=N, nx=nx, m_rows=(N + 1) * nx + (N + 1) * nx + N * 2)
+    k_avg_s = kms / max(kn, 1) * 1e-3
+    for e in engines:
+        e.close()
+    return {"metric": "LPV-MPP planner solves/sec (N=30, nx=5, nu=2)", "value": B * args.steps / elapsed, "unit": "solves/s", "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "config": {"workload": "configs[2]: batch=%d LPV-MPP planner solves (velocity-max cost), N=30, L-shape track, OSQP defaults + polish, cold start" % B,
+                       "mean_admm_iters": float(it.mean()), "solved_fraction": float((stt == 1).mean())},
+            "roofline": {"bound": "hbm", "frac": bl / k_avg_s / 1e9 / HBM_PEAK_GBS, "kernel": "admm_solve_kernel<5, 30, 2, equilibration vectors in global memory (3 instances per CU)>",
+                         "kernel_avg_ms": kms / max(kn, 1), "launches": kn, "algorithmic_bytes_per_launch": bl, "bytes_per_admm_iteration": bi,
+                         "note": "launches of the %d streams overlap: kernel_avg_ms is a launch sharing the chip" % S}}
 
 
 def lane_trace_summary(lane):
@@ -505,7 +670,7 @@ def load_pmc(B, planner):
     the output next to the numbers."""
     if planner or B != BATCH:
         return {}
-    for name in ("r03_pmc.json", "r02_pmc.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -641,6 +806,8 @@ def bench_mixed(args, rank, local_rank, world, dev):
     def step(n_inst=Bh):
         pair = lanes[counter[0] % S]; counter[0] += 1
         for (e, o, st), d, w in zip(pair, dev_in, ws):
+            if args.defer > 0:
+                e.join(st.cuda_stream)        # a lane has ONE output set: what an earlier step of this lane left parked is finished before the set is written again (lpvmpc.h)
             e.solve_dev(n_inst, d["x0"], d["u_prev"], d["vel_ref"], d["curv_s"], d["u_old"], d["max_ey"], o["xPred"], o["uPred"], o["status"],
                         o["iters"], o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"], stream=st.cuda_stream)
 
@@ -679,6 +846,7 @@ def bench_mixed(args, rank, local_rank, world, dev):
     # the one collective, after the timed region: (u0, status, iters) of every instance of the global batch, in instance order
     gathered = [gather_results(lanes[0][i][1]["uPred"][:, 0, :].cpu().numpy(), sts[i], its[i], half, device=dev) for i in range(2)]
     assert all(g[0].shape == (half, 2) for g in gathered)
+    out = None
     if rank == 0 and args.dump_results:
         np.savez(args.dump_results, ctrl_u0=gathered[0][0], ctrl_status=gathered[0][1], ctrl_iters=gathered[0][2],
                  plan_u0=gathered[1][0], plan_status=gathered[1][1], plan_iters=gathered[1][2], half=half, world=world, seed=2)
@@ -700,27 +868,42 @@ def bench_mixed(args, rank, local_rank, world, dev):
                             "algorithmic_bytes_per_launch": bl_p, "bytes_per_admm_iteration": bi_p,
                             "aggregate_algorithmic_GBps": (bl_c + bl_p) * args.steps * world / elapsed / 1e9,
                             "note": "dominant kernel = the planner half (about 12x the controller's iterations)"}}
-        if not args.no_cpu_baseline:
-            from oracle import osqp_ref
-            cores = usable_cores()
-            n = 256
-            sub = lambda w: {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == Bh and k != "track" else v) for k, v in w.items()}
-            t1 = time.perf_counter(); reps = 0
-            while time.perf_counter() - t1 < 10.0:
-                osqp_ref.ctrl_tick_batch(sub(ws[0]), nthreads=cores); osqp_ref.plan_tick_batch(sub(ws[1]), nthreads=cores); reps += 1
-            tt = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": 2 * n * reps / tt, "unit": "solves/s", "cores": cores, "kind": "port",
-                                   "sample": "%d x (256 controller + 256 planner instances of the same batch), oracle C ticks under OpenMP, %.1f s" % (reps, tt)}
-        print(json.dumps(out), flush=True)
     for pair in lanes:
         for e, _, _ in pair:
             e.close()
+    return out if rank == 0 else None
+
+
+def cpu_baseline_mixed(ws, Bh):
+    """The oracle's controller and planner ticks on the first 256 instances of each half of the rank-0 share, all usable host cores."""
+    import numpy as np
+    from oracle import osqp_ref
+    cores = usable_cores()
+    n = min(256, Bh)
+    sub = lambda w: {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == Bh and k != "track" else v) for k, v in w.items()}
+    t1 = time.perf_counter(); reps = 0
+    while time.perf_counter() - t1 < 10.0:
+        osqp_ref.ctrl_tick_batch(sub(ws[0]), nthreads=cores); osqp_ref.plan_tick_batch(sub(ws[1]), nthreads=cores); reps += 1
+    tt = time.perf_counter() - t1
+    return {"value": 2 * n * reps / tt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": "%d x (%d controller + %d planner instances of the same batch), oracle C ticks under OpenMP, %.1f s" % (reps, n, n, tt)}
+
+
+def cascade_starts(c, B, seed):
+    """Monte-Carlo starts of configs[4]: the reference's state at the lap event (fixture data) with perturbed y, yaw and speed."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    plant0 = np.tile(c["plant0"], (B, 1))
+    plant0[:, 1] += rng.normal(0, 0.01, B); plant0[:, 6] += rng.normal(0, 0.01, B); plant0[:, 2] += rng.uniform(-0.05, 0.3, B)
+    return plant0
 
 
 def bench_cascade(args, rank, local_rank, world, dev):
     """configs[4] shape: Monte-Carlo fleet, planner (N = 40 @ 20 Hz, the launch file's horizon: N = 30 cannot be handed
     off) + Controller_TT (N = 20 @ 30 Hz) + plant, everything on the device; vehicles are split over
-    the ranks, no collective on the data path.  value = vehicle-ticks/s (all vehicles, dead ones included)."""
+    the ranks, no collective on the data path.  value = ALIVE vehicle-ticks/s: the controller ticks that vehicles entered with a
+    finite plant state (a vehicle whose planner QP went primal infeasible carries NaN from then on and costs no iterations);
+    the all-vehicles figure of earlier rounds is kept as config.all_vehicles_ticks_per_s."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -730,9 +913,7 @@ def bench_cascade(args, rank, local_rank, world, dev):
     B = args.batch if args.batch != BATCH else max(1, 8192 // world)
     c = np.load(os.path.join(ROOT, "tests", "golden", "cascade.npz"))          # state at the reference's lap event (fixture data)
     mp = lpvmpc.Map("L_shape", 0.2)
-    rng = np.random.default_rng(3 + 1000 * rank)
-    plant0 = np.tile(c["plant0"], (B, 1))
-    plant0[:, 1] += rng.normal(0, 0.01, B); plant0[:, 6] += rng.normal(0, 0.01, B); plant0[:, 2] += rng.uniform(-0.05, 0.3, B)
+    plant0 = cascade_starts(c, B, 3 + 1000 * rank)
     Qr, Rr, dRr = W.CTRL_TUNINGS["race"]
     # The vehicles are independent, so the fleet is cut into G sub-fleets, each with its own planner / controller engine pair and
     # streams: a sub-fleet's planner launch ends in a tail of slow QPs during which most of the chip would idle, and the other
@@ -753,19 +934,17 @@ def bench_cascade(args, rank, local_rank, world, dev):
         outs = [ct.cascade_read(full=False) for ct, _ in fleets]
         o = {k: np.concatenate([x[k] for x in outs]) for k in ("plant", "lap", "plan_iters")}
         o["ticks"] = outs[0]["ticks"]
+        o["alive_ticks"] = np.concatenate([ct.cascade_alive_ticks() for ct, _ in fleets]).astype(np.int64)
         return o
-
-    def fence():
-        read_all()
-        if world > 1:
-            dist.barrier()
 
     if args.warmup > 0:
         for ct, _ in fleets:
             ct.cascade_tick(args.warmup)
     for ct, pl in fleets:
         ct.set_timing(True); pl.set_timing(True)
-    fence()
+    before = read_all()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     for ct, _ in fleets:
         ct.cascade_tick(args.steps)
@@ -774,55 +953,69 @@ def bench_cascade(args, rank, local_rank, world, dev):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     alive = np.all(np.isfinite(o["plant"]), axis=1)
+    alive_vt = float((o["alive_ticks"] - before["alive_ticks"]).sum())        # vehicle-ticks of the timed region that did work
     pst = [pl.kernel_time_stats() for _, pl in fleets]; cst = [ct.kernel_time_stats() for ct, _ in fleets]
     pms, pn = sum(x[0] for x in pst), sum(x[1] for x in pst); cms, cn = sum(x[0] for x in cst), sum(x[1] for x in cst)
-    elapsed, agg = reduce_stats(elapsed, [float(alive.sum())], device=dev)
+    laps_done = o["lap"].astype(np.int64) - 1
+    reached = [float(np.sum(laps_done >= k)) for k in range(0, 4)]
+    elapsed, agg = reduce_stats(elapsed, [float(alive.sum()), alive_vt] + reached, device=dev)
+    out = None
     if rank == 0:
         it = o["plan_iters"].astype(np.int64)
         bytes_launch, bytes_iter = algorithmic_bytes(it, N=40, nx=5, m_rows=41 * 5 + 41 * 5 + 40 * 2)
         bytes_launch /= G                                                       # one launch covers one sub-fleet
         k_avg_s = pms / max(pn, 1) * 1e-3
-        out = {"metric": "closed-loop vehicle-ticks/sec (planner N=40 @20 Hz + controller N=20 @30 Hz + plant)", "value": B * world * args.steps / elapsed,
+        fleet = B * world
+        out = {"metric": "closed-loop alive vehicle-ticks/sec (planner N=40 @20 Hz + controller N=20 @30 Hz + plant)", "value": agg[1] / elapsed,
                "unit": "vehicle-ticks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "strong" if args.batch == BATCH else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "configs[4]: %d vehicles per GPU, planner + controller cascade per 30 Hz tick, L-shape track, Monte-Carlo starts "
-                                      "around the lap-event state, cold start" % B, "vehicles_per_gpu": B, "sub_fleets": G, "alive_fraction": agg[0] / (B * world),
+                                      "around the lap-event state, cold start" % B, "vehicles_per_gpu": B, "sub_fleets": G,
+                          "value_counts": "controller ticks entered with a finite plant state (sum over the fleet / wall time); a lost vehicle costs no iterations and is not counted",
+                          "all_vehicles_ticks_per_s": fleet * args.steps / elapsed,
+                          "alive_share_of_vehicle_ticks": agg[1] / (fleet * args.steps),
+                          "alive_fraction": agg[0] / fleet,
+                          "fleet_fraction_that_completed_laps": {str(k): agg[2 + k] / fleet for k in range(4)},
                           "laps_completed_survivors_rank0": ({"min": int(o["lap"][alive].min()) - 1, "p50": float(np.median(o["lap"][alive])) - 1,
                                                               "max": int(o["lap"][alive].max()) - 1} if alive.any() else None),
                           "driving_time_s": (args.steps + args.warmup) / 30.0,
                           "attrition_note": "losses = planner QPs of the reference's open-loop recursion turning primal infeasible; the CPU oracle "
                                             "cascade loses the same share (profiles/r02_cascade_attrition_cpu_oracle.txt, tests/test_gpu_cascade.py)",
                           "real_time_factor": (args.steps / 30.0) / elapsed, "planner_ticks": int(o["ticks"][1]),
+                          "planner_mean_admm_iters": float(it[alive].mean()) if alive.any() else None,
                           "ctrl_kernel_avg_ms": cms / max(cn, 1)},
                "roofline": {"bound": "hbm", "achieved": bytes_launch / k_avg_s / 1e9 if pn else float("nan"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": (bytes_launch / k_avg_s / 1e9 / HBM_PEAK_GBS) if pn else float("nan"), "traffic": None,
                             "kernel": "admm_solve_kernel<5, 40, 2, MFMA sweeps>", "kernel_avg_ms": pms / max(pn, 1), "launches": pn,
                             "note": "planner solve kernel (95 % of a tick); algorithmic bytes from the iteration counts of the last planner tick; the sub-fleets' launches overlap, so kernel_avg_ms is the duration of a launch sharing the chip"}}
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_cascade(c, mp, W)
-        print(json.dumps(out), flush=True)
     for ct, pl in fleets:
         ct.close(); pl.close()
+    return out
 
 
-def cpu_baseline_cascade(c, mp, W, vehicles=64, ticks=60):
-    """The oracle cascade (oracle/cascade_ref.py) on a small fleet, all usable host cores."""
+def cpu_baseline_cascade(c, mp, W, vehicles=64, ticks=300):
+    """The oracle cascade (oracle/cascade_ref.py) on a small fleet with the bench's start distribution, all usable host cores, long
+    enough (300 controller ticks = 10 s of driving) to go through the same attrition; value = alive vehicle-ticks/s like the
+    device's."""
     import numpy as np
     from oracle import cascade_ref
     cores = usable_cores()
-    rng = np.random.default_rng(3)
-    plant0 = np.tile(c["plant0"], (vehicles, 1))
-    plant0[:, 1] += rng.normal(0, 0.01, vehicles); plant0[:, 6] += rng.normal(0, 0.01, vehicles); plant0[:, 2] += rng.uniform(0.0, 0.3, vehicles)
+    plant0 = cascade_starts(c, vehicles, 3)
     ref = cascade_ref.CascadeRef(mp.PointAndTangent, W.CTRL_TUNINGS["race"], (W.PLAN_Q, W.PLAN_R, W.PLAN_dR, W.PLAN_L), plant0,
                                  np.tile(c["cmd0"], (vehicles, 1)), np.tile(c["uPred0"], (vehicles, 1, 1)), half_width=mp.halfWidth,
                                  slack=mp.slack, plan_max_ey=0.2, nthreads=cores)
-    t0 = time.perf_counter(); done = 0
+    t0 = time.perf_counter(); done = 0; alive_vt = 0
     for _ in range(ticks):
+        alive_vt += int(np.sum(np.all(np.isfinite(ref.plant), axis=1)))
         ref.tick(); done += 1
+        if time.perf_counter() - t0 > 40.0:
+            break
     t = time.perf_counter() - t0
-    return {"value": vehicles * max(done, 1) / t, "unit": "vehicle-ticks/s", "cores": cores, "kind": "port",
-            "sample": "%d vehicles x %d controller ticks of oracle/cascade_ref.py (C tick functions under OpenMP, hand-off and plant in numpy), %.1f s"
-                      % (vehicles, done, t)}
+    alive_end = float(np.mean(np.all(np.isfinite(ref.plant), axis=1)))
+    return {"value": alive_vt / t, "unit": "vehicle-ticks/s", "cores": cores, "kind": "port",
+            "all_vehicles_ticks_per_s": vehicles * max(done, 1) / t, "alive_fraction_at_end": alive_end,
+            "sample": "%d vehicles x %d controller ticks of oracle/cascade_ref.py (the bench's start distribution; C tick functions under OpenMP, "
+                      "hand-off and plant in numpy), %.1f s; alive vehicle-ticks counted like the device's" % (vehicles, done, t)}
 
 
 def cpu_baseline(w, target_s=12.0, planner=False):

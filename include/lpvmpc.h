@@ -129,7 +129,8 @@ int lpvmpc_last_error_code(void);
  * check with iter >= K is parked (status LPVMPC_PENDING, whole solver state saved) and the launch ends.  Every deferred call
  * is followed, on the same stream, by a resume pass of the same kernel that continues everything parked on the handle -- from
  * this call and from earlier ones -- for "defer_budget" more iterations (default 200; 0 = to completion) and parks again what
- * is still unsolved.  Results are bit-identical to the plain call (a restored instance re-factors K from its saved state).
+ * is still unsolved.  With "defer_tail" 0 the results are bit-identical to the plain call (a restored instance re-factors K
+ * from its saved state); with the default "defer_tail" 1 the closing passes use the tail kernel: equal to round-off, see there.
  * Completion contract: an instance's outputs are final when its status is no longer LPVMPC_PENDING; lpvmpc_join(h, stream)
  * enqueues the pass that finishes whatever is still parked, so work behind it in `stream` sees complete outputs.  Until then
  * the output buffers of the deferred calls must stay valid and must not be reused for other data.  The synchronous host-array
@@ -141,8 +142,11 @@ int lpvmpc_last_error_code(void);
  * "defer_tail" (0 | 1, default 1): the passes that run parked instances to completion (lpvmpc_join, the synchronous entry
  * points, "defer_budget" 0) use the whole-CU tail kernel where one exists for the handle (controller or planner, N = 20): a 512-thread
  * workgroup per instance that applies K^-1 as a dense matrix held in registers, 1.65x faster per iteration for an instance that
- * has the GPU to itself.  Statuses, iteration counts and polish flags equal the other kernel's; solutions agree to round-off
- * (1e-7 polished, 1e-6 for an un-polished iterate; observed 1.4e-8 / 7e-10 over 196 608 instances), so bit-identity with the plain call holds with 0 only. */
+ * has the GPU to itself.  Statuses, iteration counts and polish flags have been OBSERVED equal to the other kernel's on every
+ * instance compared so far (196 608 over four tracks; the seeds of tests/test_gpu_deferral.py are regression fixtures for this
+ * build) -- an observation, not a guarantee: the two kernels round differently, and a termination test that is decided by
+ * round-off can move by one check (25 iterations) on another toolchain or device.  Solutions agree to round-off (1e-7 polished,
+ * 1e-6 for an un-polished iterate; observed 1.4e-8 / 7e-10), so bit-identity with the plain call holds with 0 only. */
 int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value);
 /* Straggler deferral (see "defer_after"): enqueues on `stream` (a hipStream_t; ordered behind the stream of the handle's last
  * deferred call if it is another one) the resume pass that runs every parked instance to completion.  No-op without deferral. */

@@ -115,5 +115,15 @@ def test_device_assembly_has_no_copy_in_front_of_an_exec_restore(ffi):
             fh.write("_Zk:\n.LBB0_1:\n\tv_mov_b32_e32 v33, 0x58\n\ts_and_saveexec_b64 s[12:13], s[20:21]\n\tds_read_b64 v[30:31], v233\n"
                      "\tv_mov_b32_e32 v33, v234\n\ts_or_b64 exec, exec, s[12:13]\n\tds_write_b64 v1, v[2:3]\n")
         assert chk.scan(bad) == []
+        # ... but a copy behind the narrowing whose destination got NO value under the wider mask is still flagged (the lanes outside
+        # the region would reach the join with a stale register), and so is a copy behind a mask-WIDENING instruction
+        with open(bad, "w") as fh:
+            fh.write("_Zk:\n.LBB0_1:\n\ts_and_saveexec_b64 s[12:13], s[20:21]\n\tds_read_b64 v[30:31], v233\n"
+                     "\tv_mov_b32_e32 v33, v234\n\ts_or_b64 exec, exec, s[12:13]\n\tds_write_b64 v1, v[2:3]\n")
+        assert len(chk.scan(bad)) == 1
+        with open(bad, "w") as fh:
+            fh.write("_Zk:\n.LBB0_1:\n\tv_mov_b32_e32 v33, 0x58\n\ts_or_saveexec_b64 s[12:13], s[20:21]\n"
+                     "\tv_mov_b32_e32 v33, v234\n\ts_or_b64 exec, exec, s[12:13]\n\tds_write_b64 v1, v[2:3]\n")
+        assert len(chk.scan(bad)) == 1
     finally:
         os.remove(bad)

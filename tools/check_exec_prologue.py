@@ -21,6 +21,17 @@ def dest_regs(instr):
     return []
 
 
+def writes(instr, reg):
+    """True if the instruction's first operand (its destination) covers v<reg>."""
+    ops = instr.split(None, 1)[1] if " " in instr else ""
+    if instr.startswith(("global_store", "ds_write", "scratch_store", "buffer_store", "flat_store", "s_")):
+        return False
+    m = re.match(r"v\[(\d+):(\d+)\]|v(\d+)", ops)
+    if not m:
+        return False
+    return int(m.group(3)) == reg if m.group(3) is not None else int(m.group(1)) <= reg <= int(m.group(2))
+
+
 def reads(instrs, reg):
     """True if register v<reg> appears as a SOURCE operand of one of the instructions."""
     for t in instrs:
@@ -68,11 +79,15 @@ def scan(path, window=8):
                     # a mask-narrowing instruction between the label and the restore opens a NEW guarded region inside this block
                     # (if-then without else: `v_mov v33, default; s_and_saveexec; v_mov v33, v234; s_or_b64 exec`): copies behind
                     # it belong to that region's lanes by construction, the other lanes keep the value set in front of it
-                    opened = [i_ for i_, b_ in enumerate(body[:k]) if re.match(r"s_(and|andn2|xor|or)_saveexec_b64|s_and_b64\s+exec,|s_andn2_b64\s+exec,|s_mov_b64\s+exec,", b_)]
+                    # (only instructions that NARROW the mask open such a region -- s_or_saveexec / s_xor_saveexec / s_mov exec widen or
+                    # restore it -- and a copy behind the narrowing is exempt only if its destination was given a value under the wider
+                    # mask earlier in this block: otherwise the lanes outside the region reach the join with a stale register)
+                    opened = [i_ for i_, b_ in enumerate(body[:k]) if re.match(r"s_(and|andn2)_saveexec_b64|s_and_b64\s+exec,\s*exec,|s_andn2_b64\s+exec,\s*exec,", b_)]
                     first_open = opened[0] if opened else k
                     for idx, b in enumerate(body[:k]):
-                        if idx > first_open:
-                            continue
+                        if idx > first_open and re.match(r"(v_mov_b32_e32\s+v\d+,\s*v\d+$|v_mov_b64_e32\s+v\[[\d:]+\],\s*v\[|v_accvgpr_(read|write)_b32)", b):
+                            if all(any(writes(early, d) for early in body[:first_open]) for d in dest_regs(b)):
+                                continue
                         if not re.match(r"(v_mov_b32_e32\s+v\d+,\s*v\d+$|v_mov_b64_e32\s+v\[[\d:]+\],\s*v\[|v_accvgpr_(read|write)_b32)", b):
                             continue
                         # a copy whose destination is consumed again before the mask restore is a temporary of the branch

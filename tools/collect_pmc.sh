@@ -11,6 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 TIMED="python3 bench.py --steps 100 --warmup 8 --no-cpu-baseline --no-extras"
 ISO="python3 bench.py --steps 10 --warmup 2 --streams 1 --defer 0 --no-cpu-baseline --no-extras"
+sha256sum autonomous-racing-lpv-mpp-mpc_amd/liblpvmpc.so | cut -d" " -f1 > $OUT/lib_sha256.txt      # which build the counters describe (bench.py: roofline.pmc_matches_build)
 echo "$TIMED" > $OUT/command_timed.txt
 echo "$ISO" > $OUT/command.txt
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAVES"

@@ -125,6 +125,20 @@ def main():
     cmd_iso = open(os.path.join(src, "command.txt")).read().strip()
     out = {"command": "rocprofv3 --pmc <group> --kernel-trace --output-format csv -- " + cmd_iso + " (one pass per counter group: tools/collect_pmc.sh)",
            "kernel": "admm_solve_kernel<6, 20, 2, MFMA sweeps>", "batch": B, "seed": 0}
+    # ---- which build: sha256 of the library the passes ran with (written next to them on the GPU box) and the commit this summary is made at
+    import subprocess
+    build = {}
+    try:
+        build["liblpvmpc_sha256"] = open(os.path.join(src, "lib_sha256.txt")).read().strip()
+    except OSError:
+        pass
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        build["git_head"] = subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], text=True).strip()
+        build["git_dirty_sources"] = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "autonomous-racing-lpv-mpp-mpc_amd/csrc", "include"], text=True).strip())
+    except (OSError, subprocess.CalledProcessError):
+        pass
+    out["build"] = build
     # ---- isolated plain launches (no deferral, one stream) --------------------------------------------------------------
     out.update(traffic(src, "fetch", "write", "main"))
     sq, ns, n = counters(src, ("sq1", "sq2"), "main")
