@@ -93,6 +93,8 @@ struct Solver {
     // K^-1 in registers: thread (g = tid >> 3, s = tid & 7), tid < 8 * kDenseGroups, holds rows 3g .. 3g+2 of the columns 8 c + s
     // (c = 0 .. NS-1): 63 doubles per thread at N = 20, 7 of the 8 wavefronts
     static constexpr int kDC = TAIL ? NT + 1 : 1;
+    static constexpr int kRhsPitch = ((NT + 1) + 1) & ~1;            // tail kernel: doubles per slot of the slot-major right-hand side (even: 16-byte loads)
+    static_assert(!TAIL || 8 * (((NT + 1) + 1) & ~1) <= 2 * (NT + 1) * 8, "the slot-major right-hand side must fit VT + AT");
     static constexpr int kDenseGroups = ((NT + 1) * 8 + 2) / 3;      // groups of three rows
     static constexpr int kDenseRound = 7;                             // block columns per staging round
     static constexpr int kActW = ((NT + 1) * 8 + 63) / 64;            // wavefronts that own elements in the element loops
@@ -115,13 +117,18 @@ struct Solver {
     static constexpr bool kGs = GS;                 // the equilibration vectors D / Ed / Eb live in global memory (SolveArgs::scal)
     static_assert(!GS || (NW == 2 && NT > 20 && !MF), "global scalings: planner two-wavefront kernels only");
     static constexpr bool kCacheW = (kReg && !GS && (MF || (NW == 2 && NT > 20))) || TAIL;   // (the N <= 20 DPP / one-wave instantiations have no registers to spare)
-    static constexpr int kRnd = kCacheW ? ((NT + 1) * 8 + kStride - 1) / kStride : 1;
+    // Row-compact update (controller, N = 20, two wavefronts): the 126 dynamics rows and the 120 box rows (+ the pinned-steering rows of
+    // the first `delay` stages) each fit ONE round of the 128 lanes when lane l takes row (l / 6, l % 6), instead of the two rounds
+    // of the element loop (thread <-> (stage, slot) with 8 slots per stage: 168 elements, of which the second round fills 40 lanes);
+    // only the x update still walks the 168 variables.  The row of a lane sits in bits 17.. of lpack.
+    static constexpr bool kRowMap = kCtrl && NT == 20 && NW == 2 && !TAIL;
+    static constexpr int kRnd = kCacheW ? (kRowMap ? 1 : ((NT + 1) * 8 + kStride - 1) / kStride) : 1;
     double wbx[kRnd], wbxi[kRnd];
     __device__ __forceinline__ void cache_box_weights() {
         if constexpr (kCacheW) {
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
-                const int e = tid + r * kStride - (TAIL ? kBoxT0 : 0);      // (tail kernel: the box rows belong to the threads from kBoxT0 on, see update)
+                const int e = kRowMap ? lane_row_box() : tid + r * kStride - (TAIL ? kBoxT0 : 0);      // (tail kernel: the box rows belong to the threads from kBoxT0 on, see update)
                 double w = rho, wi = rinv;
                 if (e >= 0 && e < NS * 8) {
                     const double lo = Lo[e], hi = Hi[e];
@@ -137,8 +144,16 @@ struct Solver {
         LaneC l;
         const int lp = opaque(lpack);          // unpacked here, not hoisted into five live registers
         l.r0 = lp & 15; l.r1 = (lp >> 4) & 15; l.r2 = (lp >> 8) & 15; l.bvar = (lp >> 12) & 15;
-        l.rmask = (lp >> 16) ? 1.0 : 0.0;
+        l.rmask = ((lp >> 16) & 1) ? 1.0 : 0.0;
         return l;
+    }
+
+    // kRowMap: vector index 8 k + r of the dynamics row / box row this lane updates (-1: none).  Lanes 0 .. 125 <-> rows (l / 6, l % 6);
+    // box rows exist on the stages k < N (lanes 0 .. 119), lanes 120 + k take the pinned-steering row (k, 6) of the stages k < delay
+    __device__ __forceinline__ int lane_row_dyn() const { const int t = opaque(tid); return t < 126 ? (opaque(lpack) >> 17) & 255 : -1; }
+    __device__ __forceinline__ int lane_row_box() const {
+        const int t = opaque(tid);
+        return t < 120 ? (opaque(lpack) >> 17) & 255 : (t - 120 < delay ? 8 * (t - 120) + 6 : -1);
     }
 
     __device__ __forceinline__ Solver(const DevCfg &cf, double *smem)
@@ -169,6 +184,7 @@ struct Solver {
             int first, cnt; rows_on(tj, first, cnt);
             const int r0 = cnt >= 1 ? first : 7, r1 = cnt >= 2 ? first + 1 : 7, r2 = (kCtrl && tj == 6) ? 6 : 7;
             lpack = r0 | (r1 << 4) | (r2 << 8) | (box_var(tj) << 12) | ((tj < NX ? 1 : 0) << 16);
+            if constexpr (kRowMap) { const int t = threadIdx.x; lpack |= (8 * (t / 6) + t % 6) << 17; }
         }
         c = 1.0; cinv = 1.0; pol = false; rho = rho_eq = rinv = rinv_eq = 0.0; rSm = rLt = rLb = 0.0;
         {   // lane (r, b = 2I + J, c) of an A operand: type A step T[4J + c][4I + r], type B step T[4I + c][4J + r]
@@ -888,10 +904,10 @@ struct Solver {
     __device__ __forceinline__ void dense_apply() {
         const int t0 = opaque(tid), g = t0 >> 3, s_ = t0 & 7;
         if (g < kDenseGroups) {
-            const double *rv = VT + s_;
-            double rr[kDC];                 // the whole right-hand side slice first: one LDS round trip, not one per pair of columns
+            const double2 *rv = reinterpret_cast<const double2 *>(VT + s_ * kRhsPitch);
+            double rr[kDC + 1];             // the whole right-hand side slice first: one LDS round trip, not one per pair of columns
 #pragma unroll
-            for (int c = 0; c < kDC; ++c) rr[c] = rv[8 * c];
+            for (int c = 0; c < kDC; c += 2) { const double2 v = rv[c >> 1]; rr[c] = v.x; rr[c + 1] = v.y; }
             __builtin_amdgcn_sched_barrier(0);
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
 #pragma unroll
@@ -1301,6 +1317,7 @@ struct Solver {
         return v;
     }
 
+    __device__ __forceinline__ static double rmask_one(double v) { return v; }       // (rmask = 1 on a real row: 1.0 * v == v, bit for bit)
     // bounds of a dynamics row (equalities: l = u)
     __device__ __forceinline__ double dyn_bound(int e) const { return beq[e < 8 ? e : 8]; }
 
@@ -1382,8 +1399,14 @@ struct Solver {
     // (the tail kernel writes it to VT: dense_apply reads the whole right-hand side while it stores x~ into XT)
     __device__ __forceinline__ void build_rhs(double sigma) {
         const LaneC lc = lane_consts();
-        double *const dst = TAIL ? VT : XT;
-        for (int e = opaque(tid); e < NS * 8; e += kStride) dst[e] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
+        if constexpr (TAIL) {
+            // slot-major, kRhsPitch doubles per slot: the thread (g, s) of dense_apply reads its 21 values rhs[8 c + s] as one contiguous
+            // run (16-byte loads, half the LDS instructions of the broadcast reads at stride 8); the last slots spill a few words into AT,
+            // which only the termination checks use
+            for (int e = opaque(tid); e < NS * 8; e += kStride) VT[(e & 7) * kRhsPitch + (e >> 3)] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
+        } else {
+            for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
+        }
         sync();
     }
     // z~ = A x~ fused with OSQP update_x / update_z / update_y; leaves rho z - y in ZT*.
@@ -1425,6 +1448,62 @@ struct Solver {
                     if (want_delta) { DYb[e] = dyb; DX[e] = xn - xo; }
                 }
             }
+            sync();
+            return;
+        }
+        if constexpr (kRowMap) {
+            // the same arithmetic per row and per variable as the element loop below, with the rows handed out compactly (one round)
+            const int ed = lane_row_dyn(), eb = lane_row_box();
+            const int t0 = opaque(tid);
+            // loads first
+            const int e0 = t0, e1 = t0 + kStride < NS * 8 ? t0 + kStride : t0;
+            const double xt0 = XT[e0], xo0 = X[e0], xt1 = XT[e1], xo1 = X[e1];
+            double xtd = 0.0, zd = 0.0, yd = 0.0, bd = 0.0, ei = 0.0, dot = 0.0;
+            if (ed >= 0) {
+                const int k = ed >> 3, r = ed & 7;
+                xtd = XT[ed]; zd = Zd[ed]; yd = Yd[ed]; bd = dyn_bound(ed); ei = Eid(k, r);
+                if constexpr (kMf) dot = k > 0 ? AT[ed] : 0.0;
+                else {
+                    const int kp = k > 0 ? k - 1 : 0;
+                    const double *row = tA + kp * kTS + r * 8, *sv = XT + kp * 8;
+                    const double acc0 = (row[0] * sv[0] + row[1] * sv[1]) + (row[2] * sv[2] + row[3] * sv[3]);
+                    const double acc1 = (row[4] * sv[4] + row[5] * sv[5]) + (row[6] * sv[6] + row[7] * sv[7]);
+                    dot = k > 0 ? acc0 + acc1 : 0.0;
+                }
+            }
+            double zb = 0.0, yb = 0.0, lo = 0.0, hi = 0.0, sb = 0.0, xv = 0.0;
+            if (eb >= 0) {
+                const int k = eb >> 3, r = eb & 7;
+                zb = Zb[eb]; yb = Yb[eb]; lo = Lo[eb]; hi = Hi[eb]; sb = Sb(k, r); xv = XT[k * 8 + box_var(r)];
+            }
+            // x update (168 variables: the second round fills 40 lanes)
+            const double xn0 = alpha * xt0 + oma * xo0, xn1 = alpha * xt1 + oma * xo1;
+            X[e0] = xn0;
+            if (want_delta) DX[e0] = xn0 - xo0;
+            if (t0 + kStride < NS * 8) { X[e1] = xn1; if (want_delta) DX[e1] = xn1 - xo1; }
+            if (ed >= 0) {          // dynamics row: bounds l = u = b
+                const double ztd = rmask_one(ei * xtd - dot);
+                const double zrd = alpha * ztd + oma * zd;
+                const double znd = bd;
+                const double dyd = rho_eq * (zrd - znd), ynd = yd + dyd;
+                Yd[ed] = ynd; Zd[ed] = znd; ZTd[ed] = rho_eq * znd - ynd;
+                if (want_delta) DYd[ed] = dyd;
+            }
+            if (eb >= 0) {          // box row
+                double w, winv;
+                if constexpr (kCacheW) { w = wbx[0]; winv = wbxi[0]; }
+                else {
+                    const bool loose = lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling, eq = hi - lo < kRhoTol;
+                    w = loose ? kRhoMin : (eq ? rho_eq : rho); winv = loose ? 1.0 / kRhoMin : (eq ? rinv_eq : rinv);
+                }
+                const double zrb = alpha * (sb * xv) + oma * zb;
+                const double znb = clipd(zrb + winv * yb, lo, hi);
+                const double dyb = w * (zrb - znb), ynb = yb + dyb;
+                Yb[eb] = ynb; Zb[eb] = znb; ZTb[eb] = w * znb - ynb;
+                if (want_delta) DYb[eb] = dyb;
+            }
+            // (the slots that hold no row are never written: z, y, delta_y and rho z - y stay at the zeros they were loaded with, which is
+            // what the element loop re-computes for them on every trip)
             sync();
             return;
         }
@@ -1724,10 +1803,18 @@ struct Solver {
             // (the two markers bracket the per-iteration code in the kept assembly: tools/check_kernel_resources.py counts the
             // scratch accesses and SGPR-spill lane moves between them)
             asm volatile("; LPVMPC_HOT_BEGIN");
+#ifdef LPVMPC_PHASE_ONLY
+            // diagnostic builds (tools/phase_pmc.sh): the loop runs ONE phase of the iteration (1 right-hand side, 2 KKT solve, 3 update;
+            // 0 none), so that the hardware counters of a launch can be attributed to it.  The iterates are meaningless.
+            if (LPVMPC_PHASE_ONLY == 1) build_rhs(sigma);
+            if (LPVMPC_PHASE_ONLY == 2) { if constexpr (TAIL) dense_apply(); else kkt_solve(); }
+            if (LPVMPC_PHASE_ONLY == 3) update(alpha, checked);
+#else
             build_rhs(sigma);
             STAMP(0);
             if constexpr (TAIL) { dense_apply(); STAMP(1); } else kkt_solve();
             update(alpha, checked);         // delta_x / delta_y are only read by the infeasibility tests
+#endif
             asm volatile("; LPVMPC_HOT_END");
             STAMP(3);
             if (checked || adapt) {
