@@ -899,6 +899,22 @@ struct Solver {
             }
             sync();
         }
+        // the staging area is free until the next build: it now holds the dynamics rows of the scaled [A|B] tiles again, ten doubles per
+        // row and sixty per stage, for the update phase (prev_stage_dot_pad) -- at eight doubles per row, as the tiles are stored, the
+        // eight lanes of a stage read rows that sit 16 banks apart and every fourth row of the 16 lanes of a pass lands on the same
+        // banks; at ten (and 60 per stage: 56 banks on) the twelve rows of a pass tile the banks exactly
+        for (int i = tid; i < N * 48; i += kStride) { const int k = i / 48, r = (i - 48 * k) >> 3, a_ = i & 7; STG[k * 60 + r * 10 + a_] = tA[k * kTS + r * 8 + a_]; }
+        sync();
+    }
+    // dynamics-row product of the previous stage like prev_stage_dot, rows read from the padded copy dense_build leaves in STG
+    __device__ __forceinline__ double prev_stage_dot_pad(int k, const double *v) const {
+        const int kp = k > 0 ? k - 1 : 0;
+        const double *row = STG + kp * 60 + (tj < NX ? tj : 0) * 10, *sv = v + kp * 8;
+        const double r0_ = row[0], r1_ = row[1], r2_ = row[2], r3_ = row[3], r4_ = row[4], r5_ = row[5], r6_ = row[6], r7_ = row[7];
+        const double s0_ = sv[0], s1_ = sv[1], s2_ = sv[2], s3_ = sv[3], s4_ = sv[4], s5_ = sv[5], s6_ = sv[6], s7_ = sv[7];
+        const double acc0 = (r0_ * s0_ + r1_ * s1_) + (r2_ * s2_ + r3_ * s3_);
+        const double acc1 = (r4_ * s4_ + r5_ * s5_) + (r6_ * s6_ + r7_ * s7_);
+        return k > 0 ? acc0 + acc1 : 0.0;
     }
     // XT <- K^-1 VT (the KKT solve of an ADMM iteration in the tail kernel)
     __device__ __forceinline__ void dense_apply() {
@@ -1425,7 +1441,7 @@ struct Solver {
                 if (e < NS * 8) {
                     const int k = e >> 3;
                     const double xt = XT[e], zd = Zd[e], yd = Yd[e], b = dyn_bound(e), ei = Eid(k, tj);
-                    const double dot = prev_stage_dot(k, XT);
+                    const double dot = prev_stage_dot_pad(k, XT);
                     const double ztd = rmask * (ei * xt - dot);
                     const double zrd = alpha * ztd + oma * zd;
                     const double znd = b;

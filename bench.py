@@ -514,8 +514,8 @@ def other_workloads(args, rank, local_rank, world, dev):
     dominant kernel, its mean launch time and the iteration means, the same code paths as --workload cfg3 / cfg4 / cfg5."""
     import copy
     res = {}
-    legs = (("configs[2]", dict(workload="cfg3", batch=4096, steps=2, warmup=1, streams=2, defer=0, lane_cus=0)),
-            ("configs[3]", dict(workload="cfg4", batch=8192, steps=2, warmup=1, streams=2, defer=0, lane_cus=0)),
+    legs = (("configs[2]", dict(workload="cfg3", batch=4096, steps=8, warmup=2, streams=4, defer=0, lane_cus=0)),
+            ("configs[3]", dict(workload="cfg4", batch=8192, steps=6, warmup=2, streams=3, defer=0, lane_cus=0)),
             ("configs[4]", dict(workload="cfg5", batch=8192, steps=60, warmup=2, defer=0, lane_cus=0)))
     for name, kw in legs:
         a = copy.copy(args)
