@@ -82,7 +82,7 @@ struct Solver {
     double *Zd, *Yd, *Ed, *ZTd, *DYd;
     double *Zb, *Yb, *Eb, *ZTb, *DYb, *Lo, *Hi;
     double *beq;   // [8] scaled x0 (bounds of the stage-0 dynamics rows)
-    double *SINK;  // [64 + 8 NS] write-only dump for the lanes that do not own a result (avoids exec masking)
+    double *SINK;  // [64 + 8 NS] scratch (the factorisation hands a tile from wave 0 to wave 1 through it); part of the parked image, so its size stays
     double *Pm;    // [64] unscaled stage Hessian block 2*[Q 0; 0 R + 2 diag(dR)] (LDS copy of the weights)
     double *dRl;   // [8]  dR[0..1]
     double *RED;   // [80] per-wave partial results of block-wide reductions / chain hand-over (NW == 2)
@@ -117,18 +117,13 @@ struct Solver {
     static constexpr bool kGs = GS;                 // the equilibration vectors D / Ed / Eb live in global memory (SolveArgs::scal)
     static_assert(!GS || (NW == 2 && NT > 20 && !MF), "global scalings: planner two-wavefront kernels only");
     static constexpr bool kCacheW = (kReg && !GS && (MF || (NW == 2 && NT > 20))) || TAIL;   // (the N <= 20 DPP / one-wave instantiations have no registers to spare)
-    // Row-compact update (controller, N = 20, two wavefronts): the 126 dynamics rows and the 120 box rows (+ the pinned-steering rows of
-    // the first `delay` stages) each fit ONE round of the 128 lanes when lane l takes row (l / 6, l % 6), instead of the two rounds
-    // of the element loop (thread <-> (stage, slot) with 8 slots per stage: 168 elements, of which the second round fills 40 lanes);
-    // only the x update still walks the 168 variables.  The row of a lane sits in bits 17.. of lpack.
-    static constexpr bool kRowMap = kCtrl && NT == 20 && NW == 2 && !TAIL;
-    static constexpr int kRnd = kCacheW ? (kRowMap ? 1 : ((NT + 1) * 8 + kStride - 1) / kStride) : 1;
+    static constexpr int kRnd = kCacheW ? ((NT + 1) * 8 + kStride - 1) / kStride : 1;
     double wbx[kRnd], wbxi[kRnd];
     __device__ __forceinline__ void cache_box_weights() {
         if constexpr (kCacheW) {
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
-                const int e = kRowMap ? lane_row_box() : tid + r * kStride - (TAIL ? kBoxT0 : 0);      // (tail kernel: the box rows belong to the threads from kBoxT0 on, see update)
+                const int e = tid + r * kStride - (TAIL ? kBoxT0 : 0);      // (tail kernel: the box rows belong to the threads from kBoxT0 on, see update)
                 double w = rho, wi = rinv;
                 if (e >= 0 && e < NS * 8) {
                     const double lo = Lo[e], hi = Hi[e];
@@ -146,14 +141,6 @@ struct Solver {
         l.r0 = lp & 15; l.r1 = (lp >> 4) & 15; l.r2 = (lp >> 8) & 15; l.bvar = (lp >> 12) & 15;
         l.rmask = ((lp >> 16) & 1) ? 1.0 : 0.0;
         return l;
-    }
-
-    // kRowMap: vector index 8 k + r of the dynamics row / box row this lane updates (-1: none).  Lanes 0 .. 125 <-> rows (l / 6, l % 6);
-    // box rows exist on the stages k < N (lanes 0 .. 119), lanes 120 + k take the pinned-steering row (k, 6) of the stages k < delay
-    __device__ __forceinline__ int lane_row_dyn() const { const int t = opaque(tid); return t < 126 ? (opaque(lpack) >> 17) & 255 : -1; }
-    __device__ __forceinline__ int lane_row_box() const {
-        const int t = opaque(tid);
-        return t < 120 ? (opaque(lpack) >> 17) & 255 : (t - 120 < delay ? 8 * (t - 120) + 6 : -1);
     }
 
     __device__ __forceinline__ Solver(const DevCfg &cf, double *smem)
@@ -184,7 +171,6 @@ struct Solver {
             int first, cnt; rows_on(tj, first, cnt);
             const int r0 = cnt >= 1 ? first : 7, r1 = cnt >= 2 ? first + 1 : 7, r2 = (kCtrl && tj == 6) ? 6 : 7;
             lpack = r0 | (r1 << 4) | (r2 << 8) | (box_var(tj) << 12) | ((tj < NX ? 1 : 0) << 16);
-            if constexpr (kRowMap) { const int t = threadIdx.x; lpack |= (8 * (t / 6) + t % 6) << 17; }
         }
         c = 1.0; cinv = 1.0; pol = false; rho = rho_eq = rinv = rinv_eq = 0.0; rSm = rLt = rLb = 0.0;
         {   // lane (r, b = 2I + J, c) of an A operand: type A step T[4J + c][4I + r], type B step T[4I + c][4J + r]
@@ -955,8 +941,9 @@ struct Solver {
     template <bool BOT, bool STASHED>
     __device__ __forceinline__ void twisted_forward() {
         constexpr int P = BOT ? kP1 : kP0;
-        double *const vrow = (ti == 0) ? VT + tj : SINK + lane;
-        double *const vcol = (tj == 0) ? VT + ti : SINK + lane;
+        // (an all-reduce leaves its result in every lane of the group: all of them store it, to one address -- no select, no dump area; see mf_forward)
+        double *const vrow = VT + tj;
+        double *const vcol = VT + ti;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         // The right-hand side of the middle stage is read by BOTH waves in the backward sweep while wave 0 stores x_m
         // over it: keep a copy where nobody writes (RED[48..55]) so that a late wave 1 cannot pick up x_m instead.
@@ -999,8 +986,8 @@ struct Solver {
     template <bool BOT>
     __device__ __forceinline__ void twisted_backward() {
         constexpr int P = BOT ? kP1 : kP0;
-        double *const xrow = (ti == 0) ? XT + tj : SINK + lane;
-        double *const xcol = (tj == 0) ? XT + ti : SINK + lane;
+        double *const xrow = XT + tj;
+        double *const xcol = XT + ti;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         const double link = BOT ? rLb : rLt;
         double xc = 0.0, xr = 0.0;
@@ -1062,12 +1049,16 @@ struct Solver {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         const MfLane m = mf_lane();
-        const bool c0 = (m.ln & 3) == 0;
         if (!STASHED && !BOT && m.ln < 8) RED[48 + m.ln] = XT[kMid * 8 + m.ln];   // the middle right-hand side survives x_m (see twisted_forward)
         // a type A step delivers layout B: right-hand side element eB in the blocks stB, results stored by the lanes c = 0 of them
         const double *const csA = XT + m.eB, *const csB = XT + m.eA;
-        double *const vsA = (c0 && m.stB) ? VT + m.eB : SINK + m.ln;
-        double *const vsB = (c0 && m.stA) ? VT + m.eA : SINK + m.ln;
+        // Every lane holds a finished replica of its element after mf_close (both blocks of a pair end with the whole sum, the
+        // columns c are identical): all 64 lanes store it to the element's own address -- eight addresses, eight lanes each, no
+        // select and no dump area.  (Lanes that hit one address cost nothing; the earlier form, owner lanes to the vector and
+        // the other 56 to a per-lane dump, took the same 6-8 cycles per store but collided with the dump's banks:
+        // profiles/r04_microbench_lds_store.txt, r04_phase_pmc.txt.)
+        double *const vsA = VT + m.eB;
+        double *const vsB = VT + m.eA;
         double Y = XT[stage(0) * 8 + m.eA];
         double bq[3];                                                       // right-hand sides are fetched two steps ahead
         bq[1] = csA[stage(1) * 8];
@@ -1096,21 +1087,19 @@ struct Solver {
         constexpr bool la = (P & 1) != 0;
         const double dl = mfma4(fC[P - 1], Y, 0.0), dv = mfma4(fV[P - 1], Y, 0.0);
         (la ? vsA : vsB)[stage(P - 1) * 8] = mf_close<la>(dv);
-        double *const cst = (c0 && (la ? m.stB : m.stA)) ? RED + 32 + (BOT ? 8 : 0) + (la ? m.eB : m.eA) : SINK + m.ln;
-        *cst = mf_close<la>(dl);
+        RED[32 + (BOT ? 8 : 0) + (la ? m.eB : m.eA)] = mf_close<la>(dl);
     }
     template <bool BOT>
     __device__ __forceinline__ void mf_backward() {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         const MfLane m = mf_lane();
-        const bool c0 = (m.ln & 3) == 0;
         // backward step p consumes x at chain position p + 1; x_m arrives in layout B, so step p is of type B iff P - 1 - p is even
         const double *const vsA = VT + m.eB, *const vsB = VT + m.eA;         // v_p enters as C of the owner blocks of the OUTPUT layout
-        double *const xsA = (c0 && m.stB) ? XT + m.eB : SINK + m.ln;         // results of a type A step (layout B)
-        double *const xsB = (c0 && m.stA) ? XT + m.eA : SINK + m.ln;
-        double *const asA = (c0 && m.stB) ? AT + (BOT ? 0 : 16) + m.eB : SINK + m.ln;   // [A|B]_k x_k, filed under the dynamics rows of stage k + 1
-        double *const asB = (c0 && m.stA) ? AT + (BOT ? 0 : 16) + m.eA : SINK + m.ln;
+        double *const xsA = XT + m.eB;         // results of a type A step (layout B); every lane stores its replica (see mf_forward)
+        double *const xsB = XT + m.eA;
+        double *const asA = AT + (BOT ? 0 : 16) + m.eB;   // [A|B]_k x_k, filed under the dynamics rows of stage k + 1
+        double *const asB = AT + (BOT ? 0 : 16) + m.eA;
         auto typeB = [](int p) constexpr { return ((P - 1 - p) & 1) == 0; };
         double vq[3];                                                       // pivot products are fetched two steps ahead
         vq[(P - 1) % 3] = vsB[stage(P - 1) * 8];
@@ -1118,7 +1107,7 @@ struct Solver {
         // middle stage, on both waves: x_m = S_m^-1 (b_m - L_t y_{m-1} - L_b y_{m+1}); type A step, x_m in layout B
         const double ym = RED[48 + m.eA] + (RED[32 + m.eA] + RED[40 + m.eA]);
         double X = mf_close<true>(mfma4(mS, ym, 0.0));
-        *((!BOT && c0 && m.stB) ? XT + kMid * 8 + m.eB : SINK + m.ln) = X;
+        if constexpr (!BOT) XT[kMid * 8 + m.eB] = X;
         double dal = 0.0;                                                   // dynamics-row product of the previous step, not yet closed
 #pragma unroll
         for (int p = P - 1; p >= 0; --p) {
@@ -1130,13 +1119,13 @@ struct Solver {
             const bool keep = BOT || p + 1 != P - 1;
             if (typeB(p)) {
                 const double dc = mfma4(bC[p], X, m.stA ? vl : 0.0), da = mfma4(bA[p], X, 0.0);
-                if (p <= P - 2) (keep ? asA : SINK + m.ln)[keep ? stage(p + 1) * 8 : 0] = mf_close<true>(dal);
+                if (p <= P - 2 && keep) asA[stage(p + 1) * 8] = mf_close<true>(dal);
                 X = mf_close<false>(dc);
                 xsB[stage(p) * 8] = X;
                 dal = da;
             } else {
                 const double dc = mfma4(bC[p], X, m.stB ? vl : 0.0), da = mfma4(bA[p], X, 0.0);
-                if (p <= P - 2) (keep ? asB : SINK + m.ln)[keep ? stage(p + 1) * 8 : 0] = mf_close<false>(dal);
+                if (p <= P - 2 && keep) asB[stage(p + 1) * 8] = mf_close<false>(dal);
                 X = mf_close<true>(dc);
                 xsA[stage(p) * 8] = X;
                 dal = da;
@@ -1144,12 +1133,11 @@ struct Solver {
         }
         {   // product of step 0 (type B iff P - 1 is even)
             constexpr bool keep = BOT || 0 != P - 1;
-            if (typeB(0)) (keep ? asB : SINK + m.ln)[keep ? stage(0) * 8 : 0] = mf_close<false>(dal);
-            else          (keep ? asA : SINK + m.ln)[keep ? stage(0) * 8 : 0] = mf_close<true>(dal);
+            if constexpr (keep) { if (typeB(0)) asB[stage(0) * 8] = mf_close<false>(dal); else asA[stage(0) * 8] = mf_close<true>(dal); }
         }
         if (!BOT) {     // [A|B]_0 x_0 -> dynamics rows of stage 1; x_0 is in layout B iff P is even
             constexpr bool tb = (P & 1) == 0;
-            *((c0 && (tb ? m.stA : m.stB)) ? AT + 8 + (tb ? m.eA : m.eB) : SINK + m.ln) = mf_close<!tb>(mfma4(tT, X, 0.0));
+            AT[8 + (tb ? m.eA : m.eB)] = mf_close<!tb>(mfma4(tT, X, 0.0));
         }
     }
 
@@ -1174,12 +1162,12 @@ struct Solver {
             return;
         }
         if constexpr (kReg) {
-            // Results of a reduction are replicated over 8 lanes; the owner lane stores to the vector, the
-            // other seven to SINK (same instruction, no exec masking).  Offsets 8*k are immediates.
-            double *const vrow = (ti == 0) ? VT + tj : SINK + lane;      // row-form results   (component tj)
-            double *const vcol = (tj == 0) ? VT + ti : SINK + lane;      // column-form results (component ti)
-            double *const xrow = (ti == 0) ? XT + tj : SINK + lane;
-            double *const xcol = (tj == 0) ? XT + ti : SINK + lane;
+            // Results of a reduction are replicated over 8 lanes: all eight store it, to the one address (no exec masking, no
+            // select).  Offsets 8*k are immediates.
+            double *const vrow = VT + tj;      // row-form results   (component tj)
+            double *const vcol = VT + ti;      // column-form results (component ti)
+            double *const xrow = XT + tj;
+            double *const xcol = XT + ti;
             // forward sweep y_k = b_k - L_k y_{k-1}, with the pivot products v_k = S_k^-1 y_k (off the
             // dependent chain) issued alongside; only v goes to LDS, y stays in registers.
             double yc = XT[ti], yr = 0.0;
@@ -1333,7 +1321,6 @@ struct Solver {
         return v;
     }
 
-    __device__ __forceinline__ static double rmask_one(double v) { return v; }       // (rmask = 1 on a real row: 1.0 * v == v, bit for bit)
     // bounds of a dynamics row (equalities: l = u)
     __device__ __forceinline__ double dyn_bound(int e) const { return beq[e < 8 ? e : 8]; }
 
@@ -1464,62 +1451,6 @@ struct Solver {
                     if (want_delta) { DYb[e] = dyb; DX[e] = xn - xo; }
                 }
             }
-            sync();
-            return;
-        }
-        if constexpr (kRowMap) {
-            // the same arithmetic per row and per variable as the element loop below, with the rows handed out compactly (one round)
-            const int ed = lane_row_dyn(), eb = lane_row_box();
-            const int t0 = opaque(tid);
-            // loads first
-            const int e0 = t0, e1 = t0 + kStride < NS * 8 ? t0 + kStride : t0;
-            const double xt0 = XT[e0], xo0 = X[e0], xt1 = XT[e1], xo1 = X[e1];
-            double xtd = 0.0, zd = 0.0, yd = 0.0, bd = 0.0, ei = 0.0, dot = 0.0;
-            if (ed >= 0) {
-                const int k = ed >> 3, r = ed & 7;
-                xtd = XT[ed]; zd = Zd[ed]; yd = Yd[ed]; bd = dyn_bound(ed); ei = Eid(k, r);
-                if constexpr (kMf) dot = k > 0 ? AT[ed] : 0.0;
-                else {
-                    const int kp = k > 0 ? k - 1 : 0;
-                    const double *row = tA + kp * kTS + r * 8, *sv = XT + kp * 8;
-                    const double acc0 = (row[0] * sv[0] + row[1] * sv[1]) + (row[2] * sv[2] + row[3] * sv[3]);
-                    const double acc1 = (row[4] * sv[4] + row[5] * sv[5]) + (row[6] * sv[6] + row[7] * sv[7]);
-                    dot = k > 0 ? acc0 + acc1 : 0.0;
-                }
-            }
-            double zb = 0.0, yb = 0.0, lo = 0.0, hi = 0.0, sb = 0.0, xv = 0.0;
-            if (eb >= 0) {
-                const int k = eb >> 3, r = eb & 7;
-                zb = Zb[eb]; yb = Yb[eb]; lo = Lo[eb]; hi = Hi[eb]; sb = Sb(k, r); xv = XT[k * 8 + box_var(r)];
-            }
-            // x update (168 variables: the second round fills 40 lanes)
-            const double xn0 = alpha * xt0 + oma * xo0, xn1 = alpha * xt1 + oma * xo1;
-            X[e0] = xn0;
-            if (want_delta) DX[e0] = xn0 - xo0;
-            if (t0 + kStride < NS * 8) { X[e1] = xn1; if (want_delta) DX[e1] = xn1 - xo1; }
-            if (ed >= 0) {          // dynamics row: bounds l = u = b
-                const double ztd = rmask_one(ei * xtd - dot);
-                const double zrd = alpha * ztd + oma * zd;
-                const double znd = bd;
-                const double dyd = rho_eq * (zrd - znd), ynd = yd + dyd;
-                Yd[ed] = ynd; Zd[ed] = znd; ZTd[ed] = rho_eq * znd - ynd;
-                if (want_delta) DYd[ed] = dyd;
-            }
-            if (eb >= 0) {          // box row
-                double w, winv;
-                if constexpr (kCacheW) { w = wbx[0]; winv = wbxi[0]; }
-                else {
-                    const bool loose = lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling, eq = hi - lo < kRhoTol;
-                    w = loose ? kRhoMin : (eq ? rho_eq : rho); winv = loose ? 1.0 / kRhoMin : (eq ? rinv_eq : rinv);
-                }
-                const double zrb = alpha * (sb * xv) + oma * zb;
-                const double znb = clipd(zrb + winv * yb, lo, hi);
-                const double dyb = w * (zrb - znb), ynb = yb + dyb;
-                Yb[eb] = ynb; Zb[eb] = znb; ZTb[eb] = w * znb - ynb;
-                if (want_delta) DYb[eb] = dyb;
-            }
-            // (the slots that hold no row are never written: z, y, delta_y and rho z - y stay at the zeros they were loaded with, which is
-            // what the element loop re-computes for them on every trip)
             sync();
             return;
         }
