@@ -82,7 +82,8 @@ struct Solver {
     double *Zd, *Yd, *Ed, *ZTd, *DYd;
     double *Zb, *Yb, *Eb, *ZTb, *DYb, *Lo, *Hi;
     double *beq;   // [8] scaled x0 (bounds of the stage-0 dynamics rows)
-    double *SINK;  // [64 + 8 NS] scratch (the factorisation hands a tile from wave 0 to wave 1 through it); part of the parked image, so its size stays
+    double *SINK;  // [64 + 8 NS] all zero in the MFMA kernels (their sweeps load the C operand of non-owner blocks from it); the DPP two-wavefront
+                   // factorisation hands a tile from wave 0 to wave 1 through it; part of the parked image
     double *Pm;    // [64] unscaled stage Hessian block 2*[Q 0; 0 R + 2 diag(dR)] (LDS copy of the weights)
     double *dRl;   // [8]  dR[0..1]
     double *RED;   // [80] per-wave partial results of block-wide reductions / chain hand-over (NW == 2)
@@ -1051,7 +1052,9 @@ struct Solver {
         const MfLane m = mf_lane();
         if (!STASHED && !BOT && m.ln < 8) RED[48 + m.ln] = XT[kMid * 8 + m.ln];   // the middle right-hand side survives x_m (see twisted_forward)
         // a type A step delivers layout B: right-hand side element eB in the blocks stB, results stored by the lanes c = 0 of them
-        const double *const csA = XT + m.eB, *const csB = XT + m.eA;
+        // the right-hand side enters as the C operand of the owner blocks only: the other blocks load their "right-hand side" from the
+        // all-zero area (SINK, same immediate offsets) instead of selecting 0 in front of every MFMA
+        const double *const csA = m.stB ? XT + m.eB : SINK, *const csB = m.stA ? XT + m.eA : SINK;
         // Every lane holds a finished replica of its element after mf_close (both blocks of a pair end with the whole sum, the
         // columns c are identical): all 64 lanes store it to the element's own address -- eight addresses, eight lanes each, no
         // select and no dump area.  (Lanes that hit one address cost nothing; the earlier form, owner lanes to the vector and
@@ -1071,12 +1074,12 @@ struct Solver {
             __builtin_amdgcn_sched_barrier(0);          // keep the fetch up here: sunk to its use, every step waits for LDS
             // the previous step's pivot product is closed and stored in the shadow of this step's MFMAs
             if (p & 1) {
-                const double dc = mfma4(fC[p - 1], Y, m.stB ? bl : 0.0), dv = mfma4(fV[p - 1], Y, 0.0);
+                const double dc = mfma4(fC[p - 1], Y, bl), dv = mfma4(fV[p - 1], Y, 0.0);
                 if (p >= 2) vsB[stage(p - 2) * 8] = mf_close<false>(dvl);
                 Y = mf_close<true>(dc);
                 dvl = dv;
             } else {
-                const double dc = mfma4(fC[p - 1], Y, m.stA ? bl : 0.0), dv = mfma4(fV[p - 1], Y, 0.0);
+                const double dc = mfma4(fC[p - 1], Y, bl), dv = mfma4(fV[p - 1], Y, 0.0);
                 vsA[stage(p - 2) * 8] = mf_close<true>(dvl);
                 Y = mf_close<false>(dc);
                 dvl = dv;
@@ -1095,7 +1098,7 @@ struct Solver {
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         const MfLane m = mf_lane();
         // backward step p consumes x at chain position p + 1; x_m arrives in layout B, so step p is of type B iff P - 1 - p is even
-        const double *const vsA = VT + m.eB, *const vsB = VT + m.eA;         // v_p enters as C of the owner blocks of the OUTPUT layout
+        const double *const vsA = m.stB ? VT + m.eB : SINK, *const vsB = m.stA ? VT + m.eA : SINK;         // v_p enters as C of the owner blocks of the OUTPUT layout (the others read zeros: see mf_forward)
         double *const xsA = XT + m.eB;         // results of a type A step (layout B); every lane stores its replica (see mf_forward)
         double *const xsB = XT + m.eA;
         double *const asA = AT + (BOT ? 0 : 16) + m.eB;   // [A|B]_k x_k, filed under the dynamics rows of stage k + 1
@@ -1118,13 +1121,13 @@ struct Solver {
             // step multiplies [A|B]_kMid x_m: wave 1 files it, wave 0 drops it
             const bool keep = BOT || p + 1 != P - 1;
             if (typeB(p)) {
-                const double dc = mfma4(bC[p], X, m.stA ? vl : 0.0), da = mfma4(bA[p], X, 0.0);
+                const double dc = mfma4(bC[p], X, vl), da = mfma4(bA[p], X, 0.0);
                 if (p <= P - 2 && keep) asA[stage(p + 1) * 8] = mf_close<true>(dal);
                 X = mf_close<false>(dc);
                 xsB[stage(p) * 8] = X;
                 dal = da;
             } else {
-                const double dc = mfma4(bC[p], X, m.stB ? vl : 0.0), da = mfma4(bA[p], X, 0.0);
+                const double dc = mfma4(bC[p], X, vl), da = mfma4(bA[p], X, 0.0);
                 if (p <= P - 2 && keep) asB[stage(p + 1) * 8] = mf_close<false>(dal);
                 X = mf_close<true>(dc);
                 xsA[stage(p) * 8] = X;
@@ -1650,6 +1653,7 @@ struct Solver {
             if (tid < 8) dRl[tid] = tid < 2 ? cfg.dR[tid] : 0.0;
         }
         for (int e = tid; e < NS * kTS; e += kStride) { tA[e] = 0.0; }
+        for (int e = tid; e < 64 + 8 * NS; e += kStride) SINK[e] = 0.0;        // the MFMA sweeps read their zeros here (nothing writes it in those kernels)
         for (int e = opaque(tid); e < NS * 8; e += kStride) {
             X[e] = 0; D[e] = 1.0; DX[e] = 0; Zd[e] = 0; Yd[e] = 0; Ed[e] = 1.0; DYd[e] = 0; ZTd[e] = 0;
             Zb[e] = 0; Yb[e] = 0; Eb[e] = 1.0; DYb[e] = 0; Lo[e] = 0; Hi[e] = 0; Qv[e] = 0; ZTb[e] = 0;
