@@ -746,9 +746,11 @@ def dry_run(args):
     ok = bool(g_u0.shape == (total, 2) and np.array_equal(g_u0[:, 0], np.arange(total)) and int(g_iters.sum()) == int(agg[0])
               and int(agg[1]) == total and g_status.shape == (total,))
     if rank == 0:
+        strong = args.scaling == "strong" and world > 1 and args.workload == "cfg2"
         print(json.dumps({"metric": "MPC solves/sec (N=20, nx=6, nu=2)", "value": None, "unit": "solves/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": "weak",
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": "strong" if strong else "weak",
                           "config": {"workload": args.workload, "global_instances": total, "shard_rank0": [a, b],
+                                     "steps_rank0": list(shard_range(args.steps, 0, world)) if strong else [0, args.steps], "rccl_world": world,
                                      "max_elapsed_s": elapsed, "gather_ok": ok}}), flush=True)
     if world > 1:
         dist.destroy_process_group()

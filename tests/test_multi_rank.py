@@ -73,6 +73,16 @@ def test_bench_launcher_spawns_one_rank_per_gpu():
 
 
 @pytest.mark.timeout(300)
+def test_bench_strong_scaling_cuts_the_steps_over_the_ranks():
+    """--scaling strong: ONE sequence of steps is split contiguously over the ranks (the line says so); the default stays weak."""
+    import sys
+    out = _bench_line([sys.executable, "bench.py", "--gpus", "2", "--dry-run", "--scaling", "strong", "--steps", "20", "--warmup", "4"])
+    assert out["scaling"] == "strong" and out["config"]["steps_rank0"] == [0, 10] and out["config"]["rccl_world"] == 2
+    out = _bench_line([sys.executable, "bench.py", "--gpus", "2", "--dry-run", "--steps", "20", "--warmup", "4"])
+    assert out["scaling"] == "weak" and out["config"]["steps_rank0"] == [0, 20]
+
+
+@pytest.mark.timeout(300)
 def test_bench_under_the_drivers_launcher():
     """The driver's form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2."""
     import sys
