@@ -52,14 +52,32 @@ struct Solver {
     static constexpr bool kTwo = (NW == 2);         // two wavefronts per instance: two-sided ("twisted") elimination
     static constexpr bool kRing = !TAIL && NT == 20 && NW == 2;     // may park into the long-runner ring: the kernels whose image the tail kernel continues
     static constexpr bool kMf = MF;                 // the two sweeps run on the matrix cores (v_mfma_f64_4x4x4_4b_f64), see mf_forward
-    static_assert(!MF || (NW == 2 && NT > 0), "the MFMA sweeps are written for the two-wavefront compile-time-horizon kernels");
-    static_assert(TAIL || NW == 1 || (NW == 2 && NT >= 16 && NT % 2 == 0), "two wavefronts need an even compile-time horizon >= 16");
+    // FOUR wavefronts per instance (round 4; planner N = 40 / 30): the same two chains, each RELAYED over two wavefronts -- the
+    // "outer" wavefront of a chain (0: top, 1: bottom) holds the operand tiles of chain positions 0 .. kHO-1, the "inner" one
+    // (2 / 3) those of kHO .. kMid-1 -- so a wavefront keeps half of the factor (<= 256 registers: two wavefronts per SIMD), the
+    // element phases run on 256 threads, and the half of them that does not touch the stages a running sweep works on is done BESIDE
+    // that sweep by the two wavefronts that wait for the relay (iterate4).  Same arithmetic, step for step, as the two-wavefront kernel.
+    static constexpr bool kFour = (NW == 4) && !TAIL;
+    static_assert(!MF || ((NW == 2 || NW == 4) && NT > 0), "the MFMA sweeps are written for the two- / four-wavefront compile-time-horizon kernels");
+    static_assert(NW != 4 || TAIL || (MF && !GS && NT >= 24 && NT % 2 == 0), "four wavefronts: MFMA sweeps, even compile-time horizon >= 24");
+    static_assert(TAIL || NW == 1 || NW == 4 || (NW == 2 && NT >= 16 && NT % 2 == 0), "two wavefronts need an even compile-time horizon >= 16");
     static_assert(!TAIL || (NT > 0 && NW == 8 && !MF && !GS), "the tail kernel: compile-time horizon, eight wavefronts, no MFMA sweeps");
     static constexpr bool kLastOdd = ((NT / 2 - 1) & 1) != 0;   // parity of the last chain position (both chains have NT/2 stages)
     static constexpr int kMid = NT / 2;             // NW == 2: wave 0 eliminates stages 0..kMid-1 upwards, wave 1 stages
     static constexpr int kP0 = kMid, kP1 = NT - kMid;   //         NT..kMid+1 downwards; stage kMid joins the two chains
     static constexpr int kRS = (kReg && !MF) ? (kTwo ? (kP1 > kP0 ? kP1 : kP0) : NT + 1) : 1;
-    static constexpr int kMP = MF ? kMid : 1;       // chain positions per wavefront in the MFMA sweeps
+    static constexpr int kHO = (kMid + 1) / 2;      // NW == 4: operand tiles [0, kHO) on the outer wavefront of a chain, [kHO, kMid) on the inner one
+    static constexpr int kMP = MF ? (kFour ? kHO : kMid) : 1;       // chain positions per wavefront in the MFMA sweeps
+    // NW == 4: the element phases of an ADMM iteration (right-hand side, update) are cut into set 2 -- kS2n stages of each chain's inner
+    // half, from kS2a upwards (top chain, wavefront 2) and from kS2b upwards (bottom chain, wavefront 3), one element per lane: nobody but
+    // the owning wavefront's forward steps reads their right-hand side, and their x~ and [A|B] x~ are that wavefront's own backward
+    // results (chain positions kHO + 2 .. kMid - 1) -- and set 1, the rest, one element per thread of the workgroup
+    static constexpr int kS2n = kMid - kHO - 2 < 8 ? kMid - kHO - 2 : 8;
+    static constexpr int kS2a = kHO + 2, kS2b = NT - kHO - 1 - kS2n;
+    static_assert(!kFour || (kS2n >= 1 && (NT + 1) * 8 - 16 * kS2n <= 256 && kS2a + kS2n <= kMid && kS2b > kMid && kS2b + kS2n - 1 == NT - kHO - 2), "four wavefronts: element sets do not fit");
+    // RED (doubles): [0, 80) as in the two-wavefront kernels; NW == 4 adds [80, 112) residual maxima of four wavefronts, [112, 144) four
+    // reduction slots {sum x 4, max x 4}, [144, 160) the relay of the forward sweeps (y at chain position kHO, top / bottom)
+    static constexpr int kRedSize = kFour ? 160 : 80;
     static constexpr int kStride = 64 * NW;
 
     const DevCfg &cfg;
@@ -118,13 +136,25 @@ struct Solver {
     static constexpr bool kGs = GS;                 // the equilibration vectors D / Ed / Eb live in global memory (SolveArgs::scal)
     static_assert(!GS || (NW == 2 && NT > 20 && !MF), "global scalings: planner two-wavefront kernels only");
     static constexpr bool kCacheW = (kReg && !GS && (MF || (NW == 2 && NT > 20))) || TAIL;   // (the N <= 20 DPP / one-wave instantiations have no registers to spare)
-    static constexpr int kRnd = kCacheW ? ((NT + 1) * 8 + kStride - 1) / kStride : 1;
+    static constexpr int kRnd = kCacheW ? (kFour ? 2 : ((NT + 1) * 8 + kStride - 1) / kStride) : 1;
     double wbx[kRnd], wbxi[kRnd];
+    // NW == 4: element of set 1 / set 2 (see kS2n) that thread t owns in the right-hand side and update phases (>= 8 NS: none)
+    __device__ __forceinline__ static int elem_set1(int t) {
+        int e = t;
+        if (e >= 8 * kS2a) e += 8 * kS2n;
+        if (e >= 8 * kS2b) e += 8 * kS2n;
+        return e;
+    }
+    __device__ __forceinline__ static int elem_set2(int t) {
+        const int l = t & 63, w = t >> 6;
+        return (w >= 2 && l < 8 * kS2n) ? 8 * (w == 2 ? kS2a : kS2b) + l : 8 * (NT + 1);
+    }
     __device__ __forceinline__ void cache_box_weights() {
         if constexpr (kCacheW) {
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
-                const int e = tid + r * kStride - (TAIL ? kBoxT0 : 0);      // (tail kernel: the box rows belong to the threads from kBoxT0 on, see update)
+                const int e = kFour ? (r == 0 ? elem_set1(tid) : elem_set2(tid))
+                                    : tid + r * kStride - (TAIL ? kBoxT0 : 0);      // (tail kernel: the box rows belong to the threads from kBoxT0 on, see update)
                 double w = rho, wi = rinv;
                 if (e >= 0 && e < NS * 8) {
                     const double lo = Lo[e], hi = Hi[e];
@@ -163,7 +193,7 @@ struct Solver {
             D = Ed = Eb = nullptr;
         }
         Lo = p; p += V; Hi = p; p += V;
-        beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; RED = p; p += 80; SINK = p; p += 64 + 8 * NS;
+        beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; RED = p; p += kRedSize; SINK = p; p += 64 + 8 * NS;
         RT = WS = STG = nullptr;
         if constexpr (TAIL) {   // behind the image: factor tiles, reduction slots, sweep scratch, staging
             tS = p; p += NS * kTS; tL = p; p += NS * kTS; RT = p; p += 96; WS = p; p += NW * 128; STG = p; p += kDenseRound * NS * 64;
@@ -185,7 +215,7 @@ struct Solver {
     }
     // the part of the LDS block that a pool entry carries (try_park / restore): everything up to and including SINK
     static constexpr __host__ __device__ size_t image_doubles(int N) {
-        return (size_t)(N + 1) * ((kFixN ? 1 : 3) * kTS + (GS ? 16 : 19) * 8 + 8) + 16 + 64 + 8 + 80 + 64;
+        return (size_t)(N + 1) * ((kFixN ? 1 : 3) * kTS + (GS ? 16 : 19) * 8 + 8) + 16 + 64 + 8 + kRedSize + 64;
     }
     // offset (doubles) of the tail kernel's RT area in the LDS block (ring_drain_kernel reads the trace words an entry leaves there)
     static constexpr __host__ __device__ size_t rt_offset(int N) { return image_doubles(N) + (size_t)(N + 1) * 2 * kTS; }
@@ -228,7 +258,7 @@ struct Solver {
     // wave-local ordering of LDS traffic (one wavefront executes its DS instructions in order; this only stops
     // the compiler from moving them across)
     __device__ __forceinline__ void wsync() const {
-        if constexpr (kTwo || TAIL) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        if constexpr (kTwo || kFour || TAIL) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
     }
     // all-reduce over the whole instance (one or two wavefronts); both waves combine in the same order, so
@@ -241,6 +271,7 @@ struct Solver {
     __device__ __forceinline__ double bsum(double v) const {
         v = wave_sum(v);
         if constexpr (kTwo) { double *r = RED + 64 + 4 * SLOT; if (lane == 0) r[wv] = v; __syncthreads(); v = r[0] + r[1]; }
+        if constexpr (kFour) { double *r = RED + 112 + 8 * SLOT; if (lane == 0) r[wv] = v; __syncthreads(); v = (r[0] + r[1]) + (r[2] + r[3]); }
         if constexpr (TAIL) { double *r = RT + 8 * SLOT; if (lane == 0 && wv < kActW) r[wv] = v; __syncthreads(); v = tail_sum(r); }
         return v;
     }
@@ -261,6 +292,7 @@ struct Solver {
     __device__ __forceinline__ double bmax(double v) const {
         v = wave_max(v);
         if constexpr (kTwo) { double *r = RED + 64 + 4 * SLOT; if (lane == 0) r[2 + wv] = v; __syncthreads(); v = fmax(r[2], r[3]); }
+        if constexpr (kFour) { double *r = RED + 112 + 8 * SLOT + 4; if (lane == 0) r[wv] = v; __syncthreads(); v = fmax(fmax(r[0], r[1]), fmax(r[2], r[3])); }
         if constexpr (TAIL) { double *r = RT + 8 * SLOT + 4; if (lane == 0 && wv < kActW) r[wv] = v; __syncthreads(); v = tail_max(r); }
         return v;
     }
@@ -274,6 +306,12 @@ struct Solver {
             if (lane == 0) { r[wv] = s_; r[2 + wv] = m_; }
             __syncthreads();
             s_ = r[0] + r[1]; m_ = fmax(r[2], r[3]);
+        }
+        if constexpr (kFour) {
+            double *r = RED + 112 + 8 * SLOT;
+            if (lane == 0) { r[wv] = s_; r[4 + wv] = m_; }
+            __syncthreads();
+            s_ = (r[0] + r[1]) + (r[2] + r[3]); m_ = fmax(fmax(r[4], r[5]), fmax(r[6], r[7]));
         }
         if constexpr (TAIL) {
             double *r = RT + 8 * SLOT;
@@ -675,7 +713,79 @@ struct Solver {
     __device__ __forceinline__ double ab_entry(int k, int g) const { return (g >> 3) < NX ? tA[k * kTS + g] : 0.0; }
     __device__ __forceinline__ void factor(double sig) {
         sync();
-        if constexpr (kMf) {
+        if constexpr (kFour) {
+            // The two-sided MFMA elimination below, each chain relayed over two wavefronts: the outer one (wv < 2) eliminates chain
+            // positions 0 .. kHO and keeps the operand tiles 0 .. kHO-1 that these steps leave, hands W and S^-1 of position kHO to the
+            // inner one (wv >= 2) through LDS, which goes on to position kMid-1 (operand tiles kHO .. kMid-2) and takes the link tile
+            // kMid-1 from the middle stage (wavefront 2).  Every value is the one the two-wavefront kernel computes.
+            double *const WDv = XT, *const WBv = DX, *const PUB = VT;       // free vectors: row weights, hand-over area (VT + AT)
+            static_assert(2 * (NT + 1) * 8 >= 384, "four wavefronts: the hand-over area of the factorisation does not fit VT + AT");
+            for (int e = opaque(tid); e < NS * 8; e += kStride) { WDv[e] = w_dyn(e); WBv[e] = w_box(e); }
+            sync();
+            constexpr int P = kMid;
+            const int chain = wv & 1;
+            const bool inner = wv >= 2;
+            double wd = 0.0, wtd = 0.0, sinv = 0.0;       // D forms of W, W' and S^-1 of the stage eliminated last
+            auto step = [&](int p, int j0) {
+                const int k = chain ? N - p : p;
+                const double kd = kd_d(k, sig, WDv, WBv);
+                double sk = kd;
+                if (p >= 1) {
+                    const double kot = chain ? ko_up_at(k, lj, li, WDv) : ko_down_at(k, lj, li, WDv);     // D form of Ko'
+                    const double gt = mm8(wtd, kot, 0.0);          // G' = W Ko'
+                    sk = mm8(-gt, gt, kd);                         // S = Kd - G G'
+                    const double ltn = -mm8(wd, gt, 0.0);          // -L' = -W' G'
+                    const double ln = -mm8(gt, wd, 0.0);           // -L  = -G W
+                    const bool fa = (p & 1) != 0, bb = ((P - p) & 1) == 0;      // (operand forms: see the two-wavefront branch)
+                    const double fc = fa ? ltn : qswap(ltn), fv = fa ? sinv : qswap(sinv);
+                    const double bc = bb ? qswap(ln) : ln, ba = ab_entry(k, bb ? gB : gA);
+#pragma unroll
+                    for (int pp = 0; pp < kMP; ++pp) if (pp == p - 1 - j0) { fC[pp] = fc; fV[pp] = fv; bC[pp] = bc; bA[pp] = ba; }
+                }
+                wd = chol_inverse_d(sk);
+                wtd = transpose_d(wd);
+                sinv = mm8(wd, wd, 0.0);                           // S^-1 = W' W
+            };
+            if (!inner) {
+                for (int p = 0; p <= kHO; ++p) step(p, 0);
+                PUB[chain * 128 + lane] = wd; PUB[chain * 128 + 64 + lane] = sinv;
+            }
+            sync();
+            if (inner) {
+                wd = PUB[chain * 128 + lane]; sinv = PUB[chain * 128 + 64 + lane];
+                wtd = transpose_d(wd);
+                for (int p = kHO + 1; p < P; ++p) step(p, kHO);
+                if (chain == 1) { PUB[256 + lane] = wd; PUB[320 + lane] = wtd; }
+            }
+            sync();
+            double ltn = 0.0, ln = 0.0, sm = 0.0;                  // -L_link', -L_link of this wave's chain; S_m^-1
+            if (wv == 2) {      // middle stage: S_m = K_mm - G_t G_t' - G_b G_b' with both neighbours' W
+                const double kd = kd_d(kMid, sig, WDv, WBv);
+                const double gtt = mm8(wtd, ko_down_at(kMid, lj, li, WDv), 0.0);
+                double sk = mm8(-gtt, gtt, kd);
+                ltn = -mm8(wd, gtt, 0.0); ln = -mm8(gtt, wd, 0.0);
+                const double wd1 = PUB[256 + lane], wtd1 = PUB[320 + lane];
+                const double gtb = mm8(wtd1, ko_up_at(kMid, lj, li, WDv), 0.0);
+                sk = mm8(-gtb, gtb, sk);
+                PUB[lane] = -mm8(wd1, gtb, 0.0); PUB[64 + lane] = -mm8(gtb, wd1, 0.0);
+                const double wm = chol_inverse_d(sk);
+                sm = mm8(wm, wm, 0.0);
+                PUB[128 + lane] = sm;
+            }
+            sync();
+            if (wv == 3) { ltn = PUB[lane]; ln = PUB[64 + lane]; sm = PUB[128 + lane]; }
+            if (inner) {    // link to the middle stage, the middle pivot (see the two-wavefront branch)
+                constexpr bool fa = (P & 1) != 0;
+                fC[P - 1 - kHO] = fa ? ltn : qswap(ltn); fV[P - 1 - kHO] = fa ? sinv : qswap(sinv);
+                bC[P - 1 - kHO] = qswap(ln); bA[P - 1 - kHO] = ab_entry(kMid, gB);
+                mS = sm;
+            } else {        // wave 0's closing product [A|B]_0 x_0 (x_0 leaves the last backward step in layout B iff P is even); an outer
+                constexpr bool tb = (P & 1) == 0;      // wavefront has no use for the middle pivot: the tile takes its register
+                mS = ab_entry(0, tb ? gB : gA);
+            }
+            sync();
+            return;
+        } else if constexpr (kMf) {
             // Same two-sided elimination as the DPP kernel below (wave 0: stages 0 .. kMid-1 upwards, wave 1: N .. kMid+1
             // downwards), with every 8x8 matrix in D form and every 8x8x8 product on the matrix cores (mm8), nothing staged
             // through LDS.  Per stage: G' = W Ko' (W = C_pred^-1), S = Kd - G G', L' = W' G', L = G W, C C' = S, W <- C^-1,
@@ -1144,10 +1254,219 @@ struct Solver {
         }
     }
 
+    // ---- the same sweeps relayed over two wavefronts per chain (NW == 4) -----------------------------------------------
+    // Forward step p (1 .. P; P = the link step) uses operand tile p - 1; the outer wavefront of a chain runs the steps 1 .. kHO and
+    // leaves y at chain position kHO in RED[144 ..] (layout B iff kHO is odd), the inner one picks it up and runs kHO + 1 .. P.
+    // Backward step p (P - 1 .. 0) uses tile p: inner wavefront middle stage and P - 1 .. kHO, outer wavefront kHO - 1 .. 0 starting
+    // from x at position kHO, which the inner one stored to XT like every other x.  The instructions of a step are those of
+    // mf_forward / mf_backward; only the loop bounds and the register index of a tile (p - 1 - J0, p - J0) differ.
+    // A wavefront's part of one KKT solve is ONE function with the workgroup's barriers inside (the role is uniform over the
+    // wavefront and read into a scalar register: real branches, every wavefront passes the same five barriers B1 .. B4 + the
+    // caller's): what a part needs that does not come from the other wavefronts -- addresses, the right-hand sides and pivot
+    // products it fetches two steps ahead, which are this wavefront's own stores or older than the last barrier -- is issued in
+    // front of the barrier it waits at, so that behind the barrier only the relayed vector is one LDS round trip away (a sweep
+    // phase of the two-wavefront kernel costs ~750 cycles beside its ten steps of ~65: section 4 of DESIGN.md).
+    // ELEM: the ADMM iteration -- the inner wavefront also builds the right-hand side of its set-2 elements (before its forward
+    // steps: only this wavefront reads them) and updates them (after its backward steps: x~ and [A|B] x~ of these stages are its own).
+    template <bool BOT, bool ELEM>
+    __device__ __forceinline__ void outer4(const MfLane &m, double sigma, double alpha, bool want_delta) {
+        constexpr int P = kMid;
+        auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
+        auto typeB = [](int p) constexpr { return ((P - 1 - p) & 1) == 0; };
+        {   // ---- forward steps 1 .. kHO
+            constexpr int PA = 1, PB = kHO;
+            const double *const csA = m.stB ? XT + m.eB : SINK, *const csB = m.stA ? XT + m.eA : SINK;
+            double *const vsA = VT + m.eB;
+            double *const vsB = VT + m.eA;
+            double Y = XT[stage(0) * 8 + m.eA];
+            double bq[3] = {0.0, 0.0, 0.0};                                     // right-hand sides are fetched two steps ahead
+            bq[PA % 3] = (PA & 1) ? csA[stage(PA) * 8] : csB[stage(PA) * 8];
+            if (PA + 1 <= PB) bq[(PA + 1) % 3] = ((PA + 1) & 1) ? csA[stage(PA + 1) * 8] : csB[stage(PA + 1) * 8];
+            double dvl = 0.0;                                                   // pivot product of the previous step, not yet closed
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS == 3
+            STAMP(6);
+#endif
+#pragma unroll
+            for (int p = PA; p <= PB; ++p) {
+                const double bl = bq[p % 3];
+                if (p + 2 <= PB) bq[(p + 2) % 3] = ((p + 2) & 1) ? csA[stage(p + 2) * 8] : csB[stage(p + 2) * 8];
+                __builtin_amdgcn_sched_barrier(0);
+                if (p & 1) {
+                    const double dc = mfma4(fC[p - 1], Y, bl), dv = mfma4(fV[p - 1], Y, 0.0);
+                    if (p > PA) vsB[stage(p - 2) * 8] = mf_close<false>(dvl);
+                    Y = mf_close<true>(dc);
+                    dvl = dv;
+                } else {
+                    const double dc = mfma4(fC[p - 1], Y, bl), dv = mfma4(fV[p - 1], Y, 0.0);
+                    if (p > PA) vsA[stage(p - 2) * 8] = mf_close<true>(dvl);
+                    Y = mf_close<false>(dc);
+                    dvl = dv;
+                }
+            }
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS == 3
+            STAMP(7);
+#endif
+            RED[144 + (BOT ? 8 : 0) + ((kHO & 1) ? m.eB : m.eA)] = Y;           // y at position kHO: every lane stores its replica
+            if (PB & 1) vsA[stage(PB - 1) * 8] = mf_close<true>(dvl); else vsB[stage(PB - 1) * 8] = mf_close<false>(dvl);
+        }
+        // ---- backward steps kHO - 1 .. 0: the pivot products of the first two are this wavefront's own stores
+        constexpr int PA = kHO - 1, PB = 0;
+        const double *const vsA = m.stB ? VT + m.eB : SINK, *const vsB = m.stA ? VT + m.eA : SINK;
+        double *const xsA = XT + m.eB;
+        double *const xsB = XT + m.eA;
+        double *const asA = AT + (BOT ? 0 : 16) + m.eB;   // [A|B]_k x_k, filed under the dynamics rows of stage k + 1
+        double *const asB = AT + (BOT ? 0 : 16) + m.eA;
+        wsync();
+        double vq[3] = {0.0, 0.0, 0.0};
+        vq[PA % 3] = typeB(PA) ? vsB[stage(PA) * 8] : vsA[stage(PA) * 8];
+        if (PA - 1 >= PB) vq[(PA - 1) % 3] = typeB(PA - 1) ? vsB[stage(PA - 1) * 8] : vsA[stage(PA - 1) * 8];
+        sync();             // B1: y is handed over; the inner wavefronts sweep up ...
+        STAMP(1);
+        sync();             // B2: ... and, behind the middle stage, ...
+        STAMP(2);
+        sync();             // B3: ... back
+        STAMP(3);
+        double X = XT[stage(kHO) * 8 + (typeB(kHO) ? m.eA : m.eB)];            // x at position kHO, left by the inner wavefront's last step
+        double dal = 0.0;                                                       // dynamics-row product of the previous step, not yet closed
+#pragma unroll
+        for (int p = PA; p >= PB; --p) {
+            const double vl = vq[p % 3];
+            if (p - 2 >= PB) vq[(p - 2) % 3] = typeB(p - 2) ? vsB[stage(p - 2) * 8] : vsA[stage(p - 2) * 8];
+            __builtin_amdgcn_sched_barrier(0);
+            // (x of the previous step is stored behind this step's MFMAs, not between its closing add and them: the store's issue is off the chain)
+            if (typeB(p)) {
+                const double dc = mfma4(bC[p], X, vl), da = mfma4(bA[p], X, 0.0);
+                if (p < PA) { xsA[stage(p + 1) * 8] = X; asA[stage(p + 1) * 8] = mf_close<true>(dal); }
+                X = mf_close<false>(dc);
+                dal = da;
+            } else {
+                const double dc = mfma4(bC[p], X, vl), da = mfma4(bA[p], X, 0.0);
+                if (p < PA) { xsB[stage(p + 1) * 8] = X; asB[stage(p + 1) * 8] = mf_close<false>(dal); }
+                X = mf_close<true>(dc);
+                dal = da;
+            }
+        }
+        if (typeB(0)) { xsB[stage(0) * 8] = X; asB[stage(0) * 8] = mf_close<false>(dal); } else { xsA[stage(0) * 8] = X; asA[stage(0) * 8] = mf_close<true>(dal); }        // x_0, product of step 0
+        if (!BOT) {     // [A|B]_0 x_0 -> dynamics rows of stage 1; x_0 is in layout B iff P is even
+            constexpr bool tb = (P & 1) == 0;
+            AT[8 + (tb ? m.eA : m.eB)] = mf_close<!tb>(mfma4(mS, X, 0.0));      // (mS: [A|B]_0 on the outer wavefronts, see factor)
+        }
+        sync();             // B4
+        STAMP(4);
+    }
+    template <bool BOT, bool ELEM>
+    __device__ __forceinline__ void inner4(const MfLane &m, double sigma, double alpha, bool want_delta) {
+        constexpr int P = kMid, J0 = kHO;
+        auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
+        auto typeB = [](int p) constexpr { return ((P - 1 - p) & 1) == 0; };
+        if constexpr (ELEM) { build_rhs_set<2>(sigma); wsync(); }
+        double *const vsAw = VT + m.eB;
+        double *const vsBw = VT + m.eA;
+        const double *const vsA = m.stB ? VT + m.eB : SINK, *const vsB = m.stA ? VT + m.eA : SINK;
+        double *const xsA = XT + m.eB;
+        double *const xsB = XT + m.eA;
+        {   // ---- forward steps kHO + 1 .. P (P: the link step)
+            constexpr int PA = J0 + 1, PB = P - 1;                              // the steps that take a right-hand side
+            const double *const csA = m.stB ? XT + m.eB : SINK, *const csB = m.stA ? XT + m.eA : SINK;
+            if (!BOT && m.ln < 8) RED[48 + m.ln] = XT[kMid * 8 + m.ln];        // the middle right-hand side survives x_m (see twisted_forward)
+            double bq[3] = {0.0, 0.0, 0.0};
+            if (PA <= PB) bq[PA % 3] = (PA & 1) ? csA[stage(PA) * 8] : csB[stage(PA) * 8];
+            if (PA + 1 <= PB) bq[(PA + 1) % 3] = ((PA + 1) & 1) ? csA[stage(PA + 1) * 8] : csB[stage(PA + 1) * 8];
+            STAMP(0);       // (inner wavefronts: own clock -- right-hand side set 2 + prologue)
+            sync();         // B1: the outer wavefront has left y at position kHO
+            STAMP(1);       // waiting at B1
+            double Y = RED[144 + (BOT ? 8 : 0) + ((J0 & 1) ? m.eB : m.eA)];
+            double dvl = 0.0;
+#pragma unroll
+            for (int p = PA; p <= PB; ++p) {
+                const double bl = bq[p % 3];
+                if (p + 2 <= PB) bq[(p + 2) % 3] = ((p + 2) & 1) ? csA[stage(p + 2) * 8] : csB[stage(p + 2) * 8];
+                __builtin_amdgcn_sched_barrier(0);
+                if (p & 1) {
+                    const double dc = mfma4(fC[p - 1 - J0], Y, bl), dv = mfma4(fV[p - 1 - J0], Y, 0.0);
+                    if (p > PA) vsBw[stage(p - 2) * 8] = mf_close<false>(dvl);
+                    Y = mf_close<true>(dc);
+                    dvl = dv;
+                } else {
+                    const double dc = mfma4(fC[p - 1 - J0], Y, bl), dv = mfma4(fV[p - 1 - J0], Y, 0.0);
+                    if (p > PA) vsAw[stage(p - 2) * 8] = mf_close<true>(dvl);
+                    Y = mf_close<false>(dc);
+                    dvl = dv;
+                }
+            }
+            // last chain stage: this chain's contribution -L_link y_last to the middle right-hand side first (the other chain waits for it), then the pivot products
+            constexpr bool la = (P & 1) != 0;
+            const double dl = mfma4(fC[P - 1 - J0], Y, 0.0), dv = mfma4(fV[P - 1 - J0], Y, 0.0);
+            RED[32 + (BOT ? 8 : 0) + (la ? m.eB : m.eA)] = mf_close<la>(dl);
+            if (PB >= PA) { if (PB & 1) vsAw[stage(PB - 1) * 8] = mf_close<true>(dvl); else vsBw[stage(PB - 1) * 8] = mf_close<false>(dvl); }
+            (la ? vsAw : vsBw)[stage(P - 1) * 8] = mf_close<la>(dv);
+        }
+        // ---- backward: middle stage, steps P - 1 .. kHO; the pivot products of the first two steps are this wavefront's own stores
+        constexpr int PA = P - 1, PB = J0;
+        double *const asA = AT + (BOT ? 0 : 16) + m.eB;   // [A|B]_k x_k, filed under the dynamics rows of stage k + 1
+        double *const asB = AT + (BOT ? 0 : 16) + m.eA;
+        wsync();
+        double vq[3] = {0.0, 0.0, 0.0};
+        vq[PA % 3] = typeB(PA) ? vsB[stage(PA) * 8] : vsA[stage(PA) * 8];
+        if (PA - 1 >= PB) vq[(PA - 1) % 3] = typeB(PA - 1) ? vsB[stage(PA - 1) * 8] : vsA[stage(PA - 1) * 8];
+        STAMP(2);           // forward steps
+        sync();             // B2: both chains' contributions to the middle right-hand side are there
+        STAMP(3);           // waiting at B2
+        // middle stage, on both inner wavefronts: x_m = S_m^-1 (b_m - L_t y_{m-1} - L_b y_{m+1}); type A step, x_m in layout B
+        const double ym = RED[48 + m.eA] + (RED[32 + m.eA] + RED[40 + m.eA]);
+        double X = mf_close<true>(mfma4(mS, ym, 0.0));
+        if constexpr (!BOT) XT[kMid * 8 + m.eB] = X;
+        double dal = 0.0;
+#pragma unroll
+        for (int p = PA; p >= PB; --p) {
+            const double vl = vq[p % 3];
+            if (p - 2 >= PB) vq[(p - 2) % 3] = typeB(p - 2) ? vsB[stage(p - 2) * 8] : vsA[stage(p - 2) * 8];
+            __builtin_amdgcn_sched_barrier(0);
+            const bool keep = BOT || p + 1 != P - 1;      // both chains' first step multiplies [A|B]_kMid x_m: the bottom chain files it
+            if (typeB(p)) {     // (x of the previous step is stored behind this step's MFMAs: see outer4)
+                const double dc = mfma4(bC[p - J0], X, vl), da = mfma4(bA[p - J0], X, 0.0);
+                if (p < PA) xsA[stage(p + 1) * 8] = X;
+                if (p < PA && keep) asA[stage(p + 1) * 8] = mf_close<true>(dal);
+                X = mf_close<false>(dc);
+                dal = da;
+            } else {
+                const double dc = mfma4(bC[p - J0], X, vl), da = mfma4(bA[p - J0], X, 0.0);
+                if (p < PA) xsB[stage(p + 1) * 8] = X;
+                if (p < PA && keep) asB[stage(p + 1) * 8] = mf_close<false>(dal);
+                X = mf_close<true>(dc);
+                dal = da;
+            }
+        }
+        if (typeB(PB)) xsB[stage(PB) * 8] = X; else xsA[stage(PB) * 8] = X;      // x at position kHO first: the outer wavefront waits for it
+        {   // product of this wavefront's last step
+            constexpr bool keep = BOT || PB != P - 1;
+            if constexpr (keep) { if (typeB(PB)) asB[stage(PB) * 8] = mf_close<false>(dal); else asA[stage(PB) * 8] = mf_close<true>(dal); }
+        }
+        STAMP(4);           // backward steps
+        sync();             // B3: x at position kHO is in XT; the outer wavefronts sweep back
+        STAMP(5);           // waiting at B3
+        if constexpr (ELEM) { wsync(); update<2>(alpha, want_delta); }
+        STAMP(6);           // update set 2
+        sync();             // B4
+        STAMP(7);           // waiting at B4
+    }
+    // the four parts of one KKT solve of the four-wavefront kernel (the right-hand side is complete in XT, a barrier behind it)
+    template <bool ELEM>
+    __device__ __forceinline__ void relay4(const MfLane &m, double sigma, double alpha, bool want_delta) {
+        const int role = __builtin_amdgcn_readfirstlane(wv);
+        if (role == 0) outer4<false, ELEM>(m, sigma, alpha, want_delta);
+        else if (role == 1) outer4<true, ELEM>(m, sigma, alpha, want_delta);
+        else if (role == 2) inner4<false, ELEM>(m, sigma, alpha, want_delta);
+        else inner4<true, ELEM>(m, sigma, alpha, want_delta);
+    }
+
     // STASHED: the caller has already copied the middle stage's right-hand side to RED[48..55]
     template <bool STASHED = false>
     __device__ __forceinline__ void kkt_solve() {
-        if constexpr (kMf) {
+        if constexpr (kFour) {      // (the polish solves; the ADMM iteration adds its element phases: iterate4)
+            relay4<false>(mf_lane(), 0.0, 0.0, false);
+            return;
+        } else if constexpr (kMf) {
             if (wv == 0) mf_forward<false, STASHED>(); else mf_forward<true, STASHED>();
             sync();
             STAMP(1);
@@ -1295,6 +1614,15 @@ struct Solver {
 #pragma unroll
             for (int i = 0; i < 8; ++i) m_[i] = fmax(RED[i], RED[16 + i]);
         }
+        if constexpr (kFour) {
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) RED[80 + wv * 8 + i] = m_[i];
+            }
+            sync();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m_[i] = fmax(fmax(RED[80 + i], RED[88 + i]), fmax(RED[96 + i], RED[104 + i]));
+        }
         if constexpr (TAIL) {
             if (lane == 0 && wv < kActW) {
 #pragma unroll
@@ -1415,8 +1743,32 @@ struct Solver {
         }
         sync();
     }
+    // NW == 4: the right-hand side of ONE element per thread (SET 1: every thread of the workgroup, SET 2: the inner wavefronts; see kS2a)
+    template <int SET>
+    __device__ __forceinline__ void build_rhs_set(double sigma) {
+        const LaneC lc = lane_consts();
+        const int t0 = opaque(tid);
+        const int e = SET == 1 ? elem_set1(t0) : elem_set2(t0);
+        if (e < NS * 8) XT[e] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
+    }
+    // One ADMM iteration of the four-wavefront kernel: set 1 of the right-hand side on all four wavefronts, the relayed KKT solve
+    // with set 2 of the right-hand side and of the update on the inner wavefronts beside it (inner4), set 1 of the update.
+    // (Measured and not taken: the right-hand side of a chain's first eight stages on its outer wavefront, fetched in front of B0 --
+    // the fetch then waits behind the element phase's LDS traffic in front of the barrier instead of behind it: no gain.)
+    __device__ __forceinline__ void iterate4(double sigma, double alpha, bool want_delta) {
+        build_rhs_set<1>(sigma);
+        const MfLane m = mf_lane();         // (in front of the barrier: the sweeps' lane constants form while the stores drain)
+        sync();             // B0
+        STAMP(0);
+        relay4<true>(m, sigma, alpha, want_delta);
+        update<1>(alpha, want_delta);
+        sync();             // B5
+        STAMP(5);
+    }
     // z~ = A x~ fused with OSQP update_x / update_z / update_y; leaves rho z - y in ZT*.
     // All LDS reads of a round are issued before any of its writes.
+    // (SET: four-wavefront kernel only -- 1 / 2 = that element set, no barrier; see iterate4)
+    template <int SET = 0>
     __device__ __forceinline__ void update(double alpha, bool want_delta) {
         const double oma = 1.0 - alpha;
         const LaneC lc = lane_consts();
@@ -1484,7 +1836,12 @@ struct Solver {
             X[e] = xn;
             if (want_delta) { DYd[e] = dyd; DYb[e] = dyb; DX[e] = xn - xo; }
         };
-        if constexpr (kCacheW) {
+        if constexpr (kFour) {
+            const int t0 = opaque(tid);
+            if constexpr (SET != 2) { const int e = elem_set1(t0); if (e < NS * 8) element(e, true, wbx[0], wbxi[0]); }
+            if constexpr (SET != 1) { const int e = elem_set2(t0); if (e < NS * 8) element(e, true, wbx[1], wbxi[1]); }
+            if constexpr (SET != 0) return;
+        } else if constexpr (kCacheW) {
             const int t0 = opaque(tid);
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
@@ -1761,10 +2118,13 @@ struct Solver {
             if (LPVMPC_PHASE_ONLY == 2) { if constexpr (TAIL) dense_apply(); else kkt_solve(); }
             if (LPVMPC_PHASE_ONLY == 3) update(alpha, checked);
 #else
+            if constexpr (kFour) iterate4(sigma, alpha, checked);
+            else {
             build_rhs(sigma);
             STAMP(0);
             if constexpr (TAIL) { dense_apply(); STAMP(1); } else kkt_solve();
             update(alpha, checked);         // delta_x / delta_y are only read by the infeasibility tests
+            }
 #endif
             asm volatile("; LPVMPC_HOT_END");
             STAMP(3);
@@ -1839,6 +2199,9 @@ struct Solver {
             for (int e = opaque(tid); e < NS * 8; e += kStride) { st_out[NS * 8 + e] = 0.0; st_out[2 * NS * 8 + e] = 0.0; }
         }
 #ifdef LPVMPC_STAMPS
+        if constexpr (kFour) {          // the inner top wavefront's own eight segments (inner4) behind wavefront 0's six
+            if (tid == 128) for (int i = 0; i < 8; ++i) o_.xPred[(size_t)inst * NS * NX + 8 + i] = (double)stamp[i] / iter;
+        }
         if (tid == 0 && o_.resid) {     // diagnostic build: resid carries per-iteration cycle counts instead
             double *o = o_.resid + (size_t)inst * 4;
 #if LPVMPC_STAMPS == 2
@@ -1846,6 +2209,10 @@ struct Solver {
 #else
             o[0] = (double)stamp[0] / iter; o[1] = (double)stamp[1] / iter; o[2] = (double)stamp[2] / iter; o[3] = (double)stamp[3] / iter;
 #endif
+            if constexpr (kFour) {      // six segments of iterate4: the first words of the instance's xPred carry them
+                for (int i = 0; i < 6; ++i) o_.xPred[(size_t)inst * NS * NX + i] = (double)stamp[i] / iter;
+                o_.xPred[(size_t)inst * NS * NX + 6] = (double)stamp[6] / iter; o_.xPred[(size_t)inst * NS * NX + 7] = (double)stamp[7] / iter;      // (LPVMPC_STAMPS == 3: outer forward, B0 .. loop / the loop)
+            }
             if (o_.status) o_.status[inst] = status;
             if (o_.iters) o_.iters[inst] = iter;
             return;
@@ -1987,7 +2354,7 @@ template <int NT, int NW, bool GS>
 #ifdef LPVMPC_FORCE_TWO_WAVES_PER_SIMD
 constexpr int min_waves_per_simd() { return NW >= 8 ? NW / 4 : NW; }      // diagnostic: provoke register spilling in the big-N kernels
 #else
-constexpr int min_waves_per_simd() { return ((NW == 2 && NT <= 20) || (NW == 1 && NT > 0 && NT <= 8) || GS || NW == 8) ? 2 : 1; }     // N = 8 (one wavefront): 256 registers without a spill -> eight instances per CU; NW = 8: the tail kernel, one workgroup per CU
+constexpr int min_waves_per_simd() { return ((NW == 2 && NT <= 20) || (NW == 1 && NT > 0 && NT <= 8) || GS || NW == 8 || NW == 4) ? 2 : 1; }     // N = 8 (one wavefront): 256 registers without a spill -> eight instances per CU; NW = 8: the tail kernel, one workgroup per CU
 #endif
 
 template <int NX, int NT, int NW, bool MF = false, bool GS = false, bool TAIL = false>
@@ -2181,17 +2548,22 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
         if (!generic && cfg.N == 8) return launch_one<6, 8, 1>(cfg, dcfg, a, stream);      // the launch file's controller horizon (MAIN_LAUNCH.launch:117)
         return launch_one<6, 0, 1>(cfg, dcfg, a, stream);
     }
-    const bool mf = kernel_variant == 4;      // diagnostic: the planner N = 30 kernel with MFMA sweeps (two instances per CU)
-    // default at N = 30: the equilibration vectors in global memory (three instances per CU) whenever the caller provides the
-    // room and nothing is parked or resumed (a parked image is the LDS image); kernel_variant 5 keeps them in LDS (two per CU)
-    // (a batch of at most two instances per CU gains nothing from the third slot: it takes the LDS form, which iterates ~5 % faster)
-    const bool gs = kernel_variant == 0 && a.scal != nullptr && a.defer_after == 0 && !a.resume && a.B > 512;
-    if (!generic && cfg.N == 30) return one_wave ? launch_one<5, 30, 1>(cfg, dcfg, a, stream)
-                                          : (mf ? launch_one<5, 30, 2, true>(cfg, dcfg, a, stream)
-                                                : (gs ? launch_one<5, 30, 2, false, true>(cfg, dcfg, a, stream) : launch_one<5, 30, 2>(cfg, dcfg, a, stream)));
-    // N = 40 (the cascade's planner horizon): MFMA sweeps and factorisation by default (two instances per CU, one wavefront per SIMD:
-    // the shorter dependent chains count for more here than at N = 30, where three instances per CU win); kernel_variant 3 = DPP sweeps
-    if (!generic && cfg.N == 40) return dpp ? launch_one<5, 40, 2>(cfg, dcfg, a, stream) : launch_one<5, 40, 2, true>(cfg, dcfg, a, stream);
+    const bool mf = kernel_variant == 4;      // diagnostic: the planner N = 30 kernel with two wavefronts and MFMA sweeps (two instances per CU)
+    // N = 30 and N = 40 (round 4): FOUR wavefronts per instance, the two chains relayed, MFMA sweeps and factorisation -- two instances
+    // per CU, two wavefronts per SIMD (Solver::kFour).  Earlier defaults stay selectable: N = 30 kernel_variant 7 = the DPP two-wavefront
+    // kernel with its equilibration vectors in global memory (three instances per CU) whenever the caller provides the room and nothing
+    // is parked or resumed (a parked image is the LDS image; batches of at most 512 instances take the LDS form, kernel_variant 5);
+    // N = 40 kernel_variant 6 = the two-wavefront MFMA kernel, 3 = DPP sweeps.
+    const bool gs = kernel_variant == 7 && a.scal != nullptr && a.defer_after == 0 && !a.resume && a.B > 512;
+    if (!generic && cfg.N == 30) {
+        if (one_wave) return launch_one<5, 30, 1>(cfg, dcfg, a, stream);
+        if (mf) return launch_one<5, 30, 2, true>(cfg, dcfg, a, stream);
+        if (gs) return launch_one<5, 30, 2, false, true>(cfg, dcfg, a, stream);
+        if (kernel_variant == 5 || kernel_variant == 7 || dpp) return launch_one<5, 30, 2>(cfg, dcfg, a, stream);
+        return launch_one<5, 30, 4, true>(cfg, dcfg, a, stream);
+    }
+    if (!generic && cfg.N == 40) return dpp ? launch_one<5, 40, 2>(cfg, dcfg, a, stream)
+                                            : (kernel_variant == 6 ? launch_one<5, 40, 2, true>(cfg, dcfg, a, stream) : launch_one<5, 40, 4, true>(cfg, dcfg, a, stream));
     if (!generic && cfg.N == 20) return dpp ? launch_one<5, 20, 2>(cfg, dcfg, a, stream) : launch_one<5, 20, 2, true>(cfg, dcfg, a, stream);     // the planner half of configs[3]
     return launch_one<5, 0, 1>(cfg, dcfg, a, stream);
 }

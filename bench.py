@@ -421,8 +421,9 @@ def main():
                          # lives in LDS and registers, the counter traffic is a hundredth of the algorithmic bytes
                          "limiter": "valu_issue", "limiter_frac": (pmc.get("valu_timed") or {}).get("frac"),
                          "pmc_build": pmc.get("build"), "pmc_matches_build": pmc_matches_build(pmc),
-                         "kernel": "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, (", equilibration vectors in global memory (3 instances per CU)" if args.kernel_variant == 0 and args.defer == 0 else "")
-                                                                            if planner else ("" if args.kernel_variant == 3 else ", MFMA sweeps")),
+                         "kernel": ("admm_solve_kernel<%d, %d, 4, MFMA sweeps, chains relayed over four wavefronts>" % (nx, N) if planner and args.kernel_variant == 0 and N in (30, 40)
+                                    else "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, (", equilibration vectors in global memory (3 instances per CU)" if args.kernel_variant == 7 and args.defer == 0 else "")
+                                                                            if planner else ("" if args.kernel_variant == 3 else ", MFMA sweeps"))),
                          "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
                          "all_launches_avg_ms": (k_ms + r_ms) / max(k_n + r_n, 1),     # main + resume launches: what a kernel trace averages under the one kernel name
                          "resume_launches": ({"count": r_n, "avg_ms": r_ms / max(r_n, 1),

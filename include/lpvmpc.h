@@ -120,9 +120,12 @@ int lpvmpc_last_error_code(void);
  * CTRL:302,316 / PLAN:204-208; default); 1 = start from the previous solve's (x, y) of the same handle and
  * batch size; 2 = the same shifted by one stage (receding horizon).  Opt-in, changes iteration counts, not optima.
  * "cascade_prefetch" (0/1, default 1): read by lpvmpc_cascade_init on the controller handle, see there.
- * "kernel_variant" 3 = the DPP two-wavefront kernels of round 1 for the controller at N = 20 and the planner at N = 20 / 40 (their
- * defaults run the KKT sweeps and the factorisation on the matrix cores); 4 = the planner N = 30 kernel with MFMA sweeps (diagnostic); 5 = the planner N = 30 kernel with
- * every vector in LDS (two instances per CU; the default keeps its three equilibration vectors in global memory and fits three).
+ * "kernel_variant" 3 = the DPP two-wavefront kernels of round 1 for the controller at N = 20 and the planner at N = 20 / 30 / 40 (their
+ * defaults run the KKT sweeps and the factorisation on the matrix cores; the planner at N = 30 / 40 with FOUR wavefronts per instance, the
+ * two elimination chains relayed over two wavefronts each); 4 = the planner N = 30 kernel with two wavefronts and MFMA sweeps (diagnostic);
+ * 5 = the planner N = 30 DPP kernel with every vector in LDS (two instances per CU); 6 = the planner N = 40 kernel with two wavefronts and
+ * MFMA sweeps (round 3's default: bit-identical to today's); 7 = the planner N = 30 DPP kernel with its three equilibration vectors in
+ * global memory (three instances per CU; round 3's default).
  * "defer_after" (iterations, 0 = off, default): STRAGGLER DEFERRAL for lpvmpc_solve_batch_dev.  One OSQP solve in a thousand
  * needs thousands of ADMM iterations where the typical one needs 50; a launch lasts as long as its slowest instance, so those
  * few hold the caller's stream for milliseconds.  With defer_after = K an instance that is still unsolved at a termination

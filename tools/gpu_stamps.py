@@ -26,3 +26,16 @@ for variant in (0, 4):
     print("planner N=30 variant %d B=512 cycles/iter: build_rhs %.0f | kkt fwd+pivot %.0f | kkt bwd %.0f | update %.0f | total %.0f" % (
         variant, *np.median(r, axis=0), np.median(r.sum(1))))
     eng.close()
+
+# planner N = 40, four wavefronts per instance: the six barrier-to-barrier segments of iterate4
+for B in (256, 512):
+    w = workloads.planner_batch(B, N=40, seed=1)
+    eng = workloads.make_solver(w, adaptive_rho=0, polish=0, check_termination=0, max_iter=200)
+    out = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+    r = out["xPred"].reshape(B, -1)[:, :6]
+    print("planner N=40 four wavefronts B=%d cycles/iter: rhs set 1 %.0f | outer forward + rhs set 2 %.0f | inner forward %.0f | inner backward %.0f | outer backward + update set 2 %.0f | update set 1 %.0f | total %.0f" % (
+        B, *np.median(r, axis=0), np.median(r.sum(1))))
+    eng.close()
+    print("   outer top wavefront's forward (STAMPS=3 builds): barrier B0 to the first step %.0f | the ten steps %.0f" % tuple(np.median(out["xPred"].reshape(B, -1)[:, 6:8], axis=0)))
+    r2 = out["xPred"].reshape(B, -1)[:, 8:16]
+    print("   inner top wavefront: rhs set 2 + prologue %.0f | wait B1 %.0f | forward %.0f | wait B2 %.0f | backward %.0f | wait B3 %.0f | update set 2 %.0f | wait B4 %.0f" % tuple(np.median(r2, axis=0)))
