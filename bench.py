@@ -421,8 +421,8 @@ def main():
                          # lives in LDS and registers, the counter traffic is a hundredth of the algorithmic bytes
                          "limiter": "valu_issue", "limiter_frac": (pmc.get("valu_timed") or {}).get("frac"),
                          "pmc_build": pmc.get("build"), "pmc_matches_build": pmc_matches_build(pmc),
-                         "kernel": ("admm_solve_kernel<%d, %d, 4, MFMA sweeps, chains relayed over four wavefronts>" % (nx, N) if planner and args.kernel_variant == 0 and N in (30, 40)
-                                    else "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, (", equilibration vectors in global memory (3 instances per CU)" if args.kernel_variant == 7 and args.defer == 0 else "")
+                         "kernel": ("admm_solve_kernel<%d, %d, 4, MFMA sweeps, chains relayed over four wavefronts>" % (nx, N) if planner and ((args.kernel_variant == 0 and (N == 40 or (N == 30 and (B <= 512 or args.defer)))) or (args.kernel_variant == 7 and N == 30))
+                                    else "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, (", equilibration vectors in global memory (3 instances per CU)" if args.kernel_variant == 0 and args.defer == 0 else "")
                                                                             if planner else ("" if args.kernel_variant == 3 else ", MFMA sweeps"))),
                          "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
                          "all_launches_avg_ms": (k_ms + r_ms) / max(k_n + r_n, 1),     # main + resume launches: what a kernel trace averages under the one kernel name
@@ -989,7 +989,7 @@ def bench_cascade(args, rank, local_rank, world, dev):
                           "ctrl_kernel_avg_ms": cms / max(cn, 1)},
                "roofline": {"bound": "hbm", "achieved": bytes_launch / k_avg_s / 1e9 if pn else float("nan"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": (bytes_launch / k_avg_s / 1e9 / HBM_PEAK_GBS) if pn else float("nan"), "traffic": None,
-                            "kernel": "admm_solve_kernel<5, 40, 2, MFMA sweeps>", "kernel_avg_ms": pms / max(pn, 1), "launches": pn,
+                            "kernel": "admm_solve_kernel<5, 40, 4, MFMA sweeps, chains relayed over four wavefronts>", "kernel_avg_ms": pms / max(pn, 1), "launches": pn,
                             "note": "planner solve kernel (95 % of a tick); algorithmic bytes from the iteration counts of the last planner tick; the sub-fleets' launches overlap, so kernel_avg_ms is the duration of a launch sharing the chip"}}
     for ct, pl in fleets:
         ct.close(); pl.close()
