@@ -1754,7 +1754,12 @@ struct Solver {
     // One ADMM iteration of the four-wavefront kernel: set 1 of the right-hand side on all four wavefronts, the relayed KKT solve
     // with set 2 of the right-hand side and of the update on the inner wavefronts beside it (inner4), set 1 of the update.
     // (Measured and not taken: the right-hand side of a chain's first eight stages on its outer wavefront, fetched in front of B0 --
-    // the fetch then waits behind the element phase's LDS traffic in front of the barrier instead of behind it: no gain.)
+    // the fetch then waits behind the element phase's LDS traffic in front of the barrier instead of behind it: no gain.  The pivot
+    // products v_p kept in registers from the forward to the backward steps of the same wavefront instead of going through VT (80 of
+    // 404 LDS instructions per iteration-instance less): the two selects per step that zero the non-owner blocks cost more than the
+    // store and the load did -- 2.72 -> 2.90 us per iteration alone on a CU, 3.65 -> 3.74 at two per CU; with the quad swap an odd
+    // chain length needs, N = 30: 3.09 -> 3.45.  Pinning the two MFMAs of a step back to back, or the pivot product's closing add
+    // between them: +8 % / +10 % per iteration.)
     __device__ __forceinline__ void iterate4(double sigma, double alpha, bool want_delta) {
         build_rhs_set<1>(sigma);
         const MfLane m = mf_lane();         // (in front of the barrier: the sweeps' lane constants form while the stores drain)
