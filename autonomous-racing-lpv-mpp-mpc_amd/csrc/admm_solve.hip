@@ -654,11 +654,15 @@ struct Solver {
             const double cit = bcast_row<(T)>(s) * rs;                                                            \
             const double cjt = __shfl(s, G * 8 + lj) * rs;                                                        \
             const double wtj = __shfl(w, G * 8 + lj) * rs;                                                        \
-            if (li > (T) && lj > (T)) s -= cit * cjt;                                                             \
+            s -= cit * cjt;     /* (unconditional: rows / columns <= T are never read again -- pivot, column and row of a later */ \
+                                /* step T' lie in the trailing block, and s itself is not returned) */                    \
             if (li == (T)) w = wtj; else if (li > (T)) w -= cit * wtj;                                            \
         }
         LPVMPC_CHOL_STEP_D(0) LPVMPC_CHOL_STEP_D(1) LPVMPC_CHOL_STEP_D(2) LPVMPC_CHOL_STEP_D(3)
-        LPVMPC_CHOL_STEP_D(4) LPVMPC_CHOL_STEP_D(5) LPVMPC_CHOL_STEP_D(6) LPVMPC_CHOL_STEP_D(7)
+        LPVMPC_CHOL_STEP_D(4) LPVMPC_CHOL_STEP_D(5) LPVMPC_CHOL_STEP_D(6)
+        // planner: variable 7 is padding at every stage (identity row and column, untouched by the Schur complements): its pivot step
+        // changes nothing (d = rs = 1, w[7][.] *= 1)
+        if constexpr (NB == 8) { LPVMPC_CHOL_STEP_D(7) }
 #undef LPVMPC_CHOL_STEP_D
         return w;
     }
