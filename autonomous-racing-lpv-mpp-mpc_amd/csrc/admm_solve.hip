@@ -1234,20 +1234,23 @@ struct Solver {
             // the previous step's [A|B] product is closed and filed in the shadow of this step's MFMAs; both waves' first
             // step multiplies [A|B]_kMid x_m: wave 1 files it, wave 0 drops it
             const bool keep = BOT || p + 1 != P - 1;
+            // (round 4: x of the previous step is stored behind this step's MFMAs, not between its closing add and them -- the store's
+            // issue is off the dependent chain)
             if (typeB(p)) {
                 const double dc = mfma4(bC[p], X, vl), da = mfma4(bA[p], X, 0.0);
+                if (p <= P - 2) xsA[stage(p + 1) * 8] = X;
                 if (p <= P - 2 && keep) asA[stage(p + 1) * 8] = mf_close<true>(dal);
                 X = mf_close<false>(dc);
-                xsB[stage(p) * 8] = X;
                 dal = da;
             } else {
                 const double dc = mfma4(bC[p], X, vl), da = mfma4(bA[p], X, 0.0);
+                if (p <= P - 2) xsB[stage(p + 1) * 8] = X;
                 if (p <= P - 2 && keep) asB[stage(p + 1) * 8] = mf_close<false>(dal);
                 X = mf_close<true>(dc);
-                xsA[stage(p) * 8] = X;
                 dal = da;
             }
         }
+        if (typeB(0)) xsB[stage(0) * 8] = X; else xsA[stage(0) * 8] = X;      // x_0
         {   // product of step 0 (type B iff P - 1 is even)
             constexpr bool keep = BOT || 0 != P - 1;
             if constexpr (keep) { if (typeB(0)) asB[stage(0) * 8] = mf_close<false>(dal); else asA[stage(0) * 8] = mf_close<true>(dal); }
