@@ -1159,11 +1159,12 @@ struct Solver {
     }
     template <bool TYPE_A>
     __device__ __forceinline__ static double mf_close(double d) { return d + dpp_mov<TYPE_A ? 0x128 : 0x141>(d); }
+    // (vq: the pivot products the backward sweep's first two steps take -- this wavefront's own stores, fetched here, in front of the
+    // barrier between the sweeps, so that behind it only the other chain's contribution to the middle stage is one LDS round trip away)
     template <bool BOT, bool STASHED>
-    __device__ __forceinline__ void mf_forward() {
+    __device__ __forceinline__ void mf_forward(const MfLane &m, double (&vq)[3]) {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
-        const MfLane m = mf_lane();
         if (!STASHED && !BOT && m.ln < 8) RED[48 + m.ln] = XT[kMid * 8 + m.ln];   // the middle right-hand side survives x_m (see twisted_forward)
         // a type A step delivers layout B: right-hand side element eB in the blocks stB, results stored by the lanes c = 0 of them
         // the right-hand side enters as the C operand of the owner blocks only: the other blocks load their "right-hand side" from the
@@ -1185,7 +1186,7 @@ struct Solver {
         for (int p = 1; p < P; ++p) {
             const double bl = bq[p % 3];
             if (p + 2 < P) bq[(p + 2) % 3] = ((p + 2) & 1) ? csA[stage(p + 2) * 8] : csB[stage(p + 2) * 8];
-            __builtin_amdgcn_sched_barrier(0);          // keep the fetch up here: sunk to its use, every step waits for LDS
+            __builtin_amdgcn_sched_barrier(0);          // keep the fetch up here: sunk to its use, every step waits for LDS (placed behind the step's MFMAs in the source: no change)
             // the previous step's pivot product is closed and stored in the shadow of this step's MFMAs
             if (p & 1) {
                 const double dc = mfma4(fC[p - 1], Y, bl), dv = mfma4(fV[p - 1], Y, 0.0);
@@ -1203,14 +1204,20 @@ struct Solver {
         // last chain stage: its pivot product and this chain's contribution -L_link y_last to the middle right-hand side
         constexpr bool la = (P & 1) != 0;
         const double dl = mfma4(fC[P - 1], Y, 0.0), dv = mfma4(fV[P - 1], Y, 0.0);
+        RED[32 + (BOT ? 8 : 0) + (la ? m.eB : m.eA)] = mf_close<la>(dl);      // (first: the other chain waits for it)
         (la ? vsA : vsB)[stage(P - 1) * 8] = mf_close<la>(dv);
-        RED[32 + (BOT ? 8 : 0) + (la ? m.eB : m.eA)] = mf_close<la>(dl);
+        wsync();
+        {
+            const double *const vlA = m.stB ? VT + m.eB : SINK, *const vlB = m.stA ? VT + m.eA : SINK;     // (the backward sweep's load pointers)
+            vq[0] = vq[1] = vq[2] = 0.0;
+            vq[(P - 1) % 3] = vlB[stage(P - 1) * 8];
+            if (P >= 2) vq[(P - 2) % 3] = vlA[stage(P - 2) * 8];
+        }
     }
     template <bool BOT>
-    __device__ __forceinline__ void mf_backward() {
+    __device__ __forceinline__ void mf_backward(const MfLane &m, double (&vq)[3]) {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
-        const MfLane m = mf_lane();
         // backward step p consumes x at chain position p + 1; x_m arrives in layout B, so step p is of type B iff P - 1 - p is even
         const double *const vsA = m.stB ? VT + m.eB : SINK, *const vsB = m.stA ? VT + m.eA : SINK;         // v_p enters as C of the owner blocks of the OUTPUT layout (the others read zeros: see mf_forward)
         double *const xsA = XT + m.eB;         // results of a type A step (layout B); every lane stores its replica (see mf_forward)
@@ -1218,9 +1225,7 @@ struct Solver {
         double *const asA = AT + (BOT ? 0 : 16) + m.eB;   // [A|B]_k x_k, filed under the dynamics rows of stage k + 1
         double *const asB = AT + (BOT ? 0 : 16) + m.eA;
         auto typeB = [](int p) constexpr { return ((P - 1 - p) & 1) == 0; };
-        double vq[3];                                                       // pivot products are fetched two steps ahead
-        vq[(P - 1) % 3] = vsB[stage(P - 1) * 8];
-        if (P >= 2) vq[(P - 2) % 3] = vsA[stage(P - 2) * 8];
+        // (pivot products are fetched two steps ahead; those of the first two steps came with vq)
         // middle stage, on both waves: x_m = S_m^-1 (b_m - L_t y_{m-1} - L_b y_{m+1}); type A step, x_m in layout B
         const double ym = RED[48 + m.eA] + (RED[32 + m.eA] + RED[40 + m.eA]);
         double X = mf_close<true>(mfma4(mS, ym, 0.0));
@@ -1467,6 +1472,18 @@ struct Solver {
         else inner4<true, ELEM>(m, sigma, alpha, want_delta);
     }
 
+    // the two MFMA sweeps of the two-wavefront kernels (the lane constants come from the caller: the ADMM iteration forms them in front
+    // of the barrier that completes the right-hand side)
+    template <bool STASHED = false>
+    __device__ __forceinline__ void kkt_solve_mf(const MfLane &m) {
+        double vq[3];
+        if (wv == 0) mf_forward<false, STASHED>(m, vq); else mf_forward<true, STASHED>(m, vq);
+        sync();
+        STAMP(1);
+        if (wv == 0) mf_backward<false>(m, vq); else mf_backward<true>(m, vq);
+        sync();
+        STAMP(2);
+    }
     // STASHED: the caller has already copied the middle stage's right-hand side to RED[48..55]
     template <bool STASHED = false>
     __device__ __forceinline__ void kkt_solve() {
@@ -1474,12 +1491,7 @@ struct Solver {
             relay4<false>(mf_lane(), 0.0, 0.0, false);
             return;
         } else if constexpr (kMf) {
-            if (wv == 0) mf_forward<false, STASHED>(); else mf_forward<true, STASHED>();
-            sync();
-            STAMP(1);
-            if (wv == 0) mf_backward<false>(); else mf_backward<true>();
-            sync();
-            STAMP(2);
+            kkt_solve_mf<STASHED>(mf_lane());
             return;
         } else if constexpr (kTwo) {
             if (wv == 0) twisted_forward<false, STASHED>(); else twisted_forward<true, STASHED>();
@@ -1738,6 +1750,7 @@ struct Solver {
     }
     // XT = sigma x - q + A' (rho z - y)        (OSQP compute_rhs, x part, reduced form)
     // (the tail kernel writes it to VT: dense_apply reads the whole right-hand side while it stores x~ into XT)
+    template <bool SYNC = true>
     __device__ __forceinline__ void build_rhs(double sigma) {
         const LaneC lc = lane_consts();
         if constexpr (TAIL) {
@@ -1748,7 +1761,7 @@ struct Solver {
         } else {
             for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
         }
-        sync();
+        if constexpr (SYNC) sync();
     }
     // NW == 4: the right-hand side of ONE element per thread (SET 1: every thread of the workgroup, SET 2: the inner wavefronts; see kS2a)
     template <int SET>
@@ -2131,7 +2144,14 @@ struct Solver {
             if (LPVMPC_PHASE_ONLY == 3) update(alpha, checked);
 #else
             if constexpr (kFour) iterate4(sigma, alpha, checked);
-            else {
+            else if constexpr (kMf) {
+                build_rhs<false>(sigma);
+                const MfLane m = mf_lane();     // (in front of the barrier: the sweeps' lane constants form while the stores drain)
+                sync();
+                STAMP(0);
+                kkt_solve_mf(m);
+                update(alpha, checked);
+            } else {
             build_rhs(sigma);
             STAMP(0);
             if constexpr (TAIL) { dense_apply(); STAMP(1); } else kkt_solve();
