@@ -1062,7 +1062,6 @@ struct Solver {
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         // The right-hand side of the middle stage is read by BOTH waves in the backward sweep while wave 0 stores x_m
         // over it: keep a copy where nobody writes (RED[48..55]) so that a late wave 1 cannot pick up x_m instead.
-        if (!STASHED && !BOT && lane < 8) RED[48 + lane] = XT[kMid * 8 + lane];
         double yc = XT[stage(0) * 8 + ti], yr = 0.0;
         double bq[3];
         bq[1] = XT[stage(1) * 8 + tj];
@@ -1097,6 +1096,8 @@ struct Solver {
             vrow[stage(P - 1) * 8] = pv;
             if (ti == 0) RED[32 + (BOT ? 8 : 0) + tj] = cb;
         }
+        // (behind the chain, not in front of it: see mf_forward)
+        if (!STASHED && !BOT && lane < 8) RED[48 + lane] = XT[kMid * 8 + lane];
     }
     template <bool BOT>
     __device__ __forceinline__ void twisted_backward() {
@@ -1165,7 +1166,6 @@ struct Solver {
     __device__ __forceinline__ void mf_forward(const MfLane &m, double (&vq)[3]) {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
-        if (!STASHED && !BOT && m.ln < 8) RED[48 + m.ln] = XT[kMid * 8 + m.ln];   // the middle right-hand side survives x_m (see twisted_forward)
         // a type A step delivers layout B: right-hand side element eB in the blocks stB, results stored by the lanes c = 0 of them
         // the right-hand side enters as the C operand of the owner blocks only: the other blocks load their "right-hand side" from the
         // all-zero area (SINK, same immediate offsets) instead of selecting 0 in front of every MFMA
@@ -1204,8 +1204,13 @@ struct Solver {
         // last chain stage: its pivot product and this chain's contribution -L_link y_last to the middle right-hand side
         constexpr bool la = (P & 1) != 0;
         const double dl = mfma4(fC[P - 1], Y, 0.0), dv = mfma4(fV[P - 1], Y, 0.0);
+        // the middle right-hand side survives x_m (see twisted_forward): copied here, behind the chain -- in front of it, the load, the
+        // wait and the store were an LDS round trip before wave 0's first step
+        double mid = 0.0;
+        if (!STASHED && !BOT) mid = XT[kMid * 8 + (m.ln & 7)];
         RED[32 + (BOT ? 8 : 0) + (la ? m.eB : m.eA)] = mf_close<la>(dl);      // (first: the other chain waits for it)
         (la ? vsA : vsB)[stage(P - 1) * 8] = mf_close<la>(dv);
+        if (!STASHED && !BOT) RED[48 + (m.ln & 7)] = mid;                      // (every lane stores a replica)
         wsync();
         {
             const double *const vlA = m.stB ? VT + m.eB : SINK, *const vlB = m.stA ? VT + m.eA : SINK;     // (the backward sweep's load pointers)
