@@ -1188,6 +1188,8 @@ struct Solver {
             if (p + 2 < P) bq[(p + 2) % 3] = ((p + 2) & 1) ? csA[stage(p + 2) * 8] : csB[stage(p + 2) * 8];
             __builtin_amdgcn_sched_barrier(0);          // keep the fetch up here: sunk to its use, every step waits for LDS (placed behind the step's MFMAs in the source: no change)
             // the previous step's pivot product is closed and stored in the shadow of this step's MFMAs
+            // (the scheduler closes it in FRONT of them, behind the chain's closing add; forcing it behind the MFMAs -- both back to back, or
+            // chain MFMA / close / pivot MFMA as the backward sweep runs -- through register dependencies costs 1.1 % / 1.2 % of the default run)
             if (p & 1) {
                 const double dc = mfma4(fC[p - 1], Y, bl), dv = mfma4(fV[p - 1], Y, 0.0);
                 if (p >= 2) vsB[stage(p - 2) * 8] = mf_close<false>(dvl);
