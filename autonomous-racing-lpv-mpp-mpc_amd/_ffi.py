@@ -77,15 +77,36 @@ EXPORTS = ("lpvmpc_version", "lpvmpc_default_config", "lpvmpc_create", "lpvmpc_d
 _lib = None
 
 
+def _bind_to_torchs_hip_runtime():
+    """A PyTorch-ROCm wheel ships its own HIP / HSA runtime (torch/lib/libamdhip64.so, same SONAME as the system's).  Two HIP
+    runtimes cannot both own the GPU in one process: with the system runtime loaded first (by liblpvmpc.so), torch's later
+    initialisation reports "No HIP GPUs are available"; with torch's loaded first, liblpvmpc.so binds to it and streams and device
+    pointers are shared.  So, where such a wheel is installed and torch is not imported yet, its runtime is loaded here (the
+    shared object only -- torch itself is not imported).  LPVMPC_SYSTEM_HIP=1 keeps the system runtime (processes that never use torch)."""
+    if "torch" in sys.modules or os.environ.get("LPVMPC_SYSTEM_HIP"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        for d in (spec.submodule_search_locations if spec else []):
+            cand = os.path.join(d, "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+                return
+    except Exception:           # no torch, or an unusual layout: the system runtime it is
+        pass
+
+
 def load():
-    """Load liblpvmpc.so.  If torch is (or will be) used in this process import it FIRST: the library
-    then binds to the HIP runtime torch already loaded (same SONAME) and device pointers are shared."""
+    """Load liblpvmpc.so; in a process that has (or may later import) a PyTorch-ROCm wheel it binds to that wheel's HIP runtime
+    (see _bind_to_torchs_hip_runtime), so the order of `import torch` and the first lpvmpc call does not matter."""
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found -- build it with `python __graft_entry__.py` (or `make -C %s`); "
                           "there is no CPU fallback" % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    _bind_to_torchs_hip_runtime()
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL if "torch" in sys.modules else C.RTLD_LOCAL)
     P = C.POINTER
     vp = C.c_void_p

@@ -229,3 +229,23 @@ def test_ros_wiring_with_stub_rospy(monkeypatch):
     assert "pos_info" not in callbacks
     refs = published["My_Planning"]
     assert len(refs) == 3 and np.all(np.isfinite(refs[-1]["vx_d"])) and abs(refs[0]["x_d"][0]) < 0.2 and abs(refs[0]["y_d"][0]) < 0.05
+
+
+@pytest.mark.gpu
+def test_torch_may_be_imported_after_the_first_solve():
+    """A PyTorch-ROCm wheel brings its own HIP runtime; liblpvmpc.so binds to it even when torch is imported only AFTER the first
+    solve (lpvmpc._ffi._bind_to_torchs_hip_runtime) -- with the system runtime loaded first, torch.cuda would find no GPU.  Fresh
+    process: the order of loading is the point."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from lpvmpc import workloads\n"
+            "w = workloads.controller_batch(8, N=20, seed=0)\n"
+            "eng = workloads.make_solver(w)\n"
+            "o = eng.solve(w['x0'], w['u_prev'], w['vel_ref'], w['curv_s'], w['u_old'], None, w['cf_new'], w['lap'])\n"
+            "assert (o['status'] == 1).all()\n"
+            "import torch\n"
+            "torch.cuda.init(); x = torch.ones(4, device='cuda'); assert float(x.sum()) == 4.0\n"
+            "print('ok')\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
