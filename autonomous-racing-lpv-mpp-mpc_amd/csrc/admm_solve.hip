@@ -66,6 +66,12 @@ struct Solver {
     static constexpr int kMid = NT / 2;             // NW == 2: wave 0 eliminates stages 0..kMid-1 upwards, wave 1 stages
     static constexpr int kP0 = kMid, kP1 = NT - kMid;   //         NT..kMid+1 downwards; stage kMid joins the two chains
     static constexpr int kRS = (kReg && !MF) ? (kTwo ? (kP1 > kP0 ? kP1 : kP0) : NT + 1) : 1;
+    // Even chain length: the pivot products v_p = S_p^-1 y_p never leave the registers.  The forward step that forms v_p and the backward
+    // step that takes it as its C operand are then of the same type (same pairing of the four blocks), so the RAW MFMA result -- every
+    // block its own partial sum, not closed -- is the C operand of every block and the backward step's closing add completes both
+    // sums at once: no closing move / add, no store and no load per step; 2 registers per chain position.
+    static constexpr bool kRawV = MF && (NW == 2 || NW == 4) && (kMid % 2 == 0);
+    static constexpr int kVQ = kRawV ? kMid : 3;
     static constexpr int kHO = (kMid + 1) / 2;      // NW == 4: operand tiles [0, kHO) on the outer wavefront of a chain, [kHO, kMid) on the inner one
     static constexpr int kMP = MF ? (kFour ? kHO : kMid) : 1;       // chain positions per wavefront in the MFMA sweeps
     // NW == 4: the element phases of an ADMM iteration (right-hand side, update) are cut into set 2 -- kS2n stages of each chain's inner
@@ -1163,7 +1169,7 @@ struct Solver {
     // (vq: the pivot products the backward sweep's first two steps take -- this wavefront's own stores, fetched here, in front of the
     // barrier between the sweeps, so that behind it only the other chain's contribution to the middle stage is one LDS round trip away)
     template <bool BOT, bool STASHED>
-    __device__ __forceinline__ void mf_forward(const MfLane &m, double (&vq)[3]) {
+    __device__ __forceinline__ void mf_forward(const MfLane &m, double (&vq)[kVQ]) {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         // a type A step delivers layout B: right-hand side element eB in the blocks stB, results stored by the lanes c = 0 of them
@@ -1190,7 +1196,11 @@ struct Solver {
             // the previous step's pivot product is closed and stored in the shadow of this step's MFMAs
             // (the scheduler closes it in FRONT of them, behind the chain's closing add; forcing it behind the MFMAs -- both back to back, or
             // chain MFMA / close / pivot MFMA as the backward sweep runs -- through register dependencies costs 1.1 % / 1.2 % of the default run)
-            if (p & 1) {
+            if constexpr (kRawV) {
+                const double dc = mfma4(fC[p - 1], Y, bl);
+                vq[p - 1] = mfma4(fV[p - 1], Y, 0.0);      // v_{p-1}, raw
+                Y = (p & 1) ? mf_close<true>(dc) : mf_close<false>(dc);
+            } else if (p & 1) {
                 const double dc = mfma4(fC[p - 1], Y, bl), dv = mfma4(fV[p - 1], Y, 0.0);
                 if (p >= 2) vsB[stage(p - 2) * 8] = mf_close<false>(dvl);
                 Y = mf_close<true>(dc);
@@ -1202,7 +1212,7 @@ struct Solver {
                 dvl = dv;
             }
         }
-        if (P >= 2) { if ((P - 1) & 1) vsA[stage(P - 2) * 8] = mf_close<true>(dvl); else vsB[stage(P - 2) * 8] = mf_close<false>(dvl); }
+        if constexpr (!kRawV) { if (P >= 2) { if ((P - 1) & 1) vsA[stage(P - 2) * 8] = mf_close<true>(dvl); else vsB[stage(P - 2) * 8] = mf_close<false>(dvl); } }
         // last chain stage: its pivot product and this chain's contribution -L_link y_last to the middle right-hand side
         constexpr bool la = (P & 1) != 0;
         const double dl = mfma4(fC[P - 1], Y, 0.0), dv = mfma4(fV[P - 1], Y, 0.0);
@@ -1211,10 +1221,10 @@ struct Solver {
         double mid = 0.0;
         if (!STASHED && !BOT) mid = XT[kMid * 8 + (m.ln & 7)];
         RED[32 + (BOT ? 8 : 0) + (la ? m.eB : m.eA)] = mf_close<la>(dl);      // (first: the other chain waits for it)
-        (la ? vsA : vsB)[stage(P - 1) * 8] = mf_close<la>(dv);
+        if constexpr (kRawV) vq[P - 1] = dv; else (la ? vsA : vsB)[stage(P - 1) * 8] = mf_close<la>(dv);
         if (!STASHED && !BOT) RED[48 + (m.ln & 7)] = mid;                      // (every lane stores a replica)
         wsync();
-        {
+        if constexpr (!kRawV) {
             const double *const vlA = m.stB ? VT + m.eB : SINK, *const vlB = m.stA ? VT + m.eA : SINK;     // (the backward sweep's load pointers)
             vq[0] = vq[1] = vq[2] = 0.0;
             vq[(P - 1) % 3] = vlB[stage(P - 1) * 8];
@@ -1222,7 +1232,7 @@ struct Solver {
         }
     }
     template <bool BOT>
-    __device__ __forceinline__ void mf_backward(const MfLane &m, double (&vq)[3]) {
+    __device__ __forceinline__ void mf_backward(const MfLane &m, double (&vq)[kVQ]) {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         // backward step p consumes x at chain position p + 1; x_m arrives in layout B, so step p is of type B iff P - 1 - p is even
@@ -1240,8 +1250,8 @@ struct Solver {
         double dal = 0.0;                                                   // dynamics-row product of the previous step, not yet closed
 #pragma unroll
         for (int p = P - 1; p >= 0; --p) {
-            const double vl = vq[p % 3];
-            if (p - 2 >= 0) vq[(p - 2) % 3] = typeB(p - 2) ? vsB[stage(p - 2) * 8] : vsA[stage(p - 2) * 8];
+            const double vl = vq[kRawV ? p : p % 3];
+            if constexpr (!kRawV) { if (p - 2 >= 0) vq[(p - 2) % 3] = typeB(p - 2) ? vsB[stage(p - 2) * 8] : vsA[stage(p - 2) * 8]; }
             __builtin_amdgcn_sched_barrier(0);
             // the previous step's [A|B] product is closed and filed in the shadow of this step's MFMAs; both waves' first
             // step multiplies [A|B]_kMid x_m: wave 1 files it, wave 0 drops it
@@ -1292,6 +1302,7 @@ struct Solver {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         auto typeB = [](int p) constexpr { return ((P - 1 - p) & 1) == 0; };
+        double vr[kRawV ? kHO : 1];     // kRawV: the pivot products of this wavefront's chain positions, raw
         {   // ---- forward steps 1 .. kHO
             constexpr int PA = 1, PB = kHO;
             const double *const csA = m.stB ? XT + m.eB : SINK, *const csB = m.stA ? XT + m.eA : SINK;
@@ -1310,7 +1321,11 @@ struct Solver {
                 const double bl = bq[p % 3];
                 if (p + 2 <= PB) bq[(p + 2) % 3] = ((p + 2) & 1) ? csA[stage(p + 2) * 8] : csB[stage(p + 2) * 8];
                 __builtin_amdgcn_sched_barrier(0);
-                if (p & 1) {
+                if constexpr (kRawV) {      // (the pivot product stays in its register, raw: see kRawV)
+                    const double dc = mfma4(fC[p - 1], Y, bl);
+                    vr[p - 1] = mfma4(fV[p - 1], Y, 0.0);
+                    Y = (p & 1) ? mf_close<true>(dc) : mf_close<false>(dc);
+                } else if (p & 1) {
                     const double dc = mfma4(fC[p - 1], Y, bl), dv = mfma4(fV[p - 1], Y, 0.0);
                     if (p > PA) vsB[stage(p - 2) * 8] = mf_close<false>(dvl);
                     Y = mf_close<true>(dc);
@@ -1326,7 +1341,7 @@ struct Solver {
             STAMP(7);
 #endif
             RED[144 + (BOT ? 8 : 0) + ((kHO & 1) ? m.eB : m.eA)] = Y;           // y at position kHO: every lane stores its replica
-            if (PB & 1) vsA[stage(PB - 1) * 8] = mf_close<true>(dvl); else vsB[stage(PB - 1) * 8] = mf_close<false>(dvl);
+            if constexpr (!kRawV) { if (PB & 1) vsA[stage(PB - 1) * 8] = mf_close<true>(dvl); else vsB[stage(PB - 1) * 8] = mf_close<false>(dvl); }
         }
         // ---- backward steps kHO - 1 .. 0: the pivot products of the first two are this wavefront's own stores
         constexpr int PA = kHO - 1, PB = 0;
@@ -1337,8 +1352,10 @@ struct Solver {
         double *const asB = AT + (BOT ? 0 : 16) + m.eA;
         wsync();
         double vq[3] = {0.0, 0.0, 0.0};
-        vq[PA % 3] = typeB(PA) ? vsB[stage(PA) * 8] : vsA[stage(PA) * 8];
-        if (PA - 1 >= PB) vq[(PA - 1) % 3] = typeB(PA - 1) ? vsB[stage(PA - 1) * 8] : vsA[stage(PA - 1) * 8];
+        if constexpr (!kRawV) {
+            vq[PA % 3] = typeB(PA) ? vsB[stage(PA) * 8] : vsA[stage(PA) * 8];
+            if (PA - 1 >= PB) vq[(PA - 1) % 3] = typeB(PA - 1) ? vsB[stage(PA - 1) * 8] : vsA[stage(PA - 1) * 8];
+        }
         sync();             // B1: y is handed over; the inner wavefronts sweep up ...
         STAMP(1);
         sync();             // B2: ... and, behind the middle stage, ...
@@ -1349,8 +1366,8 @@ struct Solver {
         double dal = 0.0;                                                       // dynamics-row product of the previous step, not yet closed
 #pragma unroll
         for (int p = PA; p >= PB; --p) {
-            const double vl = vq[p % 3];
-            if (p - 2 >= PB) vq[(p - 2) % 3] = typeB(p - 2) ? vsB[stage(p - 2) * 8] : vsA[stage(p - 2) * 8];
+            const double vl = kRawV ? vr[kRawV ? p : 0] : vq[p % 3];
+            if constexpr (!kRawV) { if (p - 2 >= PB) vq[(p - 2) % 3] = typeB(p - 2) ? vsB[stage(p - 2) * 8] : vsA[stage(p - 2) * 8]; }
             __builtin_amdgcn_sched_barrier(0);
             // (x of the previous step is stored behind this step's MFMAs, not between its closing add and them: the store's issue is off the chain)
             if (typeB(p)) {
@@ -1379,6 +1396,7 @@ struct Solver {
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         auto typeB = [](int p) constexpr { return ((P - 1 - p) & 1) == 0; };
         if constexpr (ELEM) { build_rhs_set<2>(sigma); wsync(); }
+        double vr[kRawV ? P - J0 : 1];  // kRawV: the pivot products of this wavefront's chain positions, raw
         double *const vsAw = VT + m.eB;
         double *const vsBw = VT + m.eA;
         const double *const vsA = m.stB ? VT + m.eB : SINK, *const vsB = m.stA ? VT + m.eA : SINK;
@@ -1401,7 +1419,11 @@ struct Solver {
                 const double bl = bq[p % 3];
                 if (p + 2 <= PB) bq[(p + 2) % 3] = ((p + 2) & 1) ? csA[stage(p + 2) * 8] : csB[stage(p + 2) * 8];
                 __builtin_amdgcn_sched_barrier(0);
-                if (p & 1) {
+                if constexpr (kRawV) {
+                    const double dc = mfma4(fC[p - 1 - J0], Y, bl);
+                    vr[p - 1 - J0] = mfma4(fV[p - 1 - J0], Y, 0.0);
+                    Y = (p & 1) ? mf_close<true>(dc) : mf_close<false>(dc);
+                } else if (p & 1) {
                     const double dc = mfma4(fC[p - 1 - J0], Y, bl), dv = mfma4(fV[p - 1 - J0], Y, 0.0);
                     if (p > PA) vsBw[stage(p - 2) * 8] = mf_close<false>(dvl);
                     Y = mf_close<true>(dc);
@@ -1417,8 +1439,11 @@ struct Solver {
             constexpr bool la = (P & 1) != 0;
             const double dl = mfma4(fC[P - 1 - J0], Y, 0.0), dv = mfma4(fV[P - 1 - J0], Y, 0.0);
             RED[32 + (BOT ? 8 : 0) + (la ? m.eB : m.eA)] = mf_close<la>(dl);
-            if (PB >= PA) { if (PB & 1) vsAw[stage(PB - 1) * 8] = mf_close<true>(dvl); else vsBw[stage(PB - 1) * 8] = mf_close<false>(dvl); }
-            (la ? vsAw : vsBw)[stage(P - 1) * 8] = mf_close<la>(dv);
+            if constexpr (kRawV) vr[P - 1 - J0] = dv;
+            else {
+                if (PB >= PA) { if (PB & 1) vsAw[stage(PB - 1) * 8] = mf_close<true>(dvl); else vsBw[stage(PB - 1) * 8] = mf_close<false>(dvl); }
+                (la ? vsAw : vsBw)[stage(P - 1) * 8] = mf_close<la>(dv);
+            }
         }
         // ---- backward: middle stage, steps P - 1 .. kHO; the pivot products of the first two steps are this wavefront's own stores
         constexpr int PA = P - 1, PB = J0;
@@ -1426,8 +1451,10 @@ struct Solver {
         double *const asB = AT + (BOT ? 0 : 16) + m.eA;
         wsync();
         double vq[3] = {0.0, 0.0, 0.0};
-        vq[PA % 3] = typeB(PA) ? vsB[stage(PA) * 8] : vsA[stage(PA) * 8];
-        if (PA - 1 >= PB) vq[(PA - 1) % 3] = typeB(PA - 1) ? vsB[stage(PA - 1) * 8] : vsA[stage(PA - 1) * 8];
+        if constexpr (!kRawV) {
+            vq[PA % 3] = typeB(PA) ? vsB[stage(PA) * 8] : vsA[stage(PA) * 8];
+            if (PA - 1 >= PB) vq[(PA - 1) % 3] = typeB(PA - 1) ? vsB[stage(PA - 1) * 8] : vsA[stage(PA - 1) * 8];
+        }
         STAMP(2);           // forward steps
         sync();             // B2: both chains' contributions to the middle right-hand side are there
         STAMP(3);           // waiting at B2
@@ -1438,8 +1465,8 @@ struct Solver {
         double dal = 0.0;
 #pragma unroll
         for (int p = PA; p >= PB; --p) {
-            const double vl = vq[p % 3];
-            if (p - 2 >= PB) vq[(p - 2) % 3] = typeB(p - 2) ? vsB[stage(p - 2) * 8] : vsA[stage(p - 2) * 8];
+            const double vl = kRawV ? vr[kRawV ? p - J0 : 0] : vq[p % 3];
+            if constexpr (!kRawV) { if (p - 2 >= PB) vq[(p - 2) % 3] = typeB(p - 2) ? vsB[stage(p - 2) * 8] : vsA[stage(p - 2) * 8]; }
             __builtin_amdgcn_sched_barrier(0);
             const bool keep = BOT || p + 1 != P - 1;      // both chains' first step multiplies [A|B]_kMid x_m: the bottom chain files it
             if (typeB(p)) {     // (x of the previous step is stored behind this step's MFMAs: see outer4)
@@ -1483,7 +1510,7 @@ struct Solver {
     // of the barrier that completes the right-hand side)
     template <bool STASHED = false>
     __device__ __forceinline__ void kkt_solve_mf(const MfLane &m) {
-        double vq[3];
+        double vq[kVQ];
         if (wv == 0) mf_forward<false, STASHED>(m, vq); else mf_forward<true, STASHED>(m, vq);
         sync();
         STAMP(1);
