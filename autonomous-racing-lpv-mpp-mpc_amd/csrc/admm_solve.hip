@@ -70,7 +70,10 @@ struct Solver {
     // step that takes it as its C operand are then of the same type (same pairing of the four blocks), so the RAW MFMA result -- every
     // block its own partial sum, not closed -- is the C operand of every block and the backward step's closing add completes both
     // sums at once: no closing move / add, no store and no load per step; 2 registers per chain position.
-    static constexpr bool kRawV = MF && (NW == 2 || NW == 4) && (kMid % 2 == 0);
+    // Odd chain length (N = 30): the types would alternate out of step, so the MIDDLE stage is solved as a type B step there (kFlip: its
+    // right-hand side taken in layout B, x_m delivered in layout A) and every backward step changes type with it.
+    static constexpr bool kFlip = MF && (NW == 2 || NW == 4) && (kMid % 2 != 0);
+    static constexpr bool kRawV = MF && (NW == 2 || NW == 4);
     static constexpr int kVQ = kRawV ? kMid : 3;
     static constexpr int kHO = (kMid + 1) / 2;      // NW == 4: operand tiles [0, kHO) on the outer wavefront of a chain, [kHO, kMid) on the inner one
     static constexpr int kMP = MF ? (kFour ? kHO : kMid) : 1;       // chain positions per wavefront in the MFMA sweeps
@@ -746,7 +749,7 @@ struct Solver {
                     sk = mm8(-gt, gt, kd);                         // S = Kd - G G'
                     const double ltn = -mm8(wd, gt, 0.0);          // -L' = -W' G'
                     const double ln = -mm8(gt, wd, 0.0);           // -L  = -G W
-                    const bool fa = (p & 1) != 0, bb = ((P - p) & 1) == 0;      // (operand forms: see the two-wavefront branch)
+                    const bool fa = (p & 1) != 0, bb = (((P - p) & 1) == 0) != kFlip;      // (operand forms: see the two-wavefront branch)
                     const double fc = fa ? ltn : qswap(ltn), fv = fa ? sinv : qswap(sinv);
                     const double bc = bb ? qswap(ln) : ln, ba = ab_entry(k, bb ? gB : gA);
 #pragma unroll
@@ -787,10 +790,10 @@ struct Solver {
             if (inner) {    // link to the middle stage, the middle pivot (see the two-wavefront branch)
                 constexpr bool fa = (P & 1) != 0;
                 fC[P - 1 - kHO] = fa ? ltn : qswap(ltn); fV[P - 1 - kHO] = fa ? sinv : qswap(sinv);
-                bC[P - 1 - kHO] = qswap(ln); bA[P - 1 - kHO] = ab_entry(kMid, gB);
-                mS = sm;
+                bC[P - 1 - kHO] = kFlip ? ln : qswap(ln); bA[P - 1 - kHO] = ab_entry(kMid, kFlip ? gA : gB);     // (step P - 1 is of type B, of type A with kFlip)
+                mS = kFlip ? qswap(sm) : sm;
             } else {        // wave 0's closing product [A|B]_0 x_0 (x_0 leaves the last backward step in layout B iff P is even); an outer
-                constexpr bool tb = (P & 1) == 0;      // wavefront has no use for the middle pivot: the tile takes its register
+                constexpr bool tb = ((P & 1) == 0) != kFlip;      // wavefront has no use for the middle pivot: the tile takes its register
                 mS = ab_entry(0, tb ? gB : gA);
             }
             sync();
@@ -822,7 +825,7 @@ struct Solver {
                     // forward step p consumes y_{p-1} (layout A for odd p): tiles -L_p and S_{p-1}^-1; backward step p - 1
                     // consumes x at chain position p (layout B when P - p is even): tiles -L_p' and [A|B] of stage k.
                     // A type A operand is the D form of the tile's transpose, a type B operand the same with quads 1, 2 swapped.
-                    const bool fa = (p & 1) != 0, bb = ((P - p) & 1) == 0;
+                    const bool fa = (p & 1) != 0, bb = (((P - p) & 1) == 0) != kFlip;
                     const double fc = fa ? ltn : qswap(ltn), fv = fa ? sinv : qswap(sinv);
                     const double bc = bb ? qswap(ln) : ln, ba = ab_entry(k, bb ? gB : gA);
 #pragma unroll
@@ -855,10 +858,10 @@ struct Solver {
             if (wv == 1) { ltn = PUB[128 + lane]; ln = PUB[192 + lane]; sm = PUB[256 + lane]; }
             {   // link to the middle stage (forward step P, backward step P - 1: its operand x_m is in layout B), the middle
                 // pivot (type A) and wave 0's closing product [A|B]_0 x_0 (x_0 leaves the last backward step in layout B iff P is even)
-                constexpr bool fa = (P & 1) != 0, tb = (P & 1) == 0;
+                constexpr bool fa = (P & 1) != 0, tb = ((P & 1) == 0) != kFlip;
                 fC[P - 1] = fa ? ltn : qswap(ltn); fV[P - 1] = fa ? sinv : qswap(sinv);
-                bC[P - 1] = qswap(ln); bA[P - 1] = ab_entry(kMid, gB);
-                mS = sm;
+                bC[P - 1] = kFlip ? ln : qswap(ln); bA[P - 1] = ab_entry(kMid, kFlip ? gA : gB);     // (step P - 1 is of type B, of type A with kFlip)
+                mS = kFlip ? qswap(sm) : sm;
                 tT = ab_entry(0, tb ? gB : gA);
             }
             sync();
@@ -1241,12 +1244,13 @@ struct Solver {
         double *const xsB = XT + m.eA;
         double *const asA = AT + (BOT ? 0 : 16) + m.eB;   // [A|B]_k x_k, filed under the dynamics rows of stage k + 1
         double *const asB = AT + (BOT ? 0 : 16) + m.eA;
-        auto typeB = [](int p) constexpr { return ((P - 1 - p) & 1) == 0; };
+        auto typeB = [](int p) constexpr { return (((P - 1 - p) & 1) == 0) != kFlip; };
         // (pivot products are fetched two steps ahead; those of the first two steps came with vq)
         // middle stage, on both waves: x_m = S_m^-1 (b_m - L_t y_{m-1} - L_b y_{m+1}); type A step, x_m in layout B
-        const double ym = RED[48 + m.eA] + (RED[32 + m.eA] + RED[40 + m.eA]);
-        double X = mf_close<true>(mfma4(mS, ym, 0.0));
-        if constexpr (!BOT) XT[kMid * 8 + m.eB] = X;
+        const int em = kFlip ? m.eB : m.eA;         // (kFlip: a type B step -- right-hand side in layout B, x_m in layout A)
+        const double ym = RED[48 + em] + (RED[32 + em] + RED[40 + em]);
+        double X = kFlip ? mf_close<false>(mfma4(mS, ym, 0.0)) : mf_close<true>(mfma4(mS, ym, 0.0));
+        if constexpr (!BOT) XT[kMid * 8 + (kFlip ? m.eA : m.eB)] = X;
         double dal = 0.0;                                                   // dynamics-row product of the previous step, not yet closed
 #pragma unroll
         for (int p = P - 1; p >= 0; --p) {
@@ -1278,7 +1282,7 @@ struct Solver {
             if constexpr (keep) { if (typeB(0)) asB[stage(0) * 8] = mf_close<false>(dal); else asA[stage(0) * 8] = mf_close<true>(dal); }
         }
         if (!BOT) {     // [A|B]_0 x_0 -> dynamics rows of stage 1; x_0 is in layout B iff P is even
-            constexpr bool tb = (P & 1) == 0;
+            constexpr bool tb = ((P & 1) == 0) != kFlip;
             AT[8 + (tb ? m.eA : m.eB)] = mf_close<!tb>(mfma4(tT, X, 0.0));
         }
     }
@@ -1301,7 +1305,7 @@ struct Solver {
     __device__ __forceinline__ void outer4(const MfLane &m, double sigma, double alpha, bool want_delta) {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
-        auto typeB = [](int p) constexpr { return ((P - 1 - p) & 1) == 0; };
+        auto typeB = [](int p) constexpr { return (((P - 1 - p) & 1) == 0) != kFlip; };
         double vr[kRawV ? kHO : 1];     // kRawV: the pivot products of this wavefront's chain positions, raw
         {   // ---- forward steps 1 .. kHO
             constexpr int PA = 1, PB = kHO;
@@ -1384,7 +1388,7 @@ struct Solver {
         }
         if (typeB(0)) { xsB[stage(0) * 8] = X; asB[stage(0) * 8] = mf_close<false>(dal); } else { xsA[stage(0) * 8] = X; asA[stage(0) * 8] = mf_close<true>(dal); }        // x_0, product of step 0
         if (!BOT) {     // [A|B]_0 x_0 -> dynamics rows of stage 1; x_0 is in layout B iff P is even
-            constexpr bool tb = (P & 1) == 0;
+            constexpr bool tb = ((P & 1) == 0) != kFlip;
             AT[8 + (tb ? m.eA : m.eB)] = mf_close<!tb>(mfma4(mS, X, 0.0));      // (mS: [A|B]_0 on the outer wavefronts, see factor)
         }
         sync();             // B4
@@ -1394,7 +1398,7 @@ struct Solver {
     __device__ __forceinline__ void inner4(const MfLane &m, double sigma, double alpha, bool want_delta) {
         constexpr int P = kMid, J0 = kHO;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
-        auto typeB = [](int p) constexpr { return ((P - 1 - p) & 1) == 0; };
+        auto typeB = [](int p) constexpr { return (((P - 1 - p) & 1) == 0) != kFlip; };
         if constexpr (ELEM) { build_rhs_set<2>(sigma); wsync(); }
         double vr[kRawV ? P - J0 : 1];  // kRawV: the pivot products of this wavefront's chain positions, raw
         double *const vsAw = VT + m.eB;
@@ -1459,9 +1463,10 @@ struct Solver {
         sync();             // B2: both chains' contributions to the middle right-hand side are there
         STAMP(3);           // waiting at B2
         // middle stage, on both inner wavefronts: x_m = S_m^-1 (b_m - L_t y_{m-1} - L_b y_{m+1}); type A step, x_m in layout B
-        const double ym = RED[48 + m.eA] + (RED[32 + m.eA] + RED[40 + m.eA]);
-        double X = mf_close<true>(mfma4(mS, ym, 0.0));
-        if constexpr (!BOT) XT[kMid * 8 + m.eB] = X;
+        const int em = kFlip ? m.eB : m.eA;         // (kFlip: a type B step -- right-hand side in layout B, x_m in layout A)
+        const double ym = RED[48 + em] + (RED[32 + em] + RED[40 + em]);
+        double X = kFlip ? mf_close<false>(mfma4(mS, ym, 0.0)) : mf_close<true>(mfma4(mS, ym, 0.0));
+        if constexpr (!BOT) XT[kMid * 8 + (kFlip ? m.eA : m.eB)] = X;
         double dal = 0.0;
 #pragma unroll
         for (int p = PA; p >= PB; --p) {
