@@ -1242,8 +1242,10 @@ struct Solver {
         const double *const vsA = m.stB ? VT + m.eB : SINK, *const vsB = m.stA ? VT + m.eA : SINK;         // v_p enters as C of the owner blocks of the OUTPUT layout (the others read zeros: see mf_forward)
         double *const xsA = XT + m.eB;         // results of a type A step (layout B); every lane stores its replica (see mf_forward)
         double *const xsB = XT + m.eA;
-        double *const asA = AT + (BOT ? 0 : 16) + m.eB;   // [A|B]_k x_k, filed under the dynamics rows of stage k + 1
-        double *const asB = AT + (BOT ? 0 : 16) + m.eA;
+        // [A|B]_k x_k, filed under the dynamics rows of stage k + 1 -- RAW (kRawV): the two blocks of a pair file their partial sums in AT and
+        // VT (free since the pivot products stay in registers), update() adds them: the closing move / add leaves the sweep
+        double *const asA = (kRawV && !m.stB ? VT : AT) + (BOT ? 0 : 16) + m.eB;
+        double *const asB = (kRawV && !m.stA ? VT : AT) + (BOT ? 0 : 16) + m.eA;
         auto typeB = [](int p) constexpr { return (((P - 1 - p) & 1) == 0) != kFlip; };
         // (pivot products are fetched two steps ahead; those of the first two steps came with vq)
         // middle stage, on both waves: x_m = S_m^-1 (b_m - L_t y_{m-1} - L_b y_{m+1}); type A step, x_m in layout B
@@ -1265,13 +1267,13 @@ struct Solver {
             if (typeB(p)) {
                 const double dc = mfma4(bC[p], X, vl), da = mfma4(bA[p], X, 0.0);
                 if (p <= P - 2) xsA[stage(p + 1) * 8] = X;
-                if (p <= P - 2 && keep) asA[stage(p + 1) * 8] = mf_close<true>(dal);
+                if (p <= P - 2 && keep) asA[stage(p + 1) * 8] = (kRawV ? dal : mf_close<true>(dal));
                 X = mf_close<false>(dc);
                 dal = da;
             } else {
                 const double dc = mfma4(bC[p], X, vl), da = mfma4(bA[p], X, 0.0);
                 if (p <= P - 2) xsB[stage(p + 1) * 8] = X;
-                if (p <= P - 2 && keep) asB[stage(p + 1) * 8] = mf_close<false>(dal);
+                if (p <= P - 2 && keep) asB[stage(p + 1) * 8] = (kRawV ? dal : mf_close<false>(dal));
                 X = mf_close<true>(dc);
                 dal = da;
             }
@@ -1279,11 +1281,12 @@ struct Solver {
         if (typeB(0)) xsB[stage(0) * 8] = X; else xsA[stage(0) * 8] = X;      // x_0
         {   // product of step 0 (type B iff P - 1 is even)
             constexpr bool keep = BOT || 0 != P - 1;
-            if constexpr (keep) { if (typeB(0)) asB[stage(0) * 8] = mf_close<false>(dal); else asA[stage(0) * 8] = mf_close<true>(dal); }
+            if constexpr (keep) { if (typeB(0)) asB[stage(0) * 8] = (kRawV ? dal : mf_close<false>(dal)); else asA[stage(0) * 8] = (kRawV ? dal : mf_close<true>(dal)); }
         }
         if (!BOT) {     // [A|B]_0 x_0 -> dynamics rows of stage 1; x_0 is in layout B iff P is even
             constexpr bool tb = ((P & 1) == 0) != kFlip;
-            AT[8 + (tb ? m.eA : m.eB)] = mf_close<!tb>(mfma4(tT, X, 0.0));
+            const double dt = mfma4(tT, X, 0.0);
+            ((kRawV && !(tb ? m.stA : m.stB)) ? VT : AT)[8 + (tb ? m.eA : m.eB)] = kRawV ? dt : mf_close<!tb>(dt);
         }
     }
 
@@ -1352,8 +1355,10 @@ struct Solver {
         const double *const vsA = m.stB ? VT + m.eB : SINK, *const vsB = m.stA ? VT + m.eA : SINK;
         double *const xsA = XT + m.eB;
         double *const xsB = XT + m.eA;
-        double *const asA = AT + (BOT ? 0 : 16) + m.eB;   // [A|B]_k x_k, filed under the dynamics rows of stage k + 1
-        double *const asB = AT + (BOT ? 0 : 16) + m.eA;
+        // [A|B]_k x_k, filed under the dynamics rows of stage k + 1 -- RAW (kRawV): the two blocks of a pair file their partial sums in AT and
+        // VT (free since the pivot products stay in registers), update() adds them: the closing move / add leaves the sweep
+        double *const asA = (kRawV && !m.stB ? VT : AT) + (BOT ? 0 : 16) + m.eB;
+        double *const asB = (kRawV && !m.stA ? VT : AT) + (BOT ? 0 : 16) + m.eA;
         wsync();
         double vq[3] = {0.0, 0.0, 0.0};
         if constexpr (!kRawV) {
@@ -1376,20 +1381,21 @@ struct Solver {
             // (x of the previous step is stored behind this step's MFMAs, not between its closing add and them: the store's issue is off the chain)
             if (typeB(p)) {
                 const double dc = mfma4(bC[p], X, vl), da = mfma4(bA[p], X, 0.0);
-                if (p < PA) { xsA[stage(p + 1) * 8] = X; asA[stage(p + 1) * 8] = mf_close<true>(dal); }
+                if (p < PA) { xsA[stage(p + 1) * 8] = X; asA[stage(p + 1) * 8] = (kRawV ? dal : mf_close<true>(dal)); }
                 X = mf_close<false>(dc);
                 dal = da;
             } else {
                 const double dc = mfma4(bC[p], X, vl), da = mfma4(bA[p], X, 0.0);
-                if (p < PA) { xsB[stage(p + 1) * 8] = X; asB[stage(p + 1) * 8] = mf_close<false>(dal); }
+                if (p < PA) { xsB[stage(p + 1) * 8] = X; asB[stage(p + 1) * 8] = (kRawV ? dal : mf_close<false>(dal)); }
                 X = mf_close<true>(dc);
                 dal = da;
             }
         }
-        if (typeB(0)) { xsB[stage(0) * 8] = X; asB[stage(0) * 8] = mf_close<false>(dal); } else { xsA[stage(0) * 8] = X; asA[stage(0) * 8] = mf_close<true>(dal); }        // x_0, product of step 0
+        if (typeB(0)) { xsB[stage(0) * 8] = X; asB[stage(0) * 8] = (kRawV ? dal : mf_close<false>(dal)); } else { xsA[stage(0) * 8] = X; asA[stage(0) * 8] = (kRawV ? dal : mf_close<true>(dal)); }        // x_0, product of step 0
         if (!BOT) {     // [A|B]_0 x_0 -> dynamics rows of stage 1; x_0 is in layout B iff P is even
             constexpr bool tb = ((P & 1) == 0) != kFlip;
-            AT[8 + (tb ? m.eA : m.eB)] = mf_close<!tb>(mfma4(mS, X, 0.0));      // (mS: [A|B]_0 on the outer wavefronts, see factor)
+            const double dt = mfma4(mS, X, 0.0);                                // (mS: [A|B]_0 on the outer wavefronts, see factor)
+            ((kRawV && !(tb ? m.stA : m.stB)) ? VT : AT)[8 + (tb ? m.eA : m.eB)] = kRawV ? dt : mf_close<!tb>(dt);
         }
         sync();             // B4
         STAMP(4);
@@ -1451,8 +1457,10 @@ struct Solver {
         }
         // ---- backward: middle stage, steps P - 1 .. kHO; the pivot products of the first two steps are this wavefront's own stores
         constexpr int PA = P - 1, PB = J0;
-        double *const asA = AT + (BOT ? 0 : 16) + m.eB;   // [A|B]_k x_k, filed under the dynamics rows of stage k + 1
-        double *const asB = AT + (BOT ? 0 : 16) + m.eA;
+        // [A|B]_k x_k, filed under the dynamics rows of stage k + 1 -- RAW (kRawV): the two blocks of a pair file their partial sums in AT and
+        // VT (free since the pivot products stay in registers), update() adds them: the closing move / add leaves the sweep
+        double *const asA = (kRawV && !m.stB ? VT : AT) + (BOT ? 0 : 16) + m.eB;
+        double *const asB = (kRawV && !m.stA ? VT : AT) + (BOT ? 0 : 16) + m.eA;
         wsync();
         double vq[3] = {0.0, 0.0, 0.0};
         if constexpr (!kRawV) {
@@ -1477,13 +1485,13 @@ struct Solver {
             if (typeB(p)) {     // (x of the previous step is stored behind this step's MFMAs: see outer4)
                 const double dc = mfma4(bC[p - J0], X, vl), da = mfma4(bA[p - J0], X, 0.0);
                 if (p < PA) xsA[stage(p + 1) * 8] = X;
-                if (p < PA && keep) asA[stage(p + 1) * 8] = mf_close<true>(dal);
+                if (p < PA && keep) asA[stage(p + 1) * 8] = (kRawV ? dal : mf_close<true>(dal));
                 X = mf_close<false>(dc);
                 dal = da;
             } else {
                 const double dc = mfma4(bC[p - J0], X, vl), da = mfma4(bA[p - J0], X, 0.0);
                 if (p < PA) xsB[stage(p + 1) * 8] = X;
-                if (p < PA && keep) asB[stage(p + 1) * 8] = mf_close<false>(dal);
+                if (p < PA && keep) asB[stage(p + 1) * 8] = (kRawV ? dal : mf_close<false>(dal));
                 X = mf_close<true>(dc);
                 dal = da;
             }
@@ -1491,7 +1499,7 @@ struct Solver {
         if (typeB(PB)) xsB[stage(PB) * 8] = X; else xsA[stage(PB) * 8] = X;      // x at position kHO first: the outer wavefront waits for it
         {   // product of this wavefront's last step
             constexpr bool keep = BOT || PB != P - 1;
-            if constexpr (keep) { if (typeB(PB)) asB[stage(PB) * 8] = mf_close<false>(dal); else asA[stage(PB) * 8] = mf_close<true>(dal); }
+            if constexpr (keep) { if (typeB(PB)) asB[stage(PB) * 8] = (kRawV ? dal : mf_close<false>(dal)); else asA[stage(PB) * 8] = (kRawV ? dal : mf_close<true>(dal)); }
         }
         STAMP(4);           // backward steps
         sync();             // B3: x at position kHO is in XT; the outer wavefronts sweep back
@@ -1879,7 +1887,7 @@ struct Solver {
             const double zd = Zd[e], yd = Yd[e], zb = Zb[e], yb = Yb[e], lo = Lo[e], hi = Hi[e];
             const double b = dyn_bound(e), sb = Sb(k, tj), xv = XT[k * 8 + bvar], ei = Eid(k, tj);
             // previous stage's dynamics-row product: left in AT by the backward MFMA sweep, or formed here
-            const double dot = kMf ? (k > 0 ? AT[e] : 0.0) : prev_stage_dot(k, XT);
+            const double dot = kMf ? (k > 0 ? (kRawV ? AT[e] + VT[e] : AT[e]) : 0.0) : prev_stage_dot(k, XT);     // (kRawV: the two partial sums of the backward sweep)
             // dynamics row (k, tj): bounds l = u = b
             const double ztd = rmask * (ei * xt - dot);
             const double zrd = alpha * ztd + oma * zd;
