@@ -2629,19 +2629,18 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
     }
     const bool mf = kernel_variant == 4;      // diagnostic: the planner N = 30 kernel with two wavefronts and MFMA sweeps (two instances per CU)
     // N = 30 and N = 40 (round 4): FOUR wavefronts per instance, the two chains relayed, MFMA sweeps and factorisation -- two instances
-    // per CU, two wavefronts per SIMD (Solver::kFour): a lone instance iterates 25 % faster than on two wavefronts, a CU that holds two
-    // of them does the same work per second.  So at N = 40 it is the default (kernel_variant 6 = the two-wavefront MFMA kernel, 3 = DPP
-    // sweeps); at N = 30 it is the default wherever the LDS form ran before -- batches of at most 512 instances (two per CU: nothing to
-    // gain from a third slot), launches that park or resume (a parked image is the LDS image), callers without the room for the scalings --
-    // and big batches keep the DPP two-wavefront kernel with its equilibration vectors in global memory (three instances per CU: 0.179
-    // against 0.163 M solves/s on the saturated configs[2] bench; a single 2048-instance batch: 23.9 against 21.9 ms -- kernel_variant 7
-    // selects the four-wavefront kernel there too).  kernel_variant 5 = the DPP kernel in LDS form, 4 = two wavefronts with MFMA sweeps.
-    const bool gs = kernel_variant == 0 && a.scal != nullptr && a.defer_after == 0 && !a.resume && a.B > 512;
+    // per CU, two wavefronts per SIMD (Solver::kFour).  A lone instance iterates a quarter faster than on two wavefronts; on a saturated
+    // chip the four-wavefront kernels draw level with (N = 40: the two-wavefront MFMA kernel, kernel_variant 6) or pass (N = 30: 0.183
+    // against 0.180 M solves/s on configs[2]) what ran before, so they are the defaults for every batch size -- one arithmetic per (kind, N).
+    // N = 30 kernel_variant 7 = round 3's default: the DPP two-wavefront kernel with its equilibration vectors in global memory (three
+    // instances per CU) whenever the caller provides the room, nothing is parked or resumed and the batch exceeds 512 instances, the
+    // LDS form (kernel_variant 5) otherwise; 4 = two wavefronts with MFMA sweeps; N = 40 kernel_variant 3 = DPP sweeps.
+    const bool gs = kernel_variant == 7 && a.scal != nullptr && a.defer_after == 0 && !a.resume && a.B > 512;
     if (!generic && cfg.N == 30) {
         if (one_wave) return launch_one<5, 30, 1>(cfg, dcfg, a, stream);
         if (mf) return launch_one<5, 30, 2, true>(cfg, dcfg, a, stream);
         if (gs) return launch_one<5, 30, 2, false, true>(cfg, dcfg, a, stream);
-        if (kernel_variant == 5 || dpp) return launch_one<5, 30, 2>(cfg, dcfg, a, stream);
+        if (kernel_variant == 5 || kernel_variant == 7 || dpp) return launch_one<5, 30, 2>(cfg, dcfg, a, stream);
         return launch_one<5, 30, 4, true>(cfg, dcfg, a, stream);
     }
     if (!generic && cfg.N == 40) return dpp ? launch_one<5, 40, 2>(cfg, dcfg, a, stream)

@@ -121,15 +121,12 @@ int lpvmpc_last_error_code(void);
  * batch size; 2 = the same shifted by one stage (receding horizon).  Opt-in, changes iteration counts, not optima.
  * "cascade_prefetch" (0/1, default 1): read by lpvmpc_cascade_init on the controller handle, see there.
  * "kernel_variant" 3 = the DPP two-wavefront kernels of round 1 for the controller at N = 20 and the planner at N = 20 / 30 / 40 (their
- * defaults run the KKT sweeps and the factorisation on the matrix cores; the planner at N = 40, and at N = 30 for batches of at most 512
- * instances or with straggler deferral, with FOUR wavefronts per instance, the two elimination chains relayed over two wavefronts each;
- * bigger N = 30 batches keep the DPP kernel with its three equilibration vectors in global memory, three instances per CU);
- * 4 = the planner N = 30 kernel with two wavefronts and MFMA sweeps (diagnostic); 5 = the planner N = 30 DPP kernel with every vector in LDS
- * (two instances per CU); 6 = the planner N = 40 kernel with two wavefronts and MFMA sweeps (round 3's default: bit-identical to today's);
- * 7 = the four-wavefront kernel for every N = 30 batch.  (Which kernel a default call runs depends on (kind, N) and, for the planner at
- * N = 30, on the batch size: the DPP and MFMA kernels eliminate in a different order, so the same instance solved in a 600-instance
- * and in a 48-instance call agrees to round-off -- statuses and iteration counts equal on every batch of the test suite, solutions
- * to 1e-8 -- not bit for bit; pin a variant where bit-reproducibility across batch sizes matters.)
+ * defaults run the KKT sweeps and the factorisation on the matrix cores; the planner at N = 30 / 40 with FOUR wavefronts per instance, the
+ * two elimination chains relayed over two wavefronts each); 4 = the planner N = 30 kernel with two wavefronts and MFMA sweeps (diagnostic);
+ * 5 = the planner N = 30 DPP kernel with every vector in LDS (two instances per CU); 6 = the planner N = 40 kernel with two wavefronts and
+ * MFMA sweeps (round 3's default: bit-identical to today's); 7 = round 3's default at N = 30: the DPP kernel with its three equilibration
+ * vectors in global memory (three instances per CU) for batches beyond 512 instances without deferral, variant 5 otherwise.  One kernel,
+ * hence one arithmetic, per (kind, N) by default: an instance's result does not depend on the batch it is solved in.
  * "defer_after" (iterations, 0 = off, default): STRAGGLER DEFERRAL for lpvmpc_solve_batch_dev.  One OSQP solve in a thousand
  * needs thousands of ADMM iterations where the typical one needs 50; a launch lasts as long as its slowest instance, so those
  * few hold the caller's stream for milliseconds.  With defer_after = K an instance that is still unsolved at a termination

@@ -176,7 +176,7 @@ def test_kernel_variants_agree(lpvmpc):
 
 
 def test_planner_n30_global_scalings_kernel_is_bit_identical(lpvmpc):
-    """The default planner N = 30 kernel for big batches keeps its three equilibration vectors in global memory (three instances per CU);
+    """The planner N = 30 kernel of kernel_variant 7 (round 3's default) keeps its three equilibration vectors in global memory (three instances per CU);
     kernel_variant 5 is the same code with them in LDS (two per CU).  Same arithmetic: every output word has to be equal, for a
     batch that fills the chip unevenly and a ragged one.  (With straggler deferral the handle uses the LDS form -- a parked
     image is the LDS image -- tests/test_gpu_deferral.py compares that against this kernel.)"""
@@ -184,15 +184,15 @@ def test_planner_n30_global_scalings_kernel_is_bit_identical(lpvmpc):
     for B in (1700, 601):                     # (batches of up to 512 instances take the LDS form anyway)
         w = workloads.planner_batch(B, N=30, seed=14)
         outs = {}
-        for variant in (0, 5):
+        for variant in (7, 5):
             eng = workloads.make_solver(w)
             eng.set_option("kernel_variant", variant)
             outs[variant] = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
             outs[variant] = {k: np.array(v) for k, v in outs[variant].items() if isinstance(v, np.ndarray)}
             eng.close()
         for k in ("status", "iters", "polish", "xPred", "uPred", "resid"):
-            assert np.array_equal(outs[0][k], outs[5][k], equal_nan=True), k
-        assert (outs[0]["iters"] > 100).any()
+            assert np.array_equal(outs[7][k], outs[5][k], equal_nan=True), k
+        assert (outs[7]["iters"] > 100).any()
 
 
 @pytest.mark.gpu
@@ -203,7 +203,7 @@ def test_four_wavefront_planner_kernels_are_bit_identical_to_the_two_wavefront_o
     that fills the chip unevenly (several residencies, stragglers to max_iter, polish) and a ragged one -- and straggler deferral
     (park / restore of the four-wavefront image, bounded passes) has to reproduce the plain call bit for bit."""
     from lpvmpc import workloads
-    for N, four_wave, two_wave, sizes in ((40, 0, 6, (1100, 37)), (30, 7, 4, (1300, 5))):
+    for N, four_wave, two_wave, sizes in ((40, 0, 6, (1100, 37)), (30, 0, 4, (1300, 5))):
         for B in sizes:
             w = workloads.planner_batch(B, N=N, seed=21 + B)
             outs = {}
@@ -408,8 +408,6 @@ def test_small_batch_staging_path_equals_direct_copies(lpvmpc):
         ctrl = w["kind"] == "controller"
         cut = lambda n: {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == 640 and k != "track" else v) for k, v in w.items()}
         eng = workloads.make_solver(w)
-        if not ctrl:
-            eng.set_option("kernel_variant", 5)       # one kernel for both sizes (by default a planner N = 30 batch beyond 512 instances takes the three-per-CU DPP kernel, a smaller one the four-wavefront MFMA kernel: equal to round-off, not bit for bit)
         res = []
         for n in (640, 48):
             c = cut(n)
