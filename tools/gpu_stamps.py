@@ -16,8 +16,8 @@ for B in (256, 1024):
         B, *np.median(r, axis=0), np.median(r.sum(1))))
     eng.close()
 
-# planner N = 30: DPP sweeps (default) against the MFMA sweeps (kernel_variant 4, diagnostic)
-for variant in (0, 4):
+# planner N = 30, two wavefronts: DPP sweeps (kernel_variant 5) against the MFMA sweeps (kernel_variant 4)
+for variant in (5, 4):
     w = workloads.planner_batch(512, N=30, seed=1)
     eng = workloads.make_solver(w, adaptive_rho=0, polish=0, check_termination=0, max_iter=200)
     eng.set_option("kernel_variant", variant)

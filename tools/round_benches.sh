@@ -4,7 +4,7 @@ python bench.py > gpurun_out/r04/bench_default.json 2> gpurun_out/r04/bench_defa
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r04/bench_k20_driver_style.json 2> gpurun_out/r04/bench_k20.err
 python bench.py --defer 0 --no-cpu-baseline --no-extras > gpurun_out/r04/bench_default_no_deferral_64_streams.json 2>/dev/null
 python bench.py --workload cfg3 --batch 4096 --steps 40 --warmup 4 --streams 32 > gpurun_out/r04/bench_cfg3_planner.json 2>/dev/null
-python bench.py --workload cfg3 --batch 4096 --steps 40 --warmup 4 --streams 32 --kernel-variant 7 --no-cpu-baseline > gpurun_out/r04/bench_cfg3_planner_four_wave.json 2>/dev/null
+python bench.py --workload cfg3 --batch 4096 --steps 40 --warmup 4 --streams 32 --kernel-variant 7 --no-cpu-baseline > gpurun_out/r04/bench_cfg3_planner_three_per_cu_dpp_kernel.json 2>/dev/null
 python bench.py --workload cfg4 --batch 8192 --steps 24 --warmup 2 > gpurun_out/r04/bench_cfg4_mixed.json 2>/dev/null
 python bench.py --workload cfg5 --steps 620 --warmup 10 > gpurun_out/r04/bench_cfg5_cascade.json 2>/dev/null
 python bench.py --workload cfg5 --steps 620 --warmup 10 --kernel-variant 6 --no-cpu-baseline > gpurun_out/r04/bench_cfg5_cascade_two_wave_kernel.json 2>/dev/null
