@@ -220,6 +220,34 @@ def test_four_wavefront_planner_kernels_are_bit_identical_to_the_two_wavefront_o
             assert np.allclose(outs[four_wave]["resid"][:, 2], outs[two_wave]["resid"][:, 2], rtol=1e-12, atol=1e-12, equal_nan=True)
             if B > 100:
                 assert (outs[four_wave]["iters"] >= 4000).any() and (outs[four_wave]["polish"] == 1).any()
+        # opt-in warm start (shifted) over two ticks, and non-finite inputs (no iteration, NaN out, neighbours untouched): the same on both kernels
+        w = workloads.planner_batch(200, N=N, seed=41)
+        ticks = {}
+        for variant in (four_wave, two_wave):
+            eng = workloads.make_solver(w)
+            eng.set_option("kernel_variant", variant); eng.set_option("warm_start", 2)
+            a = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+            a = {k: np.array(v) for k, v in a.items() if isinstance(v, np.ndarray)}
+            x1 = np.where(np.isfinite(a["xPred"][:, 1, :]), a["xPred"][:, 1, :], w["x0"])
+            b = eng.solve(x1, w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+            b = {k: np.array(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+            bad = w["x0"].copy(); bad[3, 1] = np.nan; bad[77, 0] = np.inf
+            eng.set_option("warm_start", 0)
+            c = eng.solve(bad, w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+            ticks[variant] = (a, b, {k: np.array(v) for k, v in c.items() if isinstance(v, np.ndarray)})
+            eng.close()
+        for t in range(3):
+            for k in ("status", "iters", "polish", "xPred", "uPred"):
+                assert np.array_equal(ticks[four_wave][t][k], ticks[two_wave][t][k], equal_nan=True), (N, "tick", t, k)
+        a, b, c = ticks[four_wave]
+        assert not np.array_equal(a["iters"], b["iters"])            # (the second tick did run from the first one's state)
+        for i in (3, 77):
+            assert c["status"][i] == -10 and c["iters"][i] == 0 and np.all(np.isnan(c["xPred"][i])) and np.all(np.isnan(c["uPred"][i]))
+        rest = np.ones(200, bool); rest[[3, 77]] = False
+        eng = workloads.make_solver(w)
+        clean = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+        eng.close()
+        assert np.array_equal(c["iters"][rest], np.array(clean["iters"])[rest]) and np.array_equal(c["uPred"][rest], np.array(clean["uPred"])[rest], equal_nan=True)
         # deferral on the four-wavefront kernel: parked after 100 iterations, bounded resume passes of 200, joined
         w = workloads.planner_batch(300, N=N, seed=33)
         eng = workloads.make_solver(w, max_iter=1500)
