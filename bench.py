@@ -510,14 +510,14 @@ def early_cpu_baseline(args, world):
 
 
 def other_workloads(args, rank, local_rank, world, dev):
-    """Short legs of configs[2] (planner N = 30, 4096 instances), configs[3] (one GPU's 8192 of the mixed batch) and configs[4]
-    (8192 vehicles, 60 controller ticks of the cascade) behind the headline's timed region: value, roofline fraction of the
+    """Short legs of configs[2] (planner N = 30, 32 steps of 4096 instances on 16 streams), configs[3] (12 steps of one GPU's 8192 of the
+    mixed batch) and configs[4] (8192 vehicles, 120 controller ticks of the cascade) behind the headline's timed region: value, roofline fraction of the
     dominant kernel, its mean launch time and the iteration means, the same code paths as --workload cfg3 / cfg4 / cfg5."""
     import copy
     res = {}
-    legs = (("configs[2]", dict(workload="cfg3", batch=4096, steps=8, warmup=2, streams=4, defer=0, lane_cus=0)),
-            ("configs[3]", dict(workload="cfg4", batch=8192, steps=6, warmup=2, streams=3, defer=0, lane_cus=0)),
-            ("configs[4]", dict(workload="cfg5", batch=8192, steps=60, warmup=2, defer=0, lane_cus=0)))
+    legs = (("configs[2]", dict(workload="cfg3", batch=4096, steps=32, warmup=4, streams=16, defer=0, lane_cus=0)),
+            ("configs[3]", dict(workload="cfg4", batch=8192, steps=12, warmup=2, streams=3, defer=0, lane_cus=0)),
+            ("configs[4]", dict(workload="cfg5", batch=8192, steps=120, warmup=4, defer=0, lane_cus=0)))
     for name, kw in legs:
         a = copy.copy(args)
         for k, v in kw.items():
