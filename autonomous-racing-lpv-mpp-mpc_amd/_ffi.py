@@ -71,8 +71,7 @@ EXPORTS = ("lpvmpc_version", "lpvmpc_default_config", "lpvmpc_create", "lpvmpc_d
            "lpvmpc_local_position_batch", "lpvmpc_global_position_batch", "lpvmpc_plant_step_batch",
            "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read", "lpvmpc_cl_release", "lpvmpc_join", "lpvmpc_resume_time_stats",
            "lpvmpc_handoff_default_config", "lpvmpc_handoff_length", "lpvmpc_handoff_operators", "lpvmpc_handoff_setup",
-           "lpvmpc_handoff_batch", "lpvmpc_cascade_init", "lpvmpc_cascade_tick", "lpvmpc_cascade_read", "lpvmpc_cascade_alive_ticks",
-           "lpvmpc_lane_create", "lpvmpc_lane_destroy", "lpvmpc_lane_step_stream", "lpvmpc_lane_attach", "lpvmpc_lane_drain_count", "lpvmpc_lane_promoted_count", "lpvmpc_lane_trace")
+           "lpvmpc_handoff_batch", "lpvmpc_cascade_init", "lpvmpc_cascade_tick", "lpvmpc_cascade_read", "lpvmpc_cascade_alive_ticks")
 
 _lib = None
 
@@ -154,20 +153,6 @@ def load():
     lib.lpvmpc_cascade_read.argtypes = [vp] + [vp] * 12
     lib.lpvmpc_cascade_alive_ticks.argtypes = [vp, vp]
     lib.lpvmpc_cascade_alive_ticks.restype = C.c_int
-    lib.lpvmpc_lane_create.argtypes = [_i, _i, _i, _i]
-    lib.lpvmpc_lane_create.restype = vp
-    lib.lpvmpc_lane_destroy.argtypes = [vp]
-    lib.lpvmpc_lane_destroy.restype = None
-    lib.lpvmpc_lane_step_stream.argtypes = [vp, _i]
-    lib.lpvmpc_lane_step_stream.restype = vp
-    lib.lpvmpc_lane_attach.argtypes = [vp, vp, _i, _i, _i]
-    lib.lpvmpc_lane_attach.restype = C.c_int
-    lib.lpvmpc_lane_drain_count.argtypes = [vp]
-    lib.lpvmpc_lane_drain_count.restype = C.c_int
-    lib.lpvmpc_lane_promoted_count.argtypes = [vp]
-    lib.lpvmpc_lane_promoted_count.restype = C.c_int
-    lib.lpvmpc_lane_trace.argtypes = [vp, vp, _i]
-    lib.lpvmpc_lane_trace.restype = C.c_int
     for name in ("lpvmpc_handoff_length", "lpvmpc_handoff_operators", "lpvmpc_handoff_setup", "lpvmpc_handoff_batch",
                  "lpvmpc_cascade_init", "lpvmpc_cascade_tick", "lpvmpc_cascade_read"):
         getattr(lib, name).restype = C.c_int

@@ -41,41 +41,6 @@ def _vehicle_params(params, need_min_vel):
     return out
 
 
-class Lane:
-    """Long-runner lane (``lpvmpc_lane_create``, include/lpvmpc.h): ``reserved_cus`` compute units are kept free of step
-    launches -- the ``step_streams`` raw HIP streams in ``.step_streams`` are masked to the other CUs -- and the solvers attached
-    with :meth:`BatchedSolver.attach_lane` finish their promoted stragglers there with the whole-CU tail kernel."""
-
-    def __init__(self, device=0, reserved_cus=8, step_streams=4, ring_entries=64):
-        self._lib = _ffi.load()
-        self._l = self._lib.lpvmpc_lane_create(int(device), int(reserved_cus), int(step_streams), int(ring_entries))
-        if not self._l:
-            msg = self._lib.lpvmpc_last_error(None)
-            raise LpvMpcError(self._lib.lpvmpc_last_error_code() or _ffi.E_ARG, msg.decode() if msg else "lpvmpc_lane_create failed")
-        self.reserved_cus, self.ring_entries = int(reserved_cus), int(ring_entries)
-        self.step_streams = [int(self._lib.lpvmpc_lane_step_stream(self._l, i)) for i in range(int(step_streams))]
-
-    def promoted_count(self):
-        return int(self._lib.lpvmpc_lane_promoted_count(self._l))
-
-    def trace(self, max_records=1024):
-        """Records of the entries the drain launches finished: columns parked_at, restored_at, finished_at (seconds on the device's
-        100 MHz clock), iterations at the hand-over, final iteration count."""
-        out = np.zeros((int(max_records), 5))
-        n = int(self._lib.lpvmpc_lane_trace(self._l, ptr(out), int(max_records)))
-        if n < 0:
-            raise LpvMpcError(n, "lpvmpc_lane_trace failed")
-        out = out[:n].copy()
-        out[:, :3] *= 1e-8
-        return out
-
-    def close(self):
-        """Destroy the lane (after the solvers attached to it have been closed or detached)."""
-        if getattr(self, "_l", None):
-            self._lib.lpvmpc_lane_destroy(self._l)
-            self._l = None
-
-
 class BatchedSolver:
     """Batched LPV-MPC (``kind="controller"``) / LPV-MPP (``kind="planner"``) solver on one MI355X.
 
@@ -168,15 +133,6 @@ class BatchedSolver:
         """Order ``stream`` behind the outstanding resume launches of the straggler deferral (option "defer_after"): the
         outputs of the deferred calls are complete for work enqueued on ``stream`` afterwards."""
         self._chk(self._lib.lpvmpc_join(self._h, C.c_void_p(int(stream))))
-
-    def attach_lane(self, lane, promote_after=200, promote_remaining=0, promote_hard=0):
-        """Attach to (``lane=None``: detach from) a long-runner :class:`Lane`; needs the straggler deferral ("defer_after").
-        ``promote_remaining`` > 0 promotes only the instances predicted to need at least that many more iterations,
-        ``promote_hard`` > 0 everything that reaches that many iterations."""
-        self._chk(self._lib.lpvmpc_lane_attach(self._h, lane._l if lane is not None else None, int(promote_after), int(promote_remaining), int(promote_hard)))
-
-    def lane_drain_count(self):
-        return int(self._lib.lpvmpc_lane_drain_count(self._h))
 
     def resume_time_stats(self):
         tot = C.c_double(0.0); n = C.c_int32(0)

@@ -50,7 +50,6 @@ struct Solver {
     static constexpr bool kFixN = (NT > 0);         // horizon known at compile time
     static constexpr bool kReg = kFixN && !TAIL;    // factor tiles in registers
     static constexpr bool kTwo = (NW == 2);         // two wavefronts per instance: two-sided ("twisted") elimination
-    static constexpr bool kRing = !TAIL && NT == 20 && NW == 2;     // may park into the long-runner ring: the kernels whose image the tail kernel continues
     static constexpr bool kMf = MF;                 // the two sweeps run on the matrix cores (v_mfma_f64_4x4x4_4b_f64), see mf_forward
     // FOUR wavefronts per instance (round 4; planner N = 40 / 30): the same two chains, each RELAYED over two wavefronts -- the
     // "outer" wavefront of a chain (0: top, 1: bottom) holds the operand tiles of chain positions 0 .. kHO-1, the "inner" one
@@ -226,8 +225,6 @@ struct Solver {
     static constexpr __host__ __device__ size_t image_doubles(int N) {
         return (size_t)(N + 1) * ((kFixN ? 1 : 3) * kTS + (GS ? 16 : 19) * 8 + 8) + 16 + 64 + 8 + kRedSize + 64;
     }
-    // offset (doubles) of the tail kernel's RT area in the LDS block (ring_drain_kernel reads the trace words an entry leaves there)
-    static constexpr __host__ __device__ size_t rt_offset(int N) { return image_doubles(N) + (size_t)(N + 1) * 2 * kTS; }
     static constexpr __host__ __device__ size_t lds_doubles(int N) {
         return image_doubles(N) + (TAIL ? (size_t)(N + 1) * (2 * kTS + kDenseRound * 64) + 96 + NW * 128 : 0);
     }
@@ -1965,73 +1962,28 @@ struct Solver {
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
             return ((unsigned long long)hi << 32) | lo;
         };
-        if constexpr (TAIL) {
-            // a ring entry is released as soon as it has been restored: its output pointers were copied to RT[64..70] (restore).
-            // (two separate paths: a pointer that may be LDS or global becomes a flat access, and RT lies beyond the first 64 KB)
-            if (a.ring_drain) {
-                const unsigned long long *pl = reinterpret_cast<const unsigned long long *>(RT + 64);
-                return Outs{(double *)uni(pl[0]), (double *)uni(pl[1]), (int32_t *)uni(pl[2]), (int32_t *)uni(pl[3]), (int32_t *)uni(pl[4]), (double *)uni(pl[5]), (double *)uni(pl[6])};
-            }
-        }
         const unsigned long long *pw = reinterpret_cast<const unsigned long long *>(a.pool_in + (size_t)entry * a.pool_stride + image_doubles(N) + 8);
         return Outs{(double *)uni(pw[0]), (double *)uni(pw[1]), (int32_t *)uni(pw[2]), (int32_t *)uni(pw[3]), (int32_t *)uni(pw[4]), (double *)uni(pw[5]), (double *)uni(pw[6])};
     }
-    __device__ __forceinline__ bool try_park(const SolveArgs &a, int entry, int inst, int iter, int to_chk, int to_adp, bool long_runner) {
-        // long-runner lane: an instance that has come this far -- and, where the launch asks for it, whose residuals of the last two
-        // termination checks predict many more iterations (long_runner) -- goes to the lane's ring when a slot is free (the drain
-        // launch on the lane's reserved CUs finishes it with the tail kernel); otherwise, and below promote_after, into the pool
-        int ring_slot = -1;
-        if constexpr (kRing) {
-            if (a.ring != nullptr && iter >= a.promote_after && (long_runner || (a.promote_hard > 0 && iter >= a.promote_hard))) {
-                if (wv == 0) {      // one load per lane and a ballot instead of a serial walk (a device-scope round trip per slot)
-                    int s_ = -1;
-                    for (int base = 0; base < a.ring_cap && s_ < 0; base += 64) {
-                        const int idx = base + lane;
-                        const int st = idx < a.ring_cap ? __hip_atomic_load(a.ring_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
-                        unsigned long long free_ = __ballot(st == 0);
-                        while (free_ != 0 && s_ < 0) {
-                            const int c_ = __ffsll((long long)free_) - 1;
-                            free_ &= free_ - 1;
-                            int got = 0;
-                            if (lane == 0) got = atomicCAS(a.ring_state + base + c_, 0, 1) == 0 ? 1 : 0;
-                            if (__builtin_amdgcn_readfirstlane(got)) s_ = base + c_;
-                        }
-                    }
-                    if (lane == 0) RED[79] = (double)s_;
-                }
-                sync();
-                ring_slot = (int)RED[79];
-                sync();
-            }
-        }
-        int slot = 0;
-        if (ring_slot < 0) {
-            if (tid == 0) RED[79] = (double)atomicAdd(a.pool_count, 1);
-            sync();
-            slot = (int)RED[79];
-            sync();
-            if (slot >= a.pool_cap) return false;                    // pool full: this instance simply goes on here
-        }
+    __device__ __forceinline__ bool try_park(const SolveArgs &a, int entry, int inst, int iter, int to_chk, int to_adp) {
+        if (tid == 0) RED[79] = (double)atomicAdd(a.pool_count, 1);
+        sync();
+        const int slot = (int)RED[79];
+        sync();
+        if (slot >= a.pool_cap) return false;                    // pool full: this instance simply goes on here
         const int n = (int)image_doubles(N);
-        double *dst = ring_slot >= 0 ? a.ring + (size_t)ring_slot * a.pool_stride : a.pool + (size_t)slot * a.pool_stride;
+        double *dst = a.pool + (size_t)slot * a.pool_stride;
         for (int i = tid; i < n; i += kStride) dst[i] = tA[i];          // tA is the base of the LDS block
         if (tid == 0) {
             double *sc = dst + n;
             sc[0] = c; sc[1] = cinv; sc[2] = rho; sc[3] = (double)iter; sc[4] = (double)to_chk; sc[5] = (double)to_adp; sc[6] = (double)inst;
-            sc[7] = (double)__builtin_amdgcn_s_memrealtime();      // when it was parked (100 MHz device clock): the lane's trace
             const Outs o = outs_of(a, entry);
             unsigned long long *pw = reinterpret_cast<unsigned long long *>(sc + 8);
             pw[0] = (unsigned long long)o.xPred; pw[1] = (unsigned long long)o.uPred; pw[2] = (unsigned long long)o.status;
             pw[3] = (unsigned long long)o.iters; pw[4] = (unsigned long long)o.polish; pw[5] = (unsigned long long)o.resid;
             pw[6] = (unsigned long long)o.state;
-            pw[7] = a.cfg_word;                        // the handle's configuration block (the lane's ring is shared by handles)
             if (o.status) o.status[inst] = LPVMPC_PENDING_;
             if (o.iters) o.iters[inst] = iter;
-        }
-        if (ring_slot >= 0) {      // publish: every thread's stores are visible device-wide before the entry reads "ready"
-            __threadfence();
-            sync();
-            if (tid == 0) { atomicExch(a.ring_state + ring_slot, kCtrl ? 2 : 4); atomicAdd(a.ring_state + a.ring_cap, 1); }      // (ready, by model; the word behind the states counts the promotions)
         }
         return true;
     }
@@ -2046,16 +1998,6 @@ struct Solver {
         iter = (int)sc[3]; to_chk = (int)sc[4]; to_adp = (int)sc[5];
         const int inst = __builtin_amdgcn_readfirstlane((int)sc[6]);
         pol = false;
-        if constexpr (TAIL) {
-            if (a.ring_drain) {     // everything the entry holds is on chip now (output pointers: RT[64..70]): the slot is free again
-                if (tid < 7) reinterpret_cast<unsigned long long *>(RT + 64)[tid] = reinterpret_cast<const unsigned long long *>(sc + 8)[tid];
-                if (tid == 7) { RT[72] = sc[3]; RT[74] = sc[7]; RT[75] = (double)__builtin_amdgcn_s_memrealtime(); }      // trace: iterations so far, promoted at, restored at
-                __threadfence();
-                sync();
-                if (tid == 0) atomicExch(a.ring_state + entry, 0);
-                return inst;
-            }
-        }
         sync();
         return inst;
     }
@@ -2217,23 +2159,7 @@ struct Solver {
                 }
                 recompute_w();              // the residual evaluation used ZT* as scratch (and rho may have changed)
                 // straggler deferral: unsolved at this check and past the budget -> park and end the workgroup (block-uniform)
-                bool long_runner = true;
-                if constexpr (kRing) {
-                    // progress of this instance for the lane's promotion rule: m = how far the worse residual is above its tolerance, kept
-                    // in a spare word of the image (beq[14]) from one termination check to the next; two checks 25 iterations apart give the
-                    // rate, m -> 1 the iterations still to go.  Scheduling only: no result depends on it.
-                    if (checked && a.ring != nullptr && a.promote_remaining > 0) {
-                        const double m_now = fmax(R.pri / (cfg.eps_abs + cfg.eps_rel * R.nAxz), R.dua / (cfg.eps_abs + cfg.eps_rel * R.nPAq));
-                        const double m_prev = beq[14];
-                        sync();
-                        if (tid == 0) beq[14] = m_now;
-                        if (m_prev > m_now && m_now > 1.0) {
-                            const float rem = (float)chk_every * __log2f((float)m_now) / __log2f((float)(m_prev / m_now));
-                            long_runner = rem >= (float)a.promote_remaining;
-                        } else long_runner = m_prev > 0.0 && m_now > 1.0;       // no progress between the two checks (or the first check: unknown)
-                    }
-                }
-                if (checked && defer_after > 0 && iter >= defer_after && iter < max_iter && try_park(a, entry, inst, iter, to_chk, to_adp, long_runner)) return;
+                if (checked && defer_after > 0 && iter >= defer_after && iter < max_iter && try_park(a, entry, inst, iter, to_chk, to_adp)) return;
             }
         }
         if (iter > max_iter) iter = max_iter;
@@ -2297,7 +2223,6 @@ struct Solver {
             return;
         }
 #endif
-        if constexpr (TAIL) { if (tid == 0 && a.ring_drain) RT[73] = (double)iter; }
         if (tid == 0) {
             if (o_.status) o_.status[inst] = status;
             if (o_.iters) o_.iters[inst] = iter;
@@ -2475,129 +2400,6 @@ static hipError_t launch_one(const DevCfg &cfg, const DevCfg *dcfg, const SolveA
         word.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL((admm_solve_kernel<NX, NT, NW, MF, GS, TAIL>), dim3(a.resume ? a.pool_cap : a.B), dim3(64 * NW), lds, stream, dcfg, a);
-    return hipGetLastError();
-}
-
-// Drain launch of the long-runner lane: the tail kernel on the lane's ring (entries of every handle attached to the lane; an
-// entry names its handle's configuration block).  Every workgroup claims a ready entry OF ITS KIND (ring state 2: controller,
-// 4: planner -- one kernel per model, each with its own register allocation), runs it to completion and looks again.
-// The launch is LONG-LIVED: a workgroup that finds nothing ready stays -- polling every few microseconds, on a CU that is
-// reserved for it anyway -- so that an entry promoted at any time during a burst of calls is picked up at once, with no launch,
-// event or barrier packet per call.  It ends when nothing is ready, being written or being worked on AND either the host has
-// asked for it (lpvmpc_join writes the stop word behind the handle's last pass) or every deferred call enqueued so far has
-// completed on the device (the host counts enqueued calls in a word of mapped host memory, a one-thread kernel behind each
-// call's last launch counts completed ones: while they differ, work that may promote is still in flight -- also when the host
-// enqueued a whole burst in a millisecond and went to wait); a bound on the polling trips (~0.5 s) is the safety net.
-// Words behind the states: [cap] promotions so far (diagnostic), [cap + 1] workgroups that hold an entry, [cap + 2] stop,
-// [cap + 3] trace records, [cap + 4] completed calls.
-constexpr int kDrainIdleTrips = 100000;     // ~0.5 s of polling trips (a sleep of ~3.4 us and one pass over the ring each): the safety net, never the normal way out
-// one claimed entry, restored and run to completion: a function of its own (not inlined into the claim loop), so that the solver
-// gets the register allocation of the stand-alone tail kernel instead of sharing it with the loop around it
-#ifdef LPVMPC_LANE_NOINLINE
-#define LPVMPC_DRAIN_ATTR __noinline__
-#else
-#define LPVMPC_DRAIN_ATTR __forceinline__     // (out of line, the LDS base is a run-time value: the update phase alone costs 800 cycles more per iteration)
-#endif
-// (the LDS block arrives as an LDS-typed pointer: a function that names the kernel's dynamic LDS itself looks its base up in a
-// table -- a scalar load and a wait in front of every phase of the iteration)
-typedef __attribute__((address_space(3))) double lds_double;
-template <int NX>
-__device__ LPVMPC_DRAIN_ATTR void ring_drain_entry(const SolveArgs &a, int entry, lds_double *lds) {
-    double *const smem = (double *)lds;
-    using Tail = Solver<NX, 20, 8, false, false, true>;
-    constexpr int kImg = (int)Tail::image_doubles(20);
-    const unsigned long long cw = reinterpret_cast<const unsigned long long *>(a.ring + (size_t)entry * a.pool_stride + kImg + 8)[7];
-    const unsigned cw_lo = __builtin_amdgcn_readfirstlane((unsigned)cw), cw_hi = __builtin_amdgcn_readfirstlane((unsigned)(cw >> 32));      // (uniform: scalar registers)
-    const DevCfg *cfgp = reinterpret_cast<const DevCfg *>(((unsigned long long)cw_hi << 32) | cw_lo);
-    Tail s(*cfgp, smem);
-    s.run(a, 0, entry);
-}
-
-template <int NX>
-__global__ void __launch_bounds__(512, 2) ring_drain_kernel(SolveArgs a) {
-    extern __shared__ __align__(16) double smem[];
-    constexpr int kReady = NX == 6 ? 2 : 4;
-    int32_t *const busy = a.ring_state + a.ring_cap + 1, *const stop = a.ring_state + a.ring_cap + 2, *const calls_done = a.ring_state + a.ring_cap + 4;
-    int idle_trips = 0;         // polling trips since this workgroup last saw work anywhere in the launch (uniform: a scalar register)
-    // The loop is uniform over the workgroup: wavefront 0 makes ONE pass over the ring per trip and publishes the outcome -- an entry,
-    // -1 (leave) or -2 (nothing yet, look again) -- and every wavefront takes the same branch behind the barrier.  (A polling loop
-    // inside the `threadIdx.x == 0` branch is not an option: the compiler turned that shape into a barrier inside a divergent
-    // loop, the other lanes of wavefront 0 ran ahead of lane 0 and read the slot before it was written -- found with rocgdb.)
-    for (;;) {
-        int &claimed = *reinterpret_cast<int *>(smem);
-        if (threadIdx.x < 64) {     // wavefront 0: one load per lane and a ballot per 64 slots
-            const int ln = threadIdx.x;
-            int s_ = -1;
-            bool pending = false;
-            for (int base = 0; base < a.ring_cap && s_ < 0; base += 64) {
-                const int idx = base + ln;
-                const int st = idx < a.ring_cap ? __hip_atomic_load(a.ring_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                unsigned long long ready = __ballot(st == kReady);
-                pending |= __ballot(st == 1 || st == kReady) != 0;
-                while (ready != 0 && s_ < 0) {
-                    const int c_ = __ffsll((long long)ready) - 1;
-                    ready &= ready - 1;
-                    int got = 0;
-                    if (ln == 0) got = atomicCAS(a.ring_state + base + c_, kReady, 3) == kReady ? 1 : 0;
-                    if (__builtin_amdgcn_readfirstlane(got)) s_ = base + c_;
-                }
-            }
-            if (ln == 0) {
-                if (s_ >= 0) { atomicAdd(busy, 1); __threadfence(); }
-                else {
-                    const bool work = pending || __hip_atomic_load(busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                    // nothing to do here: leave when the host asks for it (lpvmpc_join), or when every deferred call the host has enqueued
-                    // so far (a word in host memory, written at enqueue time) has completed on the device (counted behind its last launch)
-                    // -- nothing can be promoted any more until the next call, which finds the tail stream idle and launches a drain again
-                    const bool asked = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                    const bool quiet = a.calls_enqueued == nullptr ||
-                                       __hip_atomic_load(a.calls_enqueued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == __hip_atomic_load(calls_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    s_ = work ? -3 : ((asked || quiet || idle_trips > kDrainIdleTrips) ? -1 : -2);       // -3: look again, the launch is busy
-                }
-                claimed = s_;
-            }
-        }
-        __syncthreads();
-        const int entry = claimed;
-        __syncthreads();              // every wavefront has read the slot before restore() stores the image over it
-        if (entry == -1) return;
-        if (entry < 0) { idle_trips = entry == -2 ? idle_trips + 1 : 0; __builtin_amdgcn_s_sleep(127); continue; }
-        idle_trips = 0;
-        ring_drain_entry<NX>(a, entry, (lds_double *)smem);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (a.trace != nullptr && a.trace_cap > 0) {      // {parked at, restored at, finished at} (100 MHz ticks), iterations at the hand-over, final count
-                const double *rt = smem + Solver<NX, 20, 8, false, false, true>::rt_offset(20);
-                double *rec = a.trace + 5 * (size_t)(atomicAdd(a.ring_state + a.ring_cap + 3, 1) % a.trace_cap);
-                rec[0] = rt[74]; rec[1] = rt[75]; rec[2] = (double)__builtin_amdgcn_s_memrealtime(); rec[3] = rt[72]; rec[4] = rt[73];
-            }
-            __threadfence(); atomicSub(busy, 1);
-        }
-    }
-}
-
-__global__ void lane_call_done_kernel(int32_t *calls_done) { atomicAdd(calls_done, 1); }
-hipError_t launch_lane_call_done(int32_t *calls_done, hipStream_t stream) {
-    hipLaunchKernelGGL(lane_call_done_kernel, dim3(1), dim3(1), 0, stream, calls_done);
-    return hipGetLastError();
-}
-
-hipError_t launch_ring_drain(int kind, const SolveArgs &a, int workgroups, hipStream_t stream) {
-    if (!a.ring || !a.ring_drain || a.pool_in != a.ring || workgroups < 1) return hipErrorInvalidValue;
-    const size_t lds = Solver<6, 20, 8, false, false, true>::lds_doubles(20) * sizeof(double);       // (the same for NX = 5)
-    static std::atomic<uint64_t> attr_mask[2][4];
-    int dev = 0;
-    { hipError_t err = hipGetDevice(&dev); if (err != hipSuccess) return err; }
-    const uint64_t bit = 1ull << (dev & 63);
-    std::atomic<uint64_t> &word = attr_mask[kind == 0 ? 0 : 1][(dev >> 6) & 3];
-    if (!(word.load(std::memory_order_acquire) & bit)) {
-        hipError_t err = kind == 0 ? hipFuncSetAttribute((const void *)ring_drain_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                                   : hipFuncSetAttribute((const void *)ring_drain_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (err != hipSuccess) return err;
-        word.fetch_or(bit, std::memory_order_release);
-    }
-    if (kind == 0) hipLaunchKernelGGL(ring_drain_kernel<6>, dim3(workgroups), dim3(512), lds, stream, a);
-    else hipLaunchKernelGGL(ring_drain_kernel<5>, dim3(workgroups), dim3(512), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -70,7 +70,6 @@ static void free_ws(lpvmpc_handle *h) {
     h->cap = 0;
 }
 
-static const int kLaneTrace = 1024;      // records of finished ring entries kept per lane (lpvmpc_lane_trace)
 static const int kEventRing = 1024;      // event pairs kept by lpvmpc_set_timing (main launches, and separately resume passes)
 extern "C" int lpvmpc_join(lpvmpc_handle *h, void *stream);
 // ---- straggler deferral: the two pools ---------------------------------------------------------------------------------
@@ -104,60 +103,6 @@ static int ensure_defer(lpvmpc_handle *h, int B, hipStream_t st) {
     h->defer_cur_cap = cap; h->defer_stride = stride; h->dcur = 0;
     return LPVMPC_OK;
 }
-// long-runner lane: where a launch of this handle may promote to
-static bool lane_active(const lpvmpc_handle *h) { return h->lane && h->force_generic != 1 && h->force_generic != 2; }     // (the ring holds compile-time-horizon two-wavefront images)
-static void ring_args(const lpvmpc_handle *h, SolveArgs &a) {
-    if (!lane_active(h)) return;
-    a.ring = h->lane->ring; a.ring_state = h->lane->ring_state; a.ring_cap = h->lane->ring_cap; a.promote_after = h->promote_after;
-    a.cfg_word = (unsigned long long)h->d_cfg; a.promote_remaining = h->promote_remaining; a.promote_hard = h->promote_hard;
-}
-static int drain_launch(lpvmpc_handle *h, lpvmpc_lane *ln) {
-    SolveArgs a{};
-    a.resume = 1; a.tail = 1; a.defer_after = 0; a.x0_stride = h->nx;
-    a.pool_in = ln->ring; a.pool_stride = ln->stride; a.pool_cap = ln->ring_cap;
-    a.ring = ln->ring; a.ring_state = ln->ring_state; a.ring_cap = ln->ring_cap; a.ring_drain = 1;
-    a.trace = ln->trace; a.trace_cap = kLaneTrace; a.calls_enqueued = ln->d_enq;
-    HIP_TRY(h, lpvmpc::launch_ring_drain(h->cfg.kind, a, ln->reserved, ln->tail));
-    h->lane_drains++;
-    return LPVMPC_OK;
-}
-// Behind a deferred call: make sure a long-lived drain launch of this handle's model is on the lane's tail stream.  It polls the
-// ring, so nothing orders it behind the call (entries are published with device-scope fences); the first call of a burst
-// launches it; it leaves when lpvmpc_join asks for it or when every enqueued call has completed and the ring is empty.  (One launch, event and barrier packet per call -- the first design -- cost 50 us each
-// on the one tail stream and piled up behind the burst.)
-static int lane_drain(lpvmpc_handle *h, hipStream_t st) {
-    lpvmpc_lane *ln = h->lane;
-    if (!lane_active(h)) return LPVMPC_OK;
-    (void)st;
-    std::lock_guard<std::mutex> g(ln->mu);
-    const int k = h->cfg.kind == LPVMPC_KIND_CONTROLLER ? 0 : 1;
-    // a drain leaves when every call enqueued so far has completed: an idle tail stream means none is alive
-    const bool idle = hipStreamQuery(ln->tail) == hipSuccess;
-    if (idle) ln->drain_active[0] = ln->drain_active[1] = false;
-    if (!ln->drain_active[0] && !ln->drain_active[1]) HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(ln->ring_state + ln->ring_cap + 2), 0, 1, ln->tail));    // new burst: clear the stop word (behind the last drain)
-    if (!ln->drain_active[k]) {
-        int rc = drain_launch(h, ln); if (rc) return rc;
-        ln->drain_active[k] = true;
-    }
-    h->lane_used = true;
-    return LPVMPC_OK;
-}
-// lpvmpc_join: behind the handle's last pass on `st` the long-lived drain is asked to stop, one more drain launch -- ordered
-// behind `st` -- takes whatever the ring still holds (also when the long-lived one has given up meanwhile), and `st` waits for it
-static int lane_join(lpvmpc_handle *h, hipStream_t st) {
-    lpvmpc_lane *ln = h->lane;
-    if (!ln || !h->lane_used) return LPVMPC_OK;
-    std::lock_guard<std::mutex> g(ln->mu);
-    HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(ln->ring_state + ln->ring_cap + 2), 1, 1, st));
-    HIP_TRY(h, hipEventRecord(h->lane_event, st));
-    HIP_TRY(h, hipStreamWaitEvent(ln->tail, h->lane_event, 0));
-    int rc = drain_launch(h, ln); if (rc) return rc;
-    HIP_TRY(h, hipEventRecord(ln->tail_ev, ln->tail));
-    HIP_TRY(h, hipStreamWaitEvent(st, ln->tail_ev, 0));
-    ln->drain_active[0] = ln->drain_active[1] = false;
-    h->lane_used = false;
-    return LPVMPC_OK;
-}
 // one resume pass on `st`: continues the entries of pool[dcur] for `budget` more iterations (0 = to completion), parks the
 // unfinished ones in the other pool, which becomes the current one
 static int resume_pass(lpvmpc_handle *h, int budget, hipStream_t st) {
@@ -167,7 +112,6 @@ static int resume_pass(lpvmpc_handle *h, int budget, hipStream_t st) {
     a.pool_in = h->dpool[A]; a.pool_in_count = h->dcount[A];
     a.pool = h->dpool[Bp]; a.pool_count = h->dcount[Bp];
     a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride; a.x0_stride = h->nx;
-    if (budget > 0) ring_args(h, a);          // a bounded pass promotes what has come far enough (a pass to completion parks nothing)
     const int slot = h->rv_count % kEventRing;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->rv0[slot], st));
     HIP_TRY(h, lpvmpc::launch_solve(h->dev, h->d_cfg, a, st, h->force_generic));
@@ -220,7 +164,6 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->defer_after = 0; h->defer_budget = 200; h->defer_cap = 0; h->defer_cur_cap = 0; h->defer_stride = 0; h->rv_count = 0;
     h->dpool[0] = h->dpool[1] = nullptr; h->dcount[0] = h->dcount[1] = nullptr; h->dcur = 0; h->defer_stream = nullptr; h->defer_event = nullptr;
     h->defer_stream_set = false; h->defer_tail = 1; h->defer_skip_pass = false;
-    h->lane = nullptr; h->promote_after = 0; h->promote_remaining = 0; h->promote_hard = 0; h->lane_event = nullptr; h->lane_used = false; h->lane_drains = 0;
     h->h_pack_in = h->h_pack_out = h->d_pack_in = h->d_pack_out = nullptr;
     DevCfg &d = h->dev;
     std::memset(&d, 0, sizeof(d));
@@ -275,7 +218,6 @@ extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
     if (h->d_FWop) (void)hipFree(h->d_FWop);
     if (h->d_cfg) (void)hipFree(h->d_cfg);
     free_defer(h);
-    if (h->lane_event) (void)hipEventDestroy(h->lane_event);
     if (h->defer_event) (void)hipEventDestroy(h->defer_event);
     for (hipEvent_t e : h->rv0) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->rv1) (void)hipEventDestroy(e);
@@ -586,8 +528,6 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
         // defer_budget more iterations.  No launch lasts much longer than its budget, so the stream is never held by one slow
         // instance; lpvmpc_join runs the pass that finishes whatever is still parked.
         rc = ensure_defer(h, B, st); if (rc) return rc;
-        const bool laned = lane_active(h) && !h->defer_skip_pass;
-        if (laned) { std::lock_guard<std::mutex> g(h->lane->mu); __atomic_add_fetch(h->lane->h_enq, 1, __ATOMIC_SEQ_CST); }      // (before the call's first launch: a drain never sees "all done" while this call is on its way)
         if (h->defer_stream_set && h->defer_stream != st) {        // the pools are ordered by stream: hand them over
             HIP_TRY(h, hipEventRecord(h->defer_event, h->defer_stream));
             HIP_TRY(h, hipStreamWaitEvent(st, h->defer_event, 0));
@@ -595,16 +535,10 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
         h->defer_stream = st; h->defer_stream_set = true;
         a.defer_after = h->defer_after; a.resume = 0; a.pool = h->dpool[h->dcur]; a.pool_count = h->dcount[h->dcur];
         a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride;
-        if (laned && h->promote_after <= ((h->defer_after + 24) / 25) * 25) ring_args(h, a);     // (promotion straight from the call's own launch)
         rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
         // the bounded pass behind the call -- unless the caller joins right away (budget -1, and the synchronous host-array entry
         // point): then the closing pass (the tail kernel) takes the parked instances straight from this launch
         if (h->defer_budget >= 0 && !h->defer_skip_pass) { rc = resume_pass(h, h->defer_budget, st); if (rc) return rc; }
-        // long-runner lane: whatever this call's launches promoted is finished on the lane's reserved CUs, beside the step streams
-        if (laned) {
-            HIP_TRY(h, lpvmpc::launch_lane_call_done(h->lane->ring_state + h->lane->ring_cap + 4, st));
-            rc = lane_drain(h, st); if (rc) return rc;
-        }
     } else {
         rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
     }
@@ -622,9 +556,7 @@ extern "C" int lpvmpc_join(lpvmpc_handle *h, void *stream) {
         HIP_TRY(h, hipStreamWaitEvent(st, h->defer_event, 0));
     }
     h->defer_stream = st; h->defer_stream_set = true;
-    int rc = resume_pass(h, 0, st);                                // to completion: nothing stays parked
-    if (rc) return rc;
-    return lane_join(h, st);                                       // ... and nothing stays in the ring: `st` waits for the drain launches
+    return resume_pass(h, 0, st);                                  // to completion: nothing stays parked
 }
 
 extern "C" int lpvmpc_resume_time_stats(lpvmpc_handle *h, double *total_ms, int32_t *count) {
@@ -675,105 +607,6 @@ extern "C" int lpvmpc_solve_batch(lpvmpc_handle *h, int32_t B, const double *x0,
     if (rc) return rc;
     if (h->defer_after > 0) { rc = lpvmpc_join(h, (void *)st); if (rc) return rc; }      // a synchronous call returns finished instances only
     return io.flush_out();
-}
-
-// ------------------------------------------------------------------------------------------------
-// long-runner lane (include/lpvmpc.h: lpvmpc_lane_*)
-// ------------------------------------------------------------------------------------------------
-static const int kXccs = 8;     // gfx950: bit i of a CU mask is a CU of XCC i mod 8; a mask must leave every XCC at least one CU
-                                // (tools/microbench/cumask_probe.hip: a mask with no CU in an XCC lets that XCC run on all of its CUs)
-extern "C" lpvmpc_lane *lpvmpc_lane_create(int32_t device, int32_t reserved_cus, int32_t step_streams, int32_t ring_entries) {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fail(nullptr, LPVMPC_E_NODEVICE, "lpvmpc_lane_create: no HIP device available"); return nullptr; }
-    if (device < 0 || device >= ndev) { fail(nullptr, LPVMPC_E_ARG, "lpvmpc_lane_create: device %d of %d", device, ndev); return nullptr; }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail(nullptr, LPVMPC_E_HIP, "lpvmpc_lane_create: hipGetDeviceProperties failed"); return nullptr; }
-    const int ncu = prop.multiProcessorCount;
-    if (reserved_cus < kXccs || reserved_cus % kXccs != 0 || reserved_cus > ncu / 2 || step_streams < 0 || step_streams > 64 || ring_entries < 1 || ring_entries > 4096) {
-        fail(nullptr, LPVMPC_E_ARG, "lpvmpc_lane_create: reserved_cus must be a multiple of %d in [%d, %d], step_streams in [0, 64], ring_entries in [1, 4096]", kXccs, kXccs, ncu / 2);
-        return nullptr;
-    }
-    if (hipSetDevice(device) != hipSuccess) { fail(nullptr, LPVMPC_E_HIP, "hipSetDevice(%d) failed", device); return nullptr; }
-    lpvmpc_lane *ln = new (std::nothrow) lpvmpc_lane();
-    if (!ln) { fail(nullptr, LPVMPC_E_NOMEM, "out of host memory"); return nullptr; }
-    ln->device = device; ln->reserved = reserved_cus; ln->tail = nullptr; ln->tail_ev = nullptr; ln->ring = nullptr; ln->ring_state = nullptr; ln->trace = nullptr; ln->h_enq = nullptr; ln->d_enq = nullptr;
-    ln->ring_cap = ring_entries; ln->stride = entry_stride_for(20);
-    ln->drain_active[0] = ln->drain_active[1] = false;
-    const int words = (ncu + 31) / 32;
-    std::vector<uint32_t> mres(words, 0), mcomp(words, 0);
-    for (int i = 0; i < ncu; ++i) (i < reserved_cus ? mres : mcomp)[i / 32] |= 1u << (i % 32);
-    bool ok = hipExtStreamCreateWithCUMask(&ln->tail, words, mres.data()) == hipSuccess && hipEventCreateWithFlags(&ln->tail_ev, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < step_streams && ok; ++i) {
-        hipStream_t s = nullptr;
-        ok = hipExtStreamCreateWithCUMask(&s, words, mcomp.data()) == hipSuccess;
-        if (s) ln->step.push_back(s);
-    }
-    ok = ok && hipHostMalloc((void **)&ln->h_enq, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void **)&ln->d_enq, ln->h_enq, 0) == hipSuccess;
-    if (ok) *ln->h_enq = 0;
-    ok = ok && hipMalloc((void **)&ln->ring, (size_t)ring_entries * ln->stride * 8) == hipSuccess
-            && hipMalloc((void **)&ln->trace, (size_t)kLaneTrace * 5 * 8) == hipSuccess && hipMemset(ln->trace, 0, (size_t)kLaneTrace * 5 * 8) == hipSuccess
-            && hipMalloc((void **)&ln->ring_state, (size_t)(ring_entries + 2) * 4 + 256) == hipSuccess         // (+ room for the diagnostic words of LPVMPC_LANE_DEBUG builds)
-            && hipMemset(ln->ring_state, 0, (size_t)(ring_entries + 2) * 4 + 256) == hipSuccess;
-    if (!ok) { fail(nullptr, LPVMPC_E_HIP, "lpvmpc_lane_create: creating the CU-masked streams / the ring failed: %s", hipGetErrorString(hipGetLastError())); lpvmpc_lane_destroy(ln); return nullptr; }
-    return ln;
-}
-
-extern "C" void lpvmpc_lane_destroy(lpvmpc_lane *ln) {
-    if (!ln) return;
-    (void)hipSetDevice(ln->device);
-    if (ln->ring_state) { const int32_t one = 1; (void)hipMemcpy(ln->ring_state + ln->ring_cap + 2, &one, 4, hipMemcpyHostToDevice); }     // a drain that is still polling leaves
-    (void)hipDeviceSynchronize();
-    if (ln->tail) (void)hipStreamDestroy(ln->tail);
-    for (hipStream_t s : ln->step) (void)hipStreamDestroy(s);
-    if (ln->tail_ev) (void)hipEventDestroy(ln->tail_ev);
-    if (ln->ring) (void)hipFree(ln->ring);
-    if (ln->ring_state) (void)hipFree(ln->ring_state);
-    if (ln->trace) (void)hipFree(ln->trace);
-    if (ln->h_enq) (void)hipHostFree(ln->h_enq);
-    delete ln;
-}
-
-extern "C" void *lpvmpc_lane_step_stream(lpvmpc_lane *ln, int32_t i) {
-    return (ln && i >= 0 && (size_t)i < ln->step.size()) ? (void *)ln->step[i] : nullptr;
-}
-
-extern "C" int lpvmpc_lane_attach(lpvmpc_handle *h, lpvmpc_lane *ln, int32_t promote_after, int32_t promote_remaining, int32_t promote_hard) {
-    if (!h) return fail(nullptr, LPVMPC_E_ARG, "lpvmpc_lane_attach: handle is NULL");
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
-    // whatever is parked or promoted under the old attachment is finished first
-    if (h->dpool[0] || h->lane_used) {
-        hipStream_t st = h->defer_stream_set ? h->defer_stream : h->stream;
-        int rc = lpvmpc_join(h, (void *)st); if (rc) return rc;
-        HIP_TRY(h, hipStreamSynchronize(st));
-    }
-    if (!ln) { h->lane = nullptr; return LPVMPC_OK; }
-    if (ln->device != h->cfg.device) return fail(h, LPVMPC_E_ARG, "lpvmpc_lane_attach: the lane belongs to device %d, the handle to device %d", ln->device, h->cfg.device);
-    if (h->cfg.N != 20) return fail(h, LPVMPC_E_ARG, "lpvmpc_lane_attach: the tail kernel that drains a lane exists for N = 20 (controller and planner); this handle has N = %d", h->cfg.N);
-    if (promote_after < 25 || promote_remaining < 0 || promote_hard < 0) return fail(h, LPVMPC_E_ARG, "lpvmpc_lane_attach: promote_after >= 25 (iterations), promote_remaining >= 0, promote_hard >= 0");
-    if (!h->lane_event) HIP_TRY(h, hipEventCreateWithFlags(&h->lane_event, hipEventDisableTiming));
-    h->lane = ln; h->promote_after = promote_after; h->promote_remaining = promote_remaining; h->promote_hard = promote_hard; h->lane_used = false;
-    return LPVMPC_OK;
-}
-
-extern "C" int lpvmpc_lane_drain_count(const lpvmpc_handle *h) { return h ? h->lane_drains : 0; }
-extern "C" int lpvmpc_lane_debug_words(lpvmpc_lane *ln, unsigned long long *out20) {      // LPVMPC_LANE_DEBUG builds of the drain kernel
-    if (!ln || !out20) return LPVMPC_E_ARG;
-    if (hipSetDevice(ln->device) != hipSuccess || hipMemcpy(out20, ln->ring_state + ln->ring_cap + 2, 160, hipMemcpyDeviceToHost) != hipSuccess) return LPVMPC_E_HIP;
-    return LPVMPC_OK;
-}
-extern "C" int lpvmpc_lane_trace(lpvmpc_lane *ln, double *records, int32_t max_records) {
-    if (!ln || !records || max_records < 0) return LPVMPC_E_ARG;
-    int32_t n = 0;
-    if (hipSetDevice(ln->device) != hipSuccess || hipMemcpy(&n, ln->ring_state + ln->ring_cap + 3, 4, hipMemcpyDeviceToHost) != hipSuccess) return LPVMPC_E_HIP;
-    const int m = n < kLaneTrace ? n : kLaneTrace, k = m < max_records ? m : max_records;
-    if (k > 0 && hipMemcpy(records, ln->trace, (size_t)k * 5 * 8, hipMemcpyDeviceToHost) != hipSuccess) return LPVMPC_E_HIP;
-    return k;
-}
-extern "C" int lpvmpc_lane_promoted_count(lpvmpc_lane *ln) {
-    if (!ln) return 0;
-    int32_t n = 0;
-    if (hipSetDevice(ln->device) != hipSuccess || hipMemcpy(&n, ln->ring_state + ln->ring_cap, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return n;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -83,31 +83,15 @@ struct SolveArgs {
     // resume launches that run to completion (defer_after == 0): 1 = take the whole-CU tail kernel where one exists for the
     // handle's (kind, N) (lpvmpc_set_option "defer_tail", default on); it continues the same pool entries
     int tail;
-    // long-runner lane (lpvmpc_lane_attach): a launch that parks an instance at iter >= promote_after puts it into the lane's
-    // RING instead of the pool when a slot is free -- ring_state[i]: 0 free, 1 being written, 2 / 4 ready (controller / planner entry), 3 taken -- and a drain
-    // launch of the tail kernel on the stream masked to the lane's reserved CUs (ring_drain = 1: every workgroup claims ready
-    // entries and runs them to completion) finishes it there, beside the launches of the step streams
-    double *ring;
-    int32_t *ring_state;
-    int ring_cap, promote_after, ring_drain;
-    int promote_remaining;           // > 0: promote only what the residuals of the last two checks predict to need at least that many more iterations
-    int promote_hard;                // > 0: at this many iterations an instance is promoted whatever the prediction says
-    const int32_t *calls_enqueued;   // drain launches: deferred calls the host has enqueued so far (mapped host memory), or null
-    double *trace;                   // drain launches: [trace_cap][5] records of the entries they finished (lpvmpc_lane_trace), or null
-    int trace_cap;
-    unsigned long long cfg_word;     // the launching handle's device configuration block (recorded in the entries it parks)
 };
 constexpr int kParkScalars = 16;     // behind the LDS image of a pool entry: c, cinv, rho, iter, to_chk, to_adp, instance index and the
-                                     // instance's output pointers (xPred, uPred, status, iters, polish, resid, state) and its handle's DevCfg as 64-bit words
+                                     // instance's output pointers (xPred, uPred, status, iters, polish, resid, state) as 64-bit words
 constexpr int LPVMPC_PENDING_ = -11; // status of a parked instance until its resume launch has finished it (lpvmpc.h: LPVMPC_PENDING)
 
 // host-side launchers (defined next to their kernels)
 int solve_has_fast_path(int kind, int N);
 size_t solve_lds_bytes(int kind, int N);
 hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &a, hipStream_t stream, int force_generic);
-// drain launch of the long-runner lane (tail kernel over the lane's ring; controller / planner entries at N = 20): `workgroups` = the lane's reserved CUs
-hipError_t launch_ring_drain(int kind, const SolveArgs &a, int workgroups, hipStream_t stream);
-hipError_t launch_lane_call_done(int32_t *calls_done, hipStream_t stream);      // behind a deferred call's last launch: one more call has completed
 hipError_t launch_lpv(const DevCfg &cfg, const DevCfg *dcfg, int B, const double *x0, const double *u_prev, const double *vel_ref,
                       const double *curv_s, double cf_new, int lap, double *states, double *AB, hipStream_t stream);
 hipError_t launch_abc(const DevCfg &cfg, const DevCfg *dcfg, int B, const double *xlast, const double *delta, double *AB, hipStream_t stream);

@@ -5,7 +5,6 @@
 
 #include <cstdarg>
 #include <cstdio>
-#include <mutex>
 #include <string>
 #include <vector>
 
@@ -15,25 +14,6 @@
 #define LPVMPC_HIDDEN __attribute__((visibility("hidden")))
 
 struct lpvmpc_cascade;       // cascade_api.hip
-
-// Long-runner lane (lpvmpc_lane_create): a few CUs of the device are taken out of the step streams' CU masks and given to
-// "tail" streams on which the handles attached to the lane drain their rings of promoted stragglers (SolveArgs::ring) with the
-// whole-CU tail kernel -- beside the step launches, without competing with them for a CU.
-struct lpvmpc_lane {
-    int device, reserved;
-    hipStream_t tail;                         // masked to the reserved CUs: carries the drain launches, one at a time (eight whole-CU
-                                              // workgroups always find their CUs: a dispatch that cannot place its workgroups holds up the
-                                              // other queues of its dispatcher pipe -- measured)
-    hipEvent_t tail_ev;                       // lpvmpc_join orders the caller's stream behind the tail stream
-    std::vector<hipStream_t> step;            // masked to the complement
-    double *ring;                             // [ring_cap][stride]: promoted stragglers of every attached handle
-    int32_t *ring_state;                      // [ring_cap] 0 free, 1 being written, 2 / 4 ready (controller / planner), 3 taken; [cap] promotions, [cap + 1] busy workgroups
-    int ring_cap, stride;
-    int32_t *h_enq, *d_enq;                   // deferred calls enqueued so far by the attached handles: a word of mapped host memory and its device address
-    double *trace;                            // [kLaneTrace][5]: the entries the drain launches finished (diagnostic, cyclic)
-    bool drain_active[2];                     // a long-lived drain launch (controller / planner kernel) has been put on the tail stream since the last join
-    std::mutex mu;                            // handles of one lane may be driven from different threads
-};
 
 using lpvmpc::DevCfg;
 using lpvmpc::SolveArgs;
@@ -85,12 +65,6 @@ struct lpvmpc_handle {
     hipEvent_t defer_event;
     std::vector<hipEvent_t> rv0, rv1;   // event pairs around the resume launches (timing)
     int rv_count;
-    // long-runner lane (lpvmpc_lane_attach): launches of this handle promote into the lane's ring
-    lpvmpc_lane *lane;
-    int promote_after, promote_remaining, promote_hard;
-    hipEvent_t lane_event;              // orders a drain launch behind the pass that may have filled the ring
-    bool lane_used;                     // drain launches of this handle since its last join
-    int lane_drains;                    // drain launches so far (diagnostic)
     int cascade_prefetch;               // option "cascade_prefetch" (default 1)
     lpvmpc_cascade *cascade;            // owned by the controller handle of a cascade (lpvmpc_cascade_init)
     lpvmpc_handle *cascade_owner;       // planner handle: the controller handle whose cascade drives it (its workspace carries the planner recursion)

@@ -71,17 +71,6 @@ def main():
                          "long as its slowest instance); default: 100 for the headline workload, 0 otherwise")
     ap.add_argument("--defer-budget", type=int, default=100, help="iterations per resume pass of the straggler deferral (0 = to completion)")
     ap.add_argument("--defer-pool", type=int, default=0, help="entries of each of the two pools of parked instances (0 = max(64, B / 8))")
-    ap.add_argument("--lane-cus", type=int, default=-1,
-                    help="long-runner lane (lpvmpc_lane_create): CUs taken out of the step streams' CU masks and reserved for the whole-CU tail "
-                         "kernel, which finishes there -- beside the step launches -- the stragglers that are still unsolved after "
-                         "--promote-after iterations; a multiple of 8; 0 = no lane (stragglers wait for the closing passes; the default: a 1024-instance "
-                         "batch is exactly one residency of the 256 CUs, so every reserved CU turns each step into a two-wave launch)")
-    ap.add_argument("--promote-after", type=int, default=200, help="iterations after which a parked instance is promoted to the lane's ring")
-    ap.add_argument("--promote-remaining", type=int, default=400,
-                    help="promote only the instances whose residuals at the last two termination checks predict at least this many more "
-                         "iterations (0 = everything that is still unsolved after --promote-after)")
-    ap.add_argument("--promote-hard", type=int, default=300, help="iterations from which an instance is promoted whatever the prediction says (0 = none)")
-    ap.add_argument("--lane-ring", type=int, default=64, help="entries of the lane's ring (a full ring leaves an instance with the bounded passes)")
     ap.add_argument("--fleet-groups", type=int, default=4, help="cfg5: independent sub-fleets (engine pairs) the vehicles are cut into")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs outside the timed region (serial steps, batch latencies, one launch of all distinct "
@@ -99,8 +88,6 @@ def main():
         args.defer = 100 if args.workload == "cfg2" else 0
     if args.streams <= 0:
         args.streams = 4 if args.defer > 0 else 64          # with deferral no launch is long: a few streams fill the GPU
-    if args.lane_cus < 0:
-        args.lane_cus = 0          # measured (profiles/r04_lane_ab.txt): taking CUs from the step launches costs this workload more than the early tail start gains
 
     # --gpus N given to a plain `python bench.py`: become the launcher.  Nothing has touched the GPU yet (torch is not
     # even imported), the children are fresh processes (never an exec of a process that initialised HIP).
@@ -176,15 +163,7 @@ def main():
         e.set_option("defer_pool", args.defer_pool)
         e.set_option("defer_after", args.defer)
         e.set_option("defer_budget", args.defer_budget)
-    lane = None
-    if args.lane_cus > 0 and args.defer > 0 and not planner:
-        # the step streams are the lane's (masked to the CUs it did not reserve); every engine gets a ring on the lane
-        lane = lpvmpc.Lane(device=local_rank, reserved_cus=args.lane_cus, step_streams=S, ring_entries=args.lane_ring)
-        streams = [RawStream(p) for p in lane.step_streams]
-        for e in engines:
-            e.attach_lane(lane, promote_after=args.promote_after, promote_remaining=args.promote_remaining, promote_hard=args.promote_hard)
-    else:
-        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
 
     def new_outs(n):
         return dict(xPred=torch.empty((n, N + 1, nx), dtype=torch.float64, device=dev),
@@ -397,11 +376,6 @@ def main():
                                         ("configs[2]: batch=%d LPV-MPP planner solves per GPU (velocity-max cost), N=30, "
                                          "L-shape track, OSQP defaults + polish, cold start" % B),
                             "batch_per_gpu": B, "horizon": N, "nx": nx, "nu": 2, "streams": S, "defer_after": args.defer, "defer_budget": args.defer_budget,
-                            "lane": ({"reserved_cus": args.lane_cus, "promote_after": args.promote_after, "promote_remaining": args.promote_remaining, "promote_hard": args.promote_hard,
-                                      "ring_entries": args.lane_ring, "drain_launches": sum(e.lane_drain_count() for e in engines),
-                                      "promoted_instances": lane.promoted_count(), "trace": lane_trace_summary(lane),
-                                      "note": "step streams masked to the other CUs (hipExtStreamCreateWithCUMask); promoted stragglers are "
-                                              "finished on the reserved CUs by the whole-CU tail kernel while the steps go on"} if lane else None),
                             "distinct_batches_timed": len(used), "batch_seeds": "step j solves batch j mod %d = seed %d + (j mod %d) + 1000 rank" % (NBAT, 1 if planner else 0, NBAT),
                             "mean_admm_iters": agg[0] / total,
                             "max_admm_iters_rank0": int(max(it_slot[i].max() for i in used)),
@@ -454,8 +428,6 @@ def main():
 
     for e in engines:
         e.close()
-    if lane is not None:
-        lane.close()
     finish(world)
 
 
@@ -515,9 +487,9 @@ def other_workloads(args, rank, local_rank, world, dev):
     dominant kernel, its mean launch time and the iteration means, the same code paths as --workload cfg3 / cfg4 / cfg5."""
     import copy
     res = {}
-    legs = (("configs[2]", dict(workload="cfg3", batch=4096, steps=32, warmup=4, streams=16, defer=0, lane_cus=0)),
-            ("configs[3]", dict(workload="cfg4", batch=8192, steps=12, warmup=2, streams=3, defer=0, lane_cus=0)),
-            ("configs[4]", dict(workload="cfg5", batch=8192, steps=120, warmup=4, defer=0, lane_cus=0)))
+    legs = (("configs[2]", dict(workload="cfg3", batch=4096, steps=32, warmup=4, streams=16, defer=0)),
+            ("configs[3]", dict(workload="cfg4", batch=8192, steps=12, warmup=2, streams=3, defer=0)),
+            ("configs[4]", dict(workload="cfg5", batch=8192, steps=120, warmup=4, defer=0)))
     for name, kw in legs:
         a = copy.copy(args)
         for k, v in kw.items():
@@ -586,29 +558,6 @@ def bench_planner_leg(args, rank, local_rank, world, dev):
             "roofline": {"bound": "hbm", "frac": bl / k_avg_s / 1e9 / HBM_PEAK_GBS, "kernel": "admm_solve_kernel<5, 30, 4, MFMA sweeps, chains relayed over four wavefronts>",
                          "kernel_avg_ms": kms / max(kn, 1), "launches": kn, "algorithmic_bytes_per_launch": bl, "bytes_per_admm_iteration": bi,
                          "note": "launches of the %d streams overlap: kernel_avg_ms is a launch sharing the chip" % S}}
-
-
-def lane_trace_summary(lane):
-    """What the lane's drain launches did with the promoted instances (lpvmpc_lane_trace): how long an entry waited for a reserved
-    CU and the five longest ones (times in ms; `at` = parked, relative to the first record's parking)."""
-    import numpy as np
-    tr = lane.trace()
-    if len(tr) == 0:
-        return None
-    wait = (tr[:, 1] - tr[:, 0]) * 1e3
-    run = (tr[:, 2] - tr[:, 1]) * 1e3
-    t0 = tr[:, 0].min()
-    top = np.argsort(-tr[:, 4])[:5]
-    return {"records": int(len(tr)), "wait_ms_p50": float(np.median(wait)), "wait_ms_max": float(wait.max()),
-            "cu_ms_total": float(run.sum()),
-            "longest": [{"at": round(float((tr[i, 0] - t0) * 1e3), 3), "from_iter": int(tr[i, 3]), "iters": int(tr[i, 4]), "wait_ms": round(float(wait[i]), 3),
-                         "run_ms": round(float(run[i]), 3), "us_per_iter": round(float(run[i] * 1e3 / max(tr[i, 4] - tr[i, 3], 1)), 3)} for i in top]}
-
-
-class RawStream:
-    """A HIP stream that is not torch's (the lane's CU-masked streams): only its handle is needed here."""
-    def __init__(self, ptr):
-        self.cuda_stream = ptr
 
 
 def finish(world):

@@ -158,44 +158,9 @@ int lpvmpc_join(lpvmpc_handle *h, void *stream);
 /* Like lpvmpc_kernel_time_stats (below) for the resume launches of the straggler deferral. */
 int lpvmpc_resume_time_stats(lpvmpc_handle *h, double *total_ms, int32_t *count);
 
-/*
- * LONG-RUNNER LANE (no counterpart in the reference; opt-in, on top of the straggler deferral).  The one instance in a
- * thousand that needs thousands of ADMM iterations is a serial chain: it ends sooner only if it gets a compute unit to itself
- * EARLY, and the whole-CU tail kernel ("defer_tail") only gets one on a busy device when no step launch competes for it.
- * A lane takes `reserved_cus` CUs out of the CU masks of the `step_streams` streams it hands out and gives them to a tail
- * stream of its own (hipExtStreamCreateWithCUMask; gfx950: reserved_cus is a multiple of 8 -- one CU per XCC and step of 8).
- * A handle attached to a lane (controller or planner, N = 20) promotes an instance that is parked at iter >= promote_after
- * into the lane's ring of `ring_entries` slots, shared by the attached handles (a full ring leaves the instance in the
- * handle's pool, as without a lane); every deferred call is followed by a drain launch of the tail kernel on the tail stream
- * (ordered behind the call's launches by an event): one workgroup per reserved CU, each claiming ready ring entries and running
- * them to completion while the step streams go on.  The deferred calls must be issued on the lane's step streams
- * (lpvmpc_lane_step_stream) for the reserved CUs to be free of step workgroups; any stream works, only slower.  lpvmpc_join
- * also orders its stream behind the drain launches enqueued so far (of every attached handle).  Results are those of the tail
- * kernel ("defer_tail"), whatever that option says.  Destroy (or detach: lane = NULL) the handles before the lane.  Several
- * handles may share a lane, also from different threads.
- */
-typedef struct lpvmpc_lane lpvmpc_lane;
-lpvmpc_lane *lpvmpc_lane_create(int32_t device, int32_t reserved_cus, int32_t step_streams, int32_t ring_entries);
-void lpvmpc_lane_destroy(lpvmpc_lane *lane);
-/* hipStream_t number i (0 .. step_streams-1) masked to the CUs the lane did not reserve; NULL when out of range. */
-void *lpvmpc_lane_step_stream(lpvmpc_lane *lane, int32_t i);
-/* promote_after: iterations (>= 25; compared at the termination checks, like "defer_after"); a value <= defer_after promotes
- * straight from the call's own launch.  promote_remaining (iterations, 0 = no such test): promote only the instances whose
- * residuals at the last two termination checks -- the rate at which the worse of primal / dual residual over tolerance falls
- * -- predict at least that many more iterations; the others stay with the bounded passes, which serve the many
- * few-hundred-iteration instances at four per CU where the tail kernel gives each a whole CU.  A scheduling rule: no result
- * depends on it.  promote_hard (iterations, 0 = none): from here on an instance is promoted whatever the prediction says (the
- * residuals of the instances that run to max_iter do not fall steadily: the prediction misses some of them).  lane = NULL
- * detaches.  Finishes whatever the handle has parked first. */
-int lpvmpc_lane_attach(lpvmpc_handle *h, lpvmpc_lane *lane, int32_t promote_after, int32_t promote_remaining, int32_t promote_hard);
-/* drain launches of this handle so far (diagnostic). */
-int lpvmpc_lane_drain_count(const lpvmpc_handle *h);
-/* instances promoted into the lane's ring so far (reads a device counter: synchronises with the device). */
-int lpvmpc_lane_promoted_count(lpvmpc_lane *lane);
-/* Diagnostic: the entries the lane's drain launches have finished so far (the first 1024), five doubles each -- parked at, restored
- * on a reserved CU at, finished at (ticks of the device's 100 MHz clock), ADMM iterations at the hand-over, final iteration
- * count.  Returns the number of records written (<= max_records) or a negative LPVMPC_E_* code; synchronises with the device. */
-int lpvmpc_lane_trace(lpvmpc_lane *lane, double *records, int32_t max_records);
+/* (Round 4 shipped an experimental "long-runner lane" here -- lpvmpc_lane_*: reserved compute units for the whole-CU tail kernel.
+ * It lost on every configuration measured (profiles/r04_lane_ab.txt: the driver's burst 13.3 -> 14.1-16.6 ms, the default run
+ * 3.17 -> 2.5-2.7 M solves/s) and was removed from the library in round 5; docs/HISTORY.md keeps the design notes.) */
 
 /* Pre-size the device workspace for batches up to B (otherwise grown on demand). */
 int lpvmpc_reserve(lpvmpc_handle *h, int32_t B);

@@ -27,7 +27,7 @@ def hot_path(path):
         body.append(ln)
         if ln.startswith(".Lfunc_end"):
             spill_regs = set(re.findall(r"v_writelane_b32\s+(v\d+)", "".join(body)))
-            hot, n_ins, scratch, lanes = False, 0, 0, 0
+            hot, n_ins, scratch, stores, lanes = False, 0, 0, 0, 0
             for b in body:
                 if "LPVMPC_HOT_BEGIN" in b:
                     hot = True
@@ -37,10 +37,11 @@ def hot_path(path):
                     n_ins += 1
                     op = b.split()[0]
                     scratch += op.startswith("scratch_")
+                    stores += op.startswith("scratch_store")
                     if op in ("v_readlane_b32", "v_writelane_b32") and re.search(r"\b(v\d+)\b", b.split(None, 1)[1]) and \
                             set(re.findall(r"\bv\d+\b", b)) & spill_regs:
                         lanes += 1
-            out[name] = dict(instructions=n_ins, scratch=scratch, spill_lane_moves=lanes)
+            out[name] = dict(instructions=n_ins, scratch=scratch, scratch_stores=stores, spill_lane_moves=lanes)
             name = None
     return out
 
@@ -76,7 +77,7 @@ if __name__ == "__main__":
         elif a == "--hot-lane-allow":           # name-substring=count: a kernel outside the benchmarked set that may carry more lane moves
             name, _, lim = args.pop(0).partition("=")
             hot_allow[name] = int(lim)
-        elif a == "--hot-scratch-allow":        # name-substring=count: scratch RELOADS tolerated between the markers (loop-invariant values)
+        elif a == "--hot-scratch-allow":        # name-substring=count: scratch RELOADS (never stores) tolerated between the markers (loop-invariant values)
             name, _, lim = args.pop(0).partition("=")
             hot_scratch[name] = int(lim)
         elif a == "--hot-lane-moves":           # largest number of SGPR-spill lane moves tolerated between the hot-path markers
@@ -97,8 +98,10 @@ if __name__ == "__main__":
         h = hot.get(k["name"])
         if h and h["instructions"]:
             lanes_max = max([v for n, v in hot_allow.items() if n in k["name"]] or [hot_lanes_max if hot_lanes_max is not None else 1 << 30])
-            hflag = h["scratch"] > max([v for n, v in hot_scratch.items() if n in k["name"]] or [0]) or h["spill_lane_moves"] > lanes_max
-            print("      per-iteration code (between the markers): %d instructions, %d scratch accesses, %d SGPR-spill lane moves%s"
-                  % (h["instructions"], h["scratch"], h["spill_lane_moves"], "  <-- FAIL" if hflag else ""))
+            # the allowance covers RELOADS of loop-invariant values only: a scratch store between the markers always fails
+            loads = h["scratch"] - h["scratch_stores"]
+            hflag = loads > max([v for n, v in hot_scratch.items() if n in k["name"]] or [0]) or h["scratch_stores"] > 0 or h["spill_lane_moves"] > lanes_max
+            print("      per-iteration code (between the markers): %d instructions, %d scratch loads, %d scratch stores, %d SGPR-spill lane moves%s"
+                  % (h["instructions"], loads, h["scratch_stores"], h["spill_lane_moves"], "  <-- FAIL" if hflag else ""))
             bad += hflag
     sys.exit(1 if bad else 0)

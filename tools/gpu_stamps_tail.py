@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase shader cycles per ADMM iteration of the whole-CU tail kernel, from the diagnostic stamps build
 (make -C autonomous-racing-lpv-mpp-mpc_amd/csrc stamps [STAMPS=2]): every instance is parked at iteration 25 and run to
-max_iter by the tail kernel.  With STAMPS=2 the columns are the factorisation phases summed over the solve.
---lane: the same through a long-runner lane (the ring-drain form of the tail kernel on a reserved CU)."""
+max_iter by the tail kernel.  With STAMPS=2 the columns are the factorisation phases summed over the solve."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,16 +12,12 @@ _ffi.LIB_PATH = os.path.join(os.path.dirname(_ffi.LIB_PATH), "liblpvmpc_stamps.s
 import lpvmpc
 from lpvmpc import workloads
 dev = torch.device("cuda", 0)
-LANE = "--lane" in sys.argv
-lane = lpvmpc.Lane(device=0, reserved_cus=8, step_streams=1, ring_entries=64) if LANE else None
 t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 for B in (1, 64):
     w = workloads.controller_batch(B, N=20, seed=0)
     eng = workloads.make_solver(w, adaptive_rho=0, polish=0, check_termination=25, max_iter=2025, eps_abs=1e-30, eps_rel=1e-30, eps_prim_inf=1e-30, eps_dual_inf=1e-30)
-    eng.reserve(B); eng.set_option("defer_pool", 64); eng.set_option("defer_after", 25); eng.set_option("defer_budget", 0 if not LANE else -1)
+    eng.reserve(B); eng.set_option("defer_pool", 64); eng.set_option("defer_after", 25); eng.set_option("defer_budget", 0)
     st = 0
-    if LANE:
-        eng.attach_lane(lane, promote_after=25); st = lane.step_streams[0]
     o = dict(xPred=torch.zeros((B, 21, 6), dtype=torch.float64, device=dev), uPred=torch.zeros((B, 20, 2), dtype=torch.float64, device=dev),
              status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev),
              resid=torch.zeros((B, 4), dtype=torch.float64, device=dev), polish=torch.zeros(B, dtype=torch.int32, device=dev))
@@ -30,6 +25,6 @@ for B in (1, 64):
                   o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"], stream=st)
     eng.join(st); torch.cuda.synchronize()
     r = o["resid"].cpu().numpy(); it = o["iters"].cpu().numpy()
-    print(("lane " if LANE else "join ") + "B=%d iters %s | cycles per iteration (sum over the tail's iterations / all iterations): build_rhs %.0f | dense_apply %.0f | - %.0f | update %.0f | total %.0f"
+    print("join B=%d iters %s | cycles per iteration (sum over the tail's iterations / all iterations): build_rhs %.0f | dense_apply %.0f | - %.0f | update %.0f | total %.0f"
           % (B, np.unique(it), *np.median(r, axis=0), np.median(r.sum(1))))
     eng.close()
