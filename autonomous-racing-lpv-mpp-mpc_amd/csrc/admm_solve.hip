@@ -33,6 +33,11 @@ namespace lpvmpc {
 #else
 #define STAMP(slot) do { } while (0)
 #endif
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS == 4
+#define STAMP4(slot) do { asm volatile("s_waitcnt lgkmcnt(0)"); STAMP(slot); } while (0)      // (tail kernel, inside the phases: everything issued so far has arrived)
+#else
+#define STAMP4(slot) do { } while (0)
+#endif
 
 template <int NX, int NT, int NW, bool MF = false, bool GS = false, bool TAIL = false>
 struct Solver {
@@ -89,7 +94,8 @@ struct Solver {
     static constexpr int kStride = 64 * NW;
 
     const DevCfg &cfg;
-    const int N, NS, tid, wv, lane, ti, tj;
+    const int N, NS;
+    int tid, wv, lane, ti, tj;      // (not const: the tail kernel launders them behind its loop, see launder_ids)
     const int delay;      // controller: stages 0 .. delay-1 carry a pinned-steering equality row in box slot 6 (CTRL:518-527)
     // tiles: scaled [A|B] always in LDS; S^-1 and L in LDS (run-time horizon) or registers (kReg)
     double *tS, *tL, *tA;
@@ -117,17 +123,37 @@ struct Solver {
     // wavefront for the block sweeps that build K^-1 [NW][128], and the staging area those sweeps deliver a round of kDenseRound
     // block columns of K^-1 through [kDenseRound][NS][64]
     double *RT, *WS, *STG;
-    // K^-1 in registers: thread (g = tid >> 3, s = tid & 7), tid < 8 * kDenseGroups, holds rows 3g .. 3g+2 of the columns 8 c + s
-    // (c = 0 .. NS-1): 63 doubles per thread at N = 20, 7 of the 8 wavefronts
+    // K^-1 in registers, columns 8 c + s (c = 0 .. NS-1) of a few rows per thread (g, s = tid & 7), UNEVENLY (round 5): the threads of
+    // the first kActW wavefronts, which also own the variable elements, hold two rows (2g, 2g+1: g = tid >> 3), those of the next four
+    // wavefronts four rows (kRowsA + 4g ..: g = (tid - 64 kActW) >> 3); the last wavefront holds none (it runs the termination
+    // checks).  Every thread has the same 4 NS doubles `dm`: four rows of K^-1 on the heavy wavefronts; on the light ones two rows, and
+    // behind them the element's row of T (24), its box rows' state and constants (7 each), x, G, S, c0 (see tail_fused) -- one
+    // register array, so that what the light wavefronts keep for the element phase costs the heavy ones nothing
     static constexpr int kDC = TAIL ? NT + 1 : 1;
     static constexpr int kRhsPitch = ((NT + 1) + 1) & ~1;            // tail kernel: doubles per slot of the slot-major right-hand side (even: 16-byte loads)
     static_assert(!TAIL || 8 * (((NT + 1) + 1) & ~1) <= 2 * (NT + 1) * 8, "the slot-major right-hand side must fit VT + AT");
-    static constexpr int kDenseGroups = ((NT + 1) * 8 + 2) / 3;      // groups of three rows
+    static constexpr int kDM = TAIL ? 4 * (NT + 1) : 1;
+    static constexpr int kRowsA = 2 * 8 * (((NT + 1) * 8 + 63) / 64);   // rows held by the light wavefronts (two per 8-lane group)
+    static constexpr int kGroupsB = ((NT + 1) * 8 - kRowsA + 3) / 4;   // 8-lane groups of the heavy wavefronts that hold rows
     static constexpr int kDenseRound = 7;                             // block columns per staging round
     static constexpr int kActW = ((NT + 1) * 8 + 63) / 64;            // wavefronts that own elements in the element loops
-    static constexpr int kBoxT0 = 64 * kActW;                         // update(): first thread of the wavefronts that own the box rows
-    static_assert(!TAIL || (8 * kDenseGroups <= 64 * NW && kActW <= 4 && 2 * kActW < NW), "tail kernel: K^-1 rows / element loops do not fit the workgroup");
-    double dm0[kDC], dm1[kDC], dm2[kDC];
+    static_assert(!TAIL || (kActW + (kGroupsB + 7) / 8 <= NW - 1 && kActW <= 4 && 2 * kActW < NW), "tail kernel: K^-1 rows / element loops do not fit the workgroup (the last wavefront holds no K^-1 rows: it runs the termination checks)");
+    static_assert(!TAIL || ((NT + 1) * 8 * 24 + 64 * (NT + 1) + 8 * 64 <= kDenseRound * (NT + 1) * 64), "tail kernel: T rows and the checker's scratch do not fit the staging area");
+    double dm[kDM];
+    static constexpr int kTR = 2 * (NT + 1), kBX = kTR + 24, kXS = kBX + 14;      // light wavefronts: T row, box rows (z, y, lo, hi, sb, w, 1/w) x 2, (x, G, S, c0)
+    static_assert(!TAIL || kXS + 4 <= kDM, "tail kernel: the element registers do not fit behind the light wavefronts' rows of K^-1");
+    // ---- tail kernel, round 5: the ADMM iteration in TWO phases (dense product, fused element phase: tail_fused) ----
+    // One variable element e = tid per thread of the first kActW wavefronts, its state in registers: x, G = A_d'(rho_eq z_d - y_d) - q
+    // (the dynamics rows' part of the right-hand side, carried in variable space), S = sum of x~ since the last snapshot (y_d is
+    // rebuilt from it where it is needed: at the termination checks), c0 = (A_d' b)[e]; and the one or two box rows that act on the
+    // variable (controller: vx, delta, a have two each; planner: one per variable): z, y and the row's constants.
+    static constexpr int kBR = kCtrl ? 2 : 1;
+    double *TT;    // [8 NS][24] rows of T = A_d' A_d: the blocks that multiply x~ of stage k-1, k, k+1 (in STG, rebuilt behind every K^-1 build)
+    double *CK;    // scratch of the off-chain termination check (behind TT): A x [2][8 NS], P x, A'y, per-lane maxima [8][64], 1/Ed, 1/Eb, 1/D
+    // off-chain termination check (checker_tick): state of wavefront NW-1's coroutine -- wave-uniform, scalar registers
+    int cs, cr, ckn, ckk;
+    bool ckc, cka;
+    double ck_alpha;
     double c, cinv;
     // row weights: ADMM rho classes (OSQP set_rho_vec) or, while polishing, |flag| = 1/delta on active rows
     bool pol;
@@ -143,7 +169,7 @@ struct Solver {
     // registers instead of three f64 compares and eight selects per element and iteration in update()
     static constexpr bool kGs = GS;                 // the equilibration vectors D / Ed / Eb live in global memory (SolveArgs::scal)
     static_assert(!GS || (NW == 2 && NT > 20 && !MF), "global scalings: planner two-wavefront kernels only");
-    static constexpr bool kCacheW = (kReg && !GS && (MF || (NW == 2 && NT > 20))) || TAIL;   // (the N <= 20 DPP / one-wave instantiations have no registers to spare)
+    static constexpr bool kCacheW = kReg && !GS && (MF || (NW == 2 && NT > 20));   // (the N <= 20 DPP / one-wave instantiations have no registers to spare; the tail kernel keeps its own copies: tail_begin)
     static constexpr int kRnd = kCacheW ? (kFour ? 2 : ((NT + 1) * 8 + kStride - 1) / kStride) : 1;
     double wbx[kRnd], wbxi[kRnd];
     // NW == 4: element of set 1 / set 2 (see kS2n) that thread t owns in the right-hand side and update phases (>= 8 NS: none)
@@ -162,7 +188,7 @@ struct Solver {
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
                 const int e = kFour ? (r == 0 ? elem_set1(tid) : elem_set2(tid))
-                                    : tid + r * kStride - (TAIL ? kBoxT0 : 0);      // (tail kernel: the box rows belong to the threads from kBoxT0 on, see update)
+                                    : tid + r * kStride;
                 double w = rho, wi = rinv;
                 if (e >= 0 && e < NS * 8) {
                     const double lo = Lo[e], hi = Hi[e];
@@ -202,9 +228,11 @@ struct Solver {
         }
         Lo = p; p += V; Hi = p; p += V;
         beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; RED = p; p += kRedSize; SINK = p; p += 64 + 8 * NS;
-        RT = WS = STG = nullptr;
+        RT = WS = STG = TT = CK = nullptr;
+        cs = cr = ckn = ckk = 0; ckc = cka = false; ck_alpha = 0.0;
         if constexpr (TAIL) {   // behind the image: factor tiles, reduction slots, sweep scratch, staging
             tS = p; p += NS * kTS; tL = p; p += NS * kTS; RT = p; p += 96; WS = p; p += NW * 128; STG = p; p += kDenseRound * NS * 64;
+            TT = STG; CK = STG + NS * 8 * 24;
         }
         {
             int first, cnt; rows_on(tj, first, cnt);
@@ -251,11 +279,21 @@ struct Solver {
         if (hi - lo < kRhoTol) return kRhoEqOverIneq * rho;
         return rho;
     }
-    __device__ __forceinline__ void set_rho(double r) { rho = r; rho_eq = kRhoEqOverIneq * r; rinv = 1.0 / rho; rinv_eq = 1.0 / rho_eq; }
+    __device__ __forceinline__ void set_rho(double r) {
+        rho = r; rho_eq = kRhoEqOverIneq * r; rinv = 1.0 / rho; rinv_eq = 1.0 / rho_eq;
+        if constexpr (TAIL) { rho = unid(rho); rho_eq = unid(rho_eq); rinv = unid(rinv); rinv_eq = unid(rinv_eq); }
+    }
     // weight of a box row / dynamics row in K = P + sig I + A' diag(W) A
     __device__ __forceinline__ double w_box(int e) const { return pol ? fabs(DYb[e]) : rho_of(Lo[e], Hi[e], rho); }
     __device__ __forceinline__ double w_dyn(int e) const { return pol ? fabs(DYd[e]) : rho_eq; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // The thread indices again, from a value the optimiser cannot trace back: address arithmetic of the code BEHIND this point is formed
+    // behind it, instead of in front of the ADMM loop with one live register per address all the way through the loop (the tail
+    // kernel's registers hold K^-1: its loop has none to spare for the set-up and polish code's addresses)
+    __device__ __forceinline__ void launder_ids() {
+        tid = opaque(tid); wv = tid >> 6; lane = tid & 63; ti = lane >> 3; tj = tid & 7;
+        lpack = opaque(lpack);
+    }
     // The same value, opaque to the optimiser.  The element loops of the ADMM iteration start from it so that their LDS
     // addresses are formed inside the loop as (one per-lane base) + (immediate offset of the array) instead of being hoisted
     // out of the iteration loop as one live address register per (array, access pattern) pair -- those registers, not the
@@ -985,12 +1023,14 @@ struct Solver {
     }
     __device__ __forceinline__ void dense_build() {
         constexpr int kRoundsD = (NT + 1 + kDenseRound - 1) / kDenseRound;
-        const int g = tid >> 3, s_ = tid & 7;
-        // rows of this thread (clamped for the threads beyond the last group: they read valid addresses and never use the values)
-        const int r0 = 3 * (g < kDenseGroups ? g : kDenseGroups - 1);
-        int off[3];
+        const int s_ = tid & 7;
+        // rows of this thread (light wavefronts: two rows, the other two slots are overwritten by tail_begin; clamped for the threads
+        // beyond the last group: they read valid addresses and never use the values)
+        const bool light = tid < 64 * kActW;
+        const int r0 = light ? 2 * (tid >> 3) : kRowsA + 4 * ((tid - 64 * kActW) >> 3);
+        int off[4];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { const int r = (r0 + q < NS * 8) ? r0 + q : NS * 8 - 1; off[q] = (r >> 3) * 64 + (r & 7) * 8 + s_; }
+        for (int q = 0; q < 4; ++q) { const int r = (r0 + q < NS * 8) ? r0 + q : NS * 8 - 1; off[q] = (r >> 3) * 64 + (r & 7) * 8 + s_; }
 #pragma unroll
         for (int rd = 0; rd < kRoundsD; ++rd) {
             const int c = rd * kDenseRound + wv;
@@ -1001,54 +1041,100 @@ struct Solver {
                 const int cc = rd * kDenseRound + q;
                 if (cc <= NT) {
                     const double *src = STG + q * (NS * 64);
-                    dm0[cc < kDC ? cc : 0] = src[off[0]]; dm1[cc < kDC ? cc : 0] = src[off[1]]; dm2[cc < kDC ? cc : 0] = src[off[2]];
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) dm[(q2 * kDC + cc) < kDM ? q2 * kDC + cc : 0] = src[off[q2]];
                 }
             }
             sync();
         }
-        // the staging area is free until the next build: it now holds the dynamics rows of the scaled [A|B] tiles again, ten doubles per
-        // row and sixty per stage, for the update phase (prev_stage_dot_pad) -- at eight doubles per row, as the tiles are stored, the
-        // eight lanes of a stage read rows that sit 16 banks apart and every fourth row of the 16 lanes of a pass lands on the same
-        // banks; at ten (and 60 per stage: 56 banks on) the twelve rows of a pass tile the banks exactly
-        for (int i = tid; i < N * 48; i += kStride) { const int k = i / 48, r = (i - 48 * k) >> 3, a_ = i & 7; STG[k * 60 + r * 10 + a_] = tA[k * kTS + r * 8 + a_]; }
+        // the staging area is free until the next build: it now holds T = A_d' A_d row by row -- for variable (k, j) the 24 coefficients of
+        // x~ of the stages k-1, k, k+1 -- which the fused element phase needs (tail_fused).  A_d row (k, r): Eid(k, r) on variable (k, r),
+        // -[A|B]_{k-1}[r][a] on the variables of stage k-1.  T does not depend on rho; it is rebuilt because the build above used its room.
+        for (int i = tid; i < NS * 8 * 24; i += kStride) {
+            const int e = i / 24, q = i - 24 * e, blk = q >> 3, a_ = q & 7, k = e >> 3, j = e & 7;
+            double v = 0.0;
+            if (blk == 0) { if (j < NX && k >= 1) v = -Eid(k, j) * tA[(k - 1) * kTS + j * 8 + a_]; }
+            else if (blk == 1) {
+                if (k < N) {
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) v += tA[k * kTS + r * 8 + j] * tA[k * kTS + r * 8 + a_];
+                }
+                if (a_ == j && j < NX) { const double ei = Eid(k, j); v += ei * ei; }
+            } else if (k < N && a_ < NX) v = -tA[k * kTS + a_ * 8 + j] * Eid(k + 1, a_);
+            TT[i] = v;
+        }
+        // the reciprocals of the equilibration vectors that the checker's residual evaluation needs (as residuals() forms them)
+        for (int i = tid; i < NS * 8; i += kStride) { CK[40 * NS + 512 + i] = 1.0 / Ed[i]; CK[48 * NS + 512 + i] = 1.0 / Eb[i]; CK[56 * NS + 512 + i] = 1.0 / D[i]; }
         sync();
     }
-    // dynamics-row product of the previous stage like prev_stage_dot, rows read from the padded copy dense_build leaves in STG
-    __device__ __forceinline__ double prev_stage_dot_pad(int k, const double *v) const {
-        const int kp = k > 0 ? k - 1 : 0;
-        const double *row = STG + kp * 60 + (tj < NX ? tj : 0) * 10, *sv = v + kp * 8;
-        const double r0_ = row[0], r1_ = row[1], r2_ = row[2], r3_ = row[3], r4_ = row[4], r5_ = row[5], r6_ = row[6], r7_ = row[7];
-        const double s0_ = sv[0], s1_ = sv[1], s2_ = sv[2], s3_ = sv[3], s4_ = sv[4], s5_ = sv[5], s6_ = sv[6], s7_ = sv[7];
-        const double acc0 = (r0_ * s0_ + r1_ * s1_) + (r2_ * s2_ + r3_ * s3_);
-        const double acc1 = (r4_ * s4_ + r5_ * s5_) + (r6_ * s6_ + r7_ * s7_);
-        return k > 0 ? acc0 + acc1 : 0.0;
-    }
-    // XT <- K^-1 VT (the KKT solve of an ADMM iteration in the tail kernel)
+    // XT <- K^-1 VT (the KKT solve of an ADMM iteration in the tail kernel; the caller places the barrier)
     __device__ __forceinline__ void dense_apply() {
-        const int t0 = opaque(tid), g = t0 >> 3, s_ = t0 & 7;
-        if (g < kDenseGroups) {
+        const int t0 = opaque(tid), s_ = t0 & 7;
+        if (t0 < 64 * (NW - 1)) {
+            // The right-hand side slice of this thread's column slot (kDC values, 16-byte loads) in three batches: the first two are
+            // issued up front, the third behind the first batch's products -- all of it in flight at once would be 2 kDC registers on
+            // top of the 8 NS that hold K^-1, and the kernel has 256
+            static_assert(kDC == 21, "dense_apply: the batches are written for 21 stages");
             const double2 *rv = reinterpret_cast<const double2 *>(VT + s_ * kRhsPitch);
-            double rr[kDC + 1];             // the whole right-hand side slice first: one LDS round trip, not one per pair of columns
+            double2 ra[4], rb[4], rc[3];
 #pragma unroll
-            for (int c = 0; c < kDC; c += 2) { const double2 v = rv[c >> 1]; rr[c] = v.x; rr[c + 1] = v.y; }
+            for (int h = 0; h < 4; ++h) { ra[h] = rv[h]; rb[h] = rv[4 + h]; }
             __builtin_amdgcn_sched_barrier(0);
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
+            STAMP4(2);
+            const bool light = t0 < 64 * kActW;
+            if (light) {                    // light wavefronts: rows 2g, 2g + 1, two partial sums each
+                double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
 #pragma unroll
-            for (int c = 0; c + 1 < kDC; c += 2) {
-                a0 += dm0[c] * rr[c]; a1 += dm1[c] * rr[c]; a2 += dm2[c] * rr[c];
-                b0 += dm0[c + 1] * rr[c + 1]; b1 += dm1[c + 1] * rr[c + 1]; b2 += dm2[c + 1] * rr[c + 1];
-            }
-            if constexpr (kDC & 1) { a0 += dm0[kDC - 1] * rr[kDC - 1]; a1 += dm1[kDC - 1] * rr[kDC - 1]; a2 += dm2[kDC - 1] * rr[kDC - 1]; }
-            a0 += b0; a1 += b1; a2 += b2;
-            red_j2(a0, a1); a2 = red_j(a2);
-            if (s_ == 0) {
-                const int r = 3 * g;
-                XT[r] = a0;
-                if (r + 1 < NS * 8) XT[r + 1] = a1;
-                if (r + 2 < NS * 8) XT[r + 2] = a2;
+                for (int h = 0; h < 4; ++h) {
+                    a0 += dm[2 * h] * ra[h].x; a1 += dm[kDC + 2 * h] * ra[h].x;
+                    b0 += dm[2 * h + 1] * ra[h].y; b1 += dm[kDC + 2 * h + 1] * ra[h].y;
+                }
+#pragma unroll
+                for (int h = 0; h < 3; ++h) rc[h] = rv[8 + h];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    a0 += dm[8 + 2 * h] * rb[h].x; a1 += dm[kDC + 8 + 2 * h] * rb[h].x;
+                    b0 += dm[8 + 2 * h + 1] * rb[h].y; b1 += dm[kDC + 8 + 2 * h + 1] * rb[h].y;
+                }
+                a0 += dm[16] * rc[0].x; a1 += dm[kDC + 16] * rc[0].x; b0 += dm[17] * rc[0].y; b1 += dm[kDC + 17] * rc[0].y;
+                a0 += dm[18] * rc[1].x; a1 += dm[kDC + 18] * rc[1].x; b0 += dm[19] * rc[1].y; b1 += dm[kDC + 19] * rc[1].y;
+                a0 += dm[20] * rc[2].x; a1 += dm[kDC + 20] * rc[2].x;
+                a0 += b0; a1 += b1;
+                red_j2(a0, a1);
+                if (s_ == 0) { const int r = 2 * (t0 >> 3); XT[r] = a0; XT[r + 1] = a1; }
+                STAMP4(3);
+            } else {                        // heavy wavefronts: rows kRowsA + 4g .. + 3, one sum per row (four independent chains)
+                double a_[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { a_[q] += dm[q * kDC + 2 * h] * ra[h].x; a_[q] += dm[q * kDC + 2 * h + 1] * ra[h].y; }
+                }
+#pragma unroll
+                for (int h = 0; h < 3; ++h) rc[h] = rv[8 + h];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { a_[q] += dm[q * kDC + 8 + 2 * h] * rb[h].x; a_[q] += dm[q * kDC + 8 + 2 * h + 1] * rb[h].y; }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a_[q] += dm[q * kDC + 16] * rc[0].x; a_[q] += dm[q * kDC + 17] * rc[0].y;
+                    a_[q] += dm[q * kDC + 18] * rc[1].x; a_[q] += dm[q * kDC + 19] * rc[1].y;
+                    a_[q] += dm[q * kDC + 20] * rc[2].x;
+                }
+                red_j2(a_[0], a_[1]); red_j2(a_[2], a_[3]);
+                const int g = (t0 - 64 * kActW) >> 3, r = kRowsA + 4 * g;
+                if (s_ == 0 && g < kGroupsB) {
+                    XT[r] = a_[0];
+                    if (r + 1 < NS * 8) XT[r + 1] = a_[1];
+                    if (r + 2 < NS * 8) XT[r + 2] = a_[2];
+                    if (r + 3 < NS * 8) XT[r + 3] = a_[3];
+                }
             }
         }
-        sync();
     }
 
     // ---- XT <- K^-1 XT ---------------------------------------------------------------------------
@@ -1843,41 +1929,6 @@ struct Solver {
         const LaneC lc = lane_consts();
         const int bvar = lc.bvar;
         const double rmask = lc.rmask;
-        if constexpr (TAIL) {
-            // The tail kernel has wavefronts to spare: the dynamics rows on the first kActW of them, the box rows and the x update
-            // on the next kActW, side by side (the same arithmetic per element as below)
-            const int t0 = opaque(tid);
-            if (t0 < kBoxT0) {
-                const int e = t0;
-                if (e < NS * 8) {
-                    const int k = e >> 3;
-                    const double xt = XT[e], zd = Zd[e], yd = Yd[e], b = dyn_bound(e), ei = Eid(k, tj);
-                    const double dot = prev_stage_dot_pad(k, XT);
-                    const double ztd = rmask * (ei * xt - dot);
-                    const double zrd = alpha * ztd + oma * zd;
-                    const double znd = b;
-                    const double dyd = rho_eq * (zrd - znd), ynd = yd + dyd;
-                    Yd[e] = ynd; Zd[e] = znd; ZTd[e] = rho_eq * znd - ynd;
-                    if (want_delta) DYd[e] = dyd;
-                }
-            } else {
-                const int e = t0 - kBoxT0;
-                if (e < NS * 8) {
-                    const int k = e >> 3;
-                    const double xt = XT[e], xo = X[e], zb = Zb[e], yb = Yb[e], lo = Lo[e], hi = Hi[e], sb = Sb(k, tj), xv = XT[k * 8 + bvar];
-                    const double w = wbx[0], winv = wbxi[0];
-                    const double zrb = alpha * (sb * xv) + oma * zb;
-                    const double znb = clipd(zrb + winv * yb, lo, hi);
-                    const double dyb = w * (zrb - znb), ynb = yb + dyb;
-                    const double xn = alpha * xt + oma * xo;
-                    Yb[e] = ynb; Zb[e] = znb; ZTb[e] = w * znb - ynb;
-                    X[e] = xn;
-                    if (want_delta) { DYb[e] = dyb; DX[e] = xn - xo; }
-                }
-            }
-            sync();
-            return;
-        }
         auto element = [&](int e, bool cached, double wc, double wic) {
             const int k = e >> 3;
             const double xt = XT[e], xo = X[e];
@@ -1921,6 +1972,402 @@ struct Solver {
             for (int e = opaque(tid); e < NS * 8; e += kStride) element(e, false, 0.0, 0.0);
         }
         sync();
+    }
+
+    // ================================================================================================================
+    // Tail kernel, round 5: the ADMM iteration in two phases, termination checks off the chain
+    // ================================================================================================================
+    // An iteration of the tail kernel was three phases -- right-hand side, dense product, update -- of which the two element phases
+    // (a few dozen instructions each) cost 1700 of 2900 cycles: barrier, address arithmetic, an LDS round trip, a short dependent
+    // chain, a store, and the same again.  What forces two element phases is the dynamics rows: the update forms z~_d = A_d x~ (needs
+    // x~ of the previous stage), the next right-hand side A_d' (rho z_d - y_d) (needs the rows of the next stage).  The equality rows
+    // are LINEAR -- z_d = b after the first iteration, y_d+ = y_d + rho_eq alpha (A_d x~ - b) -- so their share of the right-hand side,
+    //     G = A_d' (rho_eq b - y_d) - q,       G+ = G - rho_eq alpha (T x~ - c0),    T = A_d' A_d (block tridiagonal),  c0 = A_d' b,
+    // can be carried in VARIABLE space: T x~ for variable (k, j) needs x~ of the stages k-1, k, k+1, which the dense product has just
+    // delivered, and nothing another thread computes in this phase.  The box rows of a variable are handled by the variable's own
+    // thread (every box row acts on exactly one variable), so the next right-hand side
+    //     rhs+ = sigma x+ + G+ + sum_r Sb_r (w_r z_r+ - y_r+)
+    // is complete in the thread: ONE element phase, two barriers per iteration.  x, G and the box rows' (z, y) live in registers; y_d is
+    // not tracked per iteration (nothing reads it between checks): S = sum of x~ since the last snapshot gives
+    // y_d(now) = y_d(snapshot) + rho_eq alpha (A_d S - n b) where it is needed.
+    //
+    // Termination checks: the last wavefront holds no rows of K^-1 and owns no element.  At a check iteration the element threads file a
+    // SNAPSHOT (x, z_b, y_b -> the image's own X, Zb, Yb arrays, which nothing else writes in this loop; x~ and S -> ZTd, ZTb; the
+    // deltas -> DX, DYb) and go on iterating; the last wavefront evaluates OSQP's update_info / check_termination / adaptive-rho rule
+    // on the snapshot, one 64-element round of one operator per phase slot (checker_tick), wave-locally, with the same formulas and
+    // the same summation order as residuals() / check_termination(), and publishes a verdict a few iterations later:
+    //   continue           -> nothing happens (the iterations that ran meanwhile are the ones that would have run anyway),
+    //   stop (any status)  -> the arrays still hold iteration k: the solve ends there, iteration count k,
+    //   new rho            -> back to the snapshot: registers from the arrays, re-factorisation, on from iteration k + 1.
+    // Every result is what the check-then-iterate order gives; only the clock differs.
+    static constexpr int CK_IDLE = 0, CK_YD = 1, CK_YDX = 17, CK_AX = 2, CK_PX = 3, CK_AT = 4, CK_RES = 5, CK_RR0 = 6, CK_RR1 = 7, CK_DEC = 8,
+                         CK_PI1 = 9, CK_PI2 = 10, CK_PI3 = 11, CK_DI0 = 12, CK_DI1 = 13, CK_DI2 = 14, CK_DI3 = 15, CK_FIN = 16;
+    __device__ __forceinline__ static bool uni(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
+    __device__ __forceinline__ static double unid(double v) {
+        const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+        return __hiloint2double(hi, lo);
+    }
+    // registers of the element threads from the image's arrays (X, Zb, Yb, Yd, Zd = b), the first right-hand side
+    __device__ __forceinline__ void tail_begin(double sigma) {
+        recompute_w();                          // ZT* = rho z - y
+        build_rhs(sigma);                       // slot-major, into VT (with its barrier)
+        const LaneC lc = lane_consts();
+        const int e = opaque(tid);
+        if (e < NS * 8) {
+            const double2 *tr = reinterpret_cast<const double2 *>(TT + e * 24);
+#pragma unroll
+            for (int h = 0; h < 12; ++h) { const double2 v = tr[h]; dm[kTR + 2 * h] = v.x; dm[kTR + 2 * h + 1] = v.y; }
+#pragma unroll
+            for (int i = kBX; i < kXS + 4; ++i) dm[i] = 0.0;
+            const int k = e >> 3, kn = k < N ? k + 1 : N;
+            const double *col = tA + k * kTS + tj, *sd = ZTd + kn * 8;
+            double c_[NX], d_[NX];
+#pragma unroll
+            for (int r = 0; r < NX; ++r) { c_[r] = col[r * 8]; d_[r] = sd[r]; }
+            double acc0 = c_[0] * d_[0] + c_[1] * d_[1], acc1 = c_[2] * d_[2] + c_[3] * d_[3];
+#pragma unroll
+            for (int r = 4; r < NX; ++r) acc0 += c_[r] * d_[r];
+            dm[kXS + 1] = (Eid(k, tj) * ZTd[e] - (acc0 + acc1)) - Qv[e];
+            dm[kXS] = X[e];
+            dm[kXS + 2] = 0.0;
+            dm[kXS + 3] = (k == 0 && tj < NX) ? Eid(0, tj) * beq[tj] : 0.0;
+#pragma unroll
+            for (int q = 0; q < kBR; ++q) {
+                const int eb = k * 8 + (q == 0 ? lc.r0 : lc.r1);
+                const double lo = Lo[eb], hi = Hi[eb];
+                const bool loose = lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling, eq = hi - lo < kRhoTol;
+                double *b_ = dm + kBX + 7 * q;
+                b_[0] = Zb[eb]; b_[1] = Yb[eb]; b_[2] = lo; b_[3] = hi; b_[4] = Sb(k, q == 0 ? lc.r0 : lc.r1);
+                b_[5] = loose ? kRhoMin : (eq ? rho_eq : rho); b_[6] = loose ? 1.0 / kRhoMin : (eq ? rinv_eq : rinv);
+            }
+        }
+        sync();                                 // ZTd / ZTb are the snapshot's x~ / S from here on
+    }
+    // the fused element phase: x+, G+, the variable's box rows, the next right-hand side; want: also file the snapshot and the deltas
+    __device__ __forceinline__ void tail_fused(double sigma, double alpha, bool want) {
+        const int e = opaque(tid);
+        if (e < NS * 8) {
+            const int k = e >> 3, km = k > 0 ? k - 1 : 0, kp = k < N ? k + 1 : N;
+            const double2 *xa = reinterpret_cast<const double2 *>(XT + km * 8), *xb = reinterpret_cast<const double2 *>(XT + k * 8),
+                          *xc = reinterpret_cast<const double2 *>(XT + kp * 8);
+            const double xt = XT[e];
+            // (x~ of the three stages in two batches -- all 24 values in flight at once would not fit beside the 8 NS registers of `dm`)
+            double2 ua[4], ub[4], uc[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) { ua[h] = xa[h]; ub[h] = xb[h]; }
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP4(4);
+            double sblk[3];
+            auto blockdot = [&](const double *tt, const double2 *uu) {      // (the row of T lives in the registers dm[kTR ..]: down, diagonal, up block)
+                const double p0 = (tt[0] * uu[0].x + tt[1] * uu[0].y) + (tt[2] * uu[1].x + tt[3] * uu[1].y);
+                const double p1 = (tt[4] * uu[2].x + tt[5] * uu[2].y) + (tt[6] * uu[3].x + tt[7] * uu[3].y);
+                return p0 + p1;
+            };
+            sblk[0] = blockdot(dm + kTR, ua);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) uc[h] = xc[h];
+            __builtin_amdgcn_sched_barrier(0);
+            sblk[1] = blockdot(dm + kTR + 8, ub);
+            sblk[2] = blockdot(dm + kTR + 16, uc);
+            const double tx = (sblk[0] + sblk[2]) + sblk[1];
+            const double oma = 1.0 - alpha;
+            const double xr = dm[kXS], gr = dm[kXS + 1], c0r = dm[kXS + 3];
+            const double xn = alpha * xt + oma * xr;
+            const double gn = gr - (rho_eq * alpha) * (tx - c0r);
+            double boxes = 0.0;
+            const LaneC lc = lane_consts();
+#pragma unroll
+            for (int q = 0; q < kBR; ++q) {
+                double *b_ = dm + kBX + 7 * q;    // z, y, lo, hi, sb, w, 1/w
+                const double zrb = alpha * (b_[4] * xt) + oma * b_[0];
+                const double znb = clipd(zrb + b_[6] * b_[1], b_[2], b_[3]);
+                const double dyb = b_[5] * (zrb - znb), ynb = b_[1] + dyb;
+                boxes += b_[4] * (b_[5] * znb - ynb);
+                b_[0] = znb; b_[1] = ynb;
+                if (want) { const int eb = k * 8 + (q == 0 ? lc.r0 : lc.r1); Zb[eb] = znb; Yb[eb] = ynb; DYb[eb] = dyb; }
+            }
+            // (handles with steeringDelay > 0 -- a third box row on delta in the first stages, CTRL:518-527 -- do not take this kernel: launch_solve)
+            VT[(e & 7) * kRhsPitch + (e >> 3)] = boxes + (sigma * xn + gn);
+            STAMP4(5);
+            double sr = dm[kXS + 2] + xt;
+            if (want) { X[e] = xn; DX[e] = xn - xr; ZTd[e] = xt; ZTb[e] = sr; sr = 0.0; }
+            dm[kXS] = xn; dm[kXS + 1] = gn; dm[kXS + 2] = sr;
+        }
+    }
+    // ---- the loop (both sides) ---------------------------------------------------------------------------------------------
+    struct TailCtl { int iter, to_chk, to_adp, status; double rn; };
+    // One TRIP = [dense-product slot] barrier [fused-phase slot] barrier.  The element side (CHK = false) runs an ADMM iteration in a
+    // trip, or nothing while a pending verdict is waited for; the checker side (CHK = true) runs one checker step per slot.  The verdict
+    // word is written in a dense-product slot and read by every thread in the following fused-phase slot.
+    // Returns 0: the solve's ADMM phase has ended (t.iter, t.status; the residual norms stay in RT[84..91]); 2: back to the snapshot of iteration t.iter with the new
+    // rho t.rn (the caller re-factors and re-enters); 3: as 0, and the closing check asked for the new rho t.rn (reported, not used).
+    template <bool CHK>
+    __device__ __forceinline__ int tail_loop(TailCtl &t, double sigma, double alpha, int max_iter, int chk_every, int adp_every) {
+        int inflight = 0, k_to_chk = 0, k_to_adp = 0, n_acc = 0;      // iteration of the check in flight (0: none), the loop counters behind it, iterations summed in S
+        int vk = -1;
+        if constexpr (CHK) launder_ids();       // (the checker's addresses are formed on its side of the role branch, not in front of it)
+        bool have_it = false, chk = false, adapt = false, want = false;
+        for (;;) {
+            if (inflight != 0 && vk == inflight) {          // the verdict of the check in flight has arrived
+                const int code = __builtin_amdgcn_readfirstlane((int)RT[80]), kk = inflight;
+                inflight = 0;
+                if (code == 2) { t.status = __builtin_amdgcn_readfirstlane((int)RT[81]); t.iter = kk; return 0; }
+                if (code == 3) {
+                    t.rn = unid(RT[82]);
+                    if (kk >= max_iter) { t.iter = kk; return 3; }
+                    t.iter = kk; t.to_chk = k_to_chk; t.to_adp = k_to_adp;
+                    return 2;
+                }
+            }
+            if (!have_it) {
+                if (t.iter >= max_iter) { if (inflight == 0) return 0; }        // (else: trips without work until the closing verdict)
+                else {
+                    ++t.iter;
+                    chk = chk_every > 0 && --t.to_chk == 0;
+                    adapt = adp_every > 0 && --t.to_adp == 0;
+                    if (chk) t.to_chk = chk_every;
+                    if (adapt) t.to_adp = adp_every;
+                    if (t.iter == max_iter) chk = true;     // OSQP's closing update_info / check_termination behind the loop
+                    want = chk || adapt;
+                    have_it = true;
+                }
+            }
+            // (a check is due while another is in flight -- a check interval shorter than a check's flight: the pending one first)
+            const bool work = have_it && !(want && inflight != 0);
+            // plain iterations that follow this one before the next check / rho update / closing iteration: they run in the tight loop
+            // below, which only a verdict's arrival leaves early
+            int more = 0;
+            if (work && !want) {
+                int m = max_iter - t.iter;
+                if (chk_every > 0 && t.to_chk < m) m = t.to_chk;
+                if (adp_every > 0 && t.to_adp < m) m = t.to_adp;
+                more = m - 1;
+            }
+            for (;;) {
+#ifdef LPVMPC_STAMPS
+                tlast = __builtin_amdgcn_s_memtime();
+#endif
+                // (the markers of tools/check_kernel_resources.py bracket the element side's trip; the checker's side is off the chain)
+                if constexpr (!CHK) asm volatile("; LPVMPC_HOT_BEGIN");
+                if constexpr (CHK) {
+#pragma unroll 1
+                    for (int sl = 0; sl < 2; ++sl) {
+                        checker_tick(sl == 0);
+                        sync();
+                        if (sl == 0) vk = __builtin_amdgcn_readfirstlane((int)RT[83]);
+                    }
+                } else {
+                    if (work) dense_apply();
+                    sync();
+                    STAMP(0);
+                    const double vkd = RT[83];      // (consumed behind the element phase: its round trip is not on the chain)
+                    if (work) tail_fused(sigma, alpha, want);
+                    vk = __builtin_amdgcn_readfirstlane((int)vkd);
+                    sync();
+                    STAMP(1);
+                }
+                if constexpr (!CHK) asm volatile("; LPVMPC_HOT_END");
+                if (work) ++n_acc;
+                if (more <= 0 || (inflight != 0 && vk == inflight)) break;
+                --more; ++t.iter; --t.to_chk; --t.to_adp;
+            }
+            if (work) {
+                if (want) {
+                    inflight = t.iter; k_to_chk = t.to_chk; k_to_adp = t.to_adp;
+                    if constexpr (CHK) { ckk = t.iter; ckn = n_acc; ckc = chk; cka = adapt; cs = CK_YD; cr = 0; }
+                    n_acc = 0;
+                }
+                have_it = false;
+            }
+        }
+    }
+    // ---- the checker: one step per phase slot on the last wavefront ----------------------------------------------------
+    // scratch: CK[0 .. 8NS) A x (dynamics rows), [8NS ..) A x (box rows), [16NS ..) P x, [24NS ..) A'y, [32NS ..) per-lane maxima [8][64], behind them
+    // 1 / Ed, 1 / Eb, 1 / D (dense_build);
+    // RT[56..58] the three rounds' partial sums, RT[59] nd, RT[60] flags (prc | drc << 1 | pic << 2 | dic << 3), RT[64..71] the eight
+    // norms of Res; the verdict: RT[80] code (1 continue, 2 stop, 3 new rho), RT[81] status, RT[82] new rho, RT[83] iteration of the
+    // check it belongs to (written last; the other wavefronts compare it with the check they are waiting for), RT[84..91] Res
+    __device__ __forceinline__ void ck_next_round(int next_state) { if (cr == 2) { cr = 0; cs = next_state; } else ++cr; }
+    __device__ __forceinline__ void ck_max_acc(int slot, int ln, double v) {
+        double *m = CK + 32 * NS + slot * 64 + ln;
+        *m = cr == 0 ? v : fmax(*m, v);
+    }
+    __device__ __forceinline__ void checker_tick(bool slot_d) {
+        if (cs == CK_IDLE) return;
+        const int ln = opaque(lane);
+        const int e_ = ln + 64 * cr;
+        const bool act = e_ < NS * 8;
+        const int e = act ? e_ : NS * 8 - 1;             // (clamped: valid addresses, results masked)
+        const int k = e >> 3;
+        const double eps_p = cfg.eps_prim_inf, eps_d = cfg.eps_dual_inf;
+        if (cs == CK_YD) {
+            // y_d at the snapshot from the sum of x~ since the snapshot before (ZTb): y_d += rho_eq alpha (A_d S - n b)
+            const LaneC lc = lane_consts();
+            const double b = dyn_bound(e), ei = Eid(k, tj);
+            const double us = lc.rmask * (ei * ZTb[e] - prev_stage_dot(k, ZTb));
+            const double yd = Yd[e] + (rho_eq * ck_alpha) * (us - (double)ckn * b);
+            if (act) Yd[e] = yd;
+            ck_next_round(CK_YDX);
+        } else if (cs == CK_YDX) {
+            // delta y_d of the check iteration from its x~ (ZTd), as update() forms it (z_d = b)
+            const LaneC lc = lane_consts();
+            const double b = dyn_bound(e), ei = Eid(k, tj);
+            const double ux = lc.rmask * (ei * ZTd[e] - prev_stage_dot(k, ZTd));
+            const double zrd = ck_alpha * ux + (1.0 - ck_alpha) * b;
+            if (act) DYd[e] = rho_eq * (zrd - b);
+            ck_next_round(CK_AX);
+        } else if (cs == CK_AX) {
+            const LaneC lc = lane_consts();
+            const double zd = lc.rmask * (Eid(k, tj) * X[e] - prev_stage_dot(k, X)), zb = Sb(k, tj) * X[k * 8 + lc.bvar];
+            if (act) { CK[e] = zd; CK[8 * NS + e] = zb; }
+            ck_next_round(CK_PX);
+        } else if (cs == CK_PX) {
+            const double pv = P_row<false>(k, X);
+            if (act) CK[16 * NS + e] = pv;
+            ck_next_round(CK_AT);
+        } else if (cs == CK_AT) {
+            const LaneC lc = lane_consts();
+            const double av = At_elem(e, Yd, Yb, lc);
+            if (act) CK[24 * NS + e] = av;
+            ck_next_round(CK_RES);
+        } else if (cs == CK_RES) {
+            // the element loop of residuals(), maxima per lane
+            const double eid = CK[40 * NS + 512 + e], eib = CK[48 * NS + 512 + e], di = CK[56 * NS + 512 + e];      // 1 / Ed, 1 / Eb, 1 / D (dense_build)
+            const double axd = CK[e], axb = CK[8 * NS + e], px = CK[16 * NS + e], aty = CK[24 * NS + e];
+            const double zd = Zd[e], zb = Zb[e], q = Qv[e];
+            const double rd = axd - zd, rb = axb - zb;
+            double m_[8];
+            m_[4] = fmax(fabs(rd), fabs(rb));
+            m_[0] = fmax(fabs(eid * rd), fabs(eib * rb));
+            m_[6] = fmax(fmax(fabs(axd), fabs(axb)), fmax(fabs(zd), fabs(zb)));
+            m_[2] = fmax(fmax(fabs(eid * axd), fabs(eib * axb)), fmax(fabs(eid * zd), fabs(eib * zb)));
+            const double dr = q + px + aty;
+            m_[5] = fabs(dr); m_[1] = fabs(di * dr);
+            m_[7] = fmax(fmax(fabs(px), fabs(aty)), fabs(q));
+            m_[3] = fmax(fmax(fabs(di * px), fabs(di * aty)), fabs(di * q));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ck_max_acc(i, ln, act ? m_[i] : 0.0);
+            ck_next_round(CK_RR0);
+        } else if (cs == CK_RR0 || cs == CK_RR1) {
+            const int i0 = cs == CK_RR0 ? 0 : 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const double v = wave_max(CK[32 * NS + (i0 + i) * 64 + ln]); if (ln == 0) RT[64 + i0 + i] = v; }
+            cs = cs == CK_RR0 ? CK_RR1 : CK_DEC;
+        } else if (cs == CK_DEC) {
+            const double pri = unid(RT[64]), dua = cinv * unid(RT[65]), nAxz = unid(RT[66]), nPAq = cinv * unid(RT[67]);
+            int fl = 0, nxt = CK_FIN;
+            if (ckc && !(pri > kInfty || dua > kInfty)) {
+                const bool prc = pri < cfg.eps_abs + cfg.eps_rel * nAxz, drc = dua < cfg.eps_abs + cfg.eps_rel * nPAq;
+                fl = (prc ? 1 : 0) | (drc ? 2 : 0);
+                nxt = !prc ? CK_PI1 : (!drc ? CK_DI1 : CK_FIN);
+            }
+            if (ln == 0) RT[60] = (double)fl;
+            cs = __builtin_amdgcn_readfirstlane(nxt);
+        } else if (cs == CK_PI1) {
+            // is_primal_infeasible, first loop: delta_y projected on the polar of the recession cone, its norm
+            double dy = DYb[e];
+            const double lo = Lo[e], hi = Hi[e];
+            if (hi > kInfty * kMinScaling) { if (lo < -kInfty * kMinScaling) dy = 0.0; else dy = fmin(dy, 0.0); }
+            else if (lo < -kInfty * kMinScaling) dy = fmax(dy, 0.0);
+            if (act) DYb[e] = dy;
+            ck_max_acc(0, ln, act ? fmax(fabs(Ed[e] * DYd[e]), fabs(Eb[e] * dy)) : 0.0);
+            if (cr == 2) {
+                const double nd = unid(wave_max(CK[32 * NS + ln]));
+                if (ln == 0) RT[59] = nd;
+                cr = 0;
+                cs = uni(nd > eps_p) ? CK_PI2 : CK_DI0;
+            } else ++cr;
+        } else if (cs == CK_PI2) {
+            const double b = dyn_bound(e), dyd = DYd[e], dyb = DYb[e];
+            double lhs = 0.0;
+            lhs += b * fmax(dyd, 0.0) + b * fmin(dyd, 0.0);
+            lhs += Hi[e] * fmax(dyb, 0.0) + Lo[e] * fmin(dyb, 0.0);
+            lhs = wave_sum(act ? lhs : 0.0);
+            if (ln == 0) RT[56 + cr] = lhs;
+            if (cr == 2) {
+                wsync();
+                const double tot = unid((RT[56] + RT[57]) + RT[58]), nd = unid(RT[59]);
+                cr = 0;
+                cs = uni(tot < -eps_p * nd) ? CK_PI3 : CK_DI0;
+            } else ++cr;
+        } else if (cs == CK_PI3) {
+            const LaneC lc = lane_consts();
+            const double av = At_elem(e, DYd, DYb, lc);
+            ck_max_acc(0, ln, act ? fabs(av / D[e]) : 0.0);
+            if (cr == 2) {
+                const double na = unid(wave_max(CK[32 * NS + ln])), nd = unid(RT[59]);
+                if (uni(na < eps_p * nd) && ln == 0) RT[60] = (double)((int)RT[60] | 4);
+                cr = 0;
+                cs = CK_DI0;
+            } else ++cr;
+        } else if (cs == CK_DI0) {
+            // check_termination: the dual certificate is evaluated when the dual residual has not converged
+            const int fl = __builtin_amdgcn_readfirstlane((int)RT[60]);
+            cs = (fl & 2) ? CK_FIN : CK_DI1;
+        } else if (cs == CK_DI1) {
+            const double dx = DX[e];
+            ck_max_acc(0, ln, act ? fabs(D[e] * dx) : 0.0);
+            const double qs = wave_sum(act ? Qv[e] * dx : 0.0);
+            if (ln == 0) RT[56 + cr] = qs;
+            if (cr == 2) {
+                wsync();
+                const double nd = unid(wave_max(CK[32 * NS + ln])), qdx = unid((RT[56] + RT[57]) + RT[58]);
+                if (ln == 0) RT[59] = nd;
+                cr = 0;
+                cs = uni(nd > eps_d && qdx < -c * eps_d * nd) ? CK_DI2 : CK_FIN;
+            } else ++cr;
+        } else if (cs == CK_DI2) {
+            const double pv = P_row<false>(k, DX);
+            ck_max_acc(0, ln, act ? fabs(pv / D[e]) : 0.0);
+            if (cr == 2) {
+                const double np = unid(wave_max(CK[32 * NS + ln])), nd = unid(RT[59]);
+                cr = 0;
+                cs = uni(np < c * eps_d * nd) ? CK_DI3 : CK_FIN;
+            } else ++cr;
+        } else if (cs == CK_DI3) {
+            const LaneC lc = lane_consts();
+            const double nd = unid(RT[59]);
+            const double zd = lc.rmask * (Eid(k, tj) * DX[e] - prev_stage_dot(k, DX)), zb = Sb(k, tj) * DX[k * 8 + lc.bvar];
+            double bad = 0.0;
+            if (tj < NX) { const double v = zd / Ed[e]; if (v > eps_d * nd || v < -eps_d * nd) bad = 1.0; }
+            if (tj < nbox(k)) {
+                const double v = zb / Eb[e];
+                if ((Hi[e] < kInfty * kMinScaling && v > eps_d * nd) || (Lo[e] > -kInfty * kMinScaling && v < -eps_d * nd)) bad = 1.0;
+            }
+            ck_max_acc(0, ln, act ? bad : 0.0);
+            if (cr == 2) {
+                const double worst = unid(wave_max(CK[32 * NS + ln]));
+                if (uni(worst == 0.0) && ln == 0) RT[60] = (double)((int)RT[60] | 8);
+                cr = 0;
+                cs = CK_FIN;
+            } else ++cr;
+        } else if (cs == CK_FIN) {
+            if (!slot_d) return;                 // the verdict is written in a dense-product slot only: the others read it behind that slot's barrier
+            const int fl = __builtin_amdgcn_readfirstlane((int)RT[60]);
+            Res r;
+            r.pri = unid(RT[64]); r.dua = cinv * unid(RT[65]); r.nAxz = unid(RT[66]); r.nPAq = cinv * unid(RT[67]);
+            r.s_pri = unid(RT[68]); r.s_dua = unid(RT[69]); r.s_Axz = unid(RT[70]); r.s_PAq = unid(RT[71]);
+            int st = LPVMPC_UNSOLVED_;
+            if (ckc) {
+                if (r.pri > kInfty || r.dua > kInfty) st = LPVMPC_NON_CVX_;
+                else if ((fl & 3) == 3) st = LPVMPC_SOLVED_;
+                else if (fl & 4) st = LPVMPC_PRIMAL_INFEASIBLE_;
+                else if (fl & 8) st = LPVMPC_DUAL_INFEASIBLE_;
+            }
+            int code = 1;
+            double rn = rho;
+            if (st != LPVMPC_UNSOLVED_) code = 2;
+            else if (cka) {
+                rn = rho_estimate(r, rho);
+                if (rn > rho * cfg.rho_tol || rn < rho / cfg.rho_tol) code = 3;
+            }
+            if (ln == 0) {
+                RT[80] = (double)code; RT[81] = (double)st; RT[82] = rn;
+                RT[84] = r.pri; RT[85] = r.dua; RT[86] = r.nAxz; RT[87] = r.nPAq; RT[88] = r.s_pri; RT[89] = r.s_dua; RT[90] = r.s_Axz; RT[91] = r.s_PAq;
+                RT[83] = (double)ckk;
+            }
+            cs = CK_IDLE;
+        }
     }
 
     // ---- opt-in warm start (the reference always cold-starts, quirk Q8) ---------------
@@ -1993,8 +2440,13 @@ struct Solver {
         const double *src = a.pool_in + (size_t)entry * a.pool_stride;
         for (int i = tid; i < n; i += kStride) tA[i] = src[i];
         const double *sc = src + n;
-        c = sc[0]; cinv = sc[1];
-        set_rho(sc[2]);
+        if constexpr (TAIL) {       // (uniform values: scalar registers -- the tail kernel's vector registers hold K^-1)
+            c = unid(sc[0]); cinv = unid(sc[1]);
+            set_rho(unid(sc[2]));
+        } else {
+            c = sc[0]; cinv = sc[1];
+            set_rho(sc[2]);
+        }
         iter = (int)sc[3]; to_chk = (int)sc[4]; to_adp = (int)sc[5];
         const int inst = __builtin_amdgcn_readfirstlane((int)sc[6]);
         pol = false;
@@ -2114,6 +2566,30 @@ struct Solver {
         const double rho_tol = cfg.rho_tol;
         int to_chk = resuming ? to_chk0 : chk_every, to_adp = resuming ? to_adp0 : adp_every;
         const int defer_after = a.defer_after > 0 ? (resuming ? iter0 - 1 + a.defer_after : a.defer_after) : 0;     // park at the first check at or beyond this iteration
+        if constexpr (TAIL) {
+            // ---- the tail kernel's loop: dense product, fused element phase; checks evaluated beside the iterations (see tail_fused).
+            // The last wavefront runs the checker's side of the same loop (tail_loop<true>): the same scalar control flow on the same
+            // values, hence the same barriers, but none of the other wavefronts' registers or code.  A new rho sends everybody back to
+            // the factorisation (which exists once in the kernel, above this loop's entry).
+            TailCtl t;
+            t.iter = iter0 - 1; t.to_chk = to_chk; t.to_adp = to_adp; t.status = LPVMPC_UNSOLVED_; t.rn = rho;
+            ck_alpha = alpha;
+            const int role = __builtin_amdgcn_readfirstlane(wv);
+            for (;;) {
+                if (tid == 0) RT[83] = -1.0;
+                tail_begin(sigma);
+                const int v = role == NW - 1 ? tail_loop<true>(t, sigma, alpha, max_iter, chk_every, adp_every)
+                                             : tail_loop<false>(t, sigma, alpha, max_iter, chk_every, adp_every);
+                if (v >= 2) set_rho(t.rn);
+                if (v != 2) break;
+                factor(sigma);
+            }
+            launder_ids();
+            // the residual norms of the verdict that ended the loop (the last one written)
+            R.pri = RT[84]; R.dua = RT[85]; R.nAxz = RT[86]; R.nPAq = RT[87]; R.s_pri = RT[88]; R.s_dua = RT[89]; R.s_Axz = RT[90]; R.s_PAq = RT[91];
+            iter = t.iter; status = t.status; pri_res = R.pri; dua_res = R.dua;
+            checked = true;
+        } else
         for (iter = iter0; iter <= max_iter; ++iter) {
             checked = chk_every > 0 && --to_chk == 0;
             const bool adapt = adp_every > 0 && --to_adp == 0;
@@ -2129,7 +2605,7 @@ struct Solver {
             // diagnostic builds (tools/phase_pmc.sh): the loop runs ONE phase of the iteration (1 right-hand side, 2 KKT solve, 3 update;
             // 0 none), so that the hardware counters of a launch can be attributed to it.  The iterates are meaningless.
             if (LPVMPC_PHASE_ONLY == 1) build_rhs(sigma);
-            if (LPVMPC_PHASE_ONLY == 2) { if constexpr (TAIL) dense_apply(); else kkt_solve(); }
+            if (LPVMPC_PHASE_ONLY == 2) kkt_solve();
             if (LPVMPC_PHASE_ONLY == 3) update(alpha, checked);
 #else
             if constexpr (kFour) iterate4(sigma, alpha, checked);
@@ -2143,7 +2619,7 @@ struct Solver {
             } else {
             build_rhs(sigma);
             STAMP(0);
-            if constexpr (TAIL) { dense_apply(); STAMP(1); } else kkt_solve();
+            kkt_solve();
             update(alpha, checked);         // delta_x / delta_y are only read by the infeasibility tests
             }
 #endif
@@ -2207,6 +2683,9 @@ struct Solver {
         if constexpr (kFour) {          // the inner top wavefront's own eight segments (inner4) behind wavefront 0's six
             if (tid == 128) for (int i = 0; i < 8; ++i) o_.xPred[(size_t)inst * NS * NX + 8 + i] = (double)stamp[i] / iter;
         }
+#if LPVMPC_STAMPS == 4
+        if constexpr (TAIL) { if (tid == 0) for (int i = 0; i < 8; ++i) o_.xPred[(size_t)inst * NS * NX + i] = (double)stamp[i] / iter; }
+#endif
         if (tid == 0 && o_.resid) {     // diagnostic build: resid carries per-iteration cycle counts instead
             double *o = o_.resid + (size_t)inst * 4;
 #if LPVMPC_STAMPS == 2
@@ -2419,9 +2898,14 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
     const bool generic = kernel_variant == 1, one_wave = kernel_variant == 2, dpp = kernel_variant == 3;
     // a resume pass that runs its entries to completion may use the whole-CU tail kernel (SolveArgs::tail); the entries must
     // have been parked by a kernel with the compile-time-horizon LDS image
-    // (controller and planner at N = 20: 168 unknowns either way, K^-1 fits the register file of a CU; 248 / 328 at N = 30 / 40 do not)
-    if (a.resume && a.tail && a.defer_after == 0 && !generic && cfg.N == 20)
+    // (controller and planner at N = 20: 168 unknowns either way, K^-1 fits the register file of a CU; 248 / 328 at N = 30 / 40 do not.
+    // steeringDelay > 0: the tail kernel's element threads keep two box rows per variable in registers and delta would have three --
+    // the reference runs delay 0 (CMAIN:49); such handles finish their parked instances with the two-wavefront kernel)
+    if (a.resume && a.tail && a.defer_after == 0 && !generic && cfg.N == 20 && cfg.steering_delay == 0)
         return cfg.kind == 0 ? launch_one<6, 20, 8, false, false, true>(cfg, dcfg, a, stream) : launch_one<5, 20, 8, false, false, true>(cfg, dcfg, a, stream);
+#ifdef LPVMPC_DEV_TAIL_ONLY
+    return hipErrorInvalidValue;       // development builds (seconds instead of minutes): the tail kernels only, for looking at their assembly
+#else
     if (cfg.kind == 0) {
         if (!generic && cfg.N == 20) return one_wave ? launch_one<6, 20, 1>(cfg, dcfg, a, stream)
                                           : (dpp ? launch_one<6, 20, 2>(cfg, dcfg, a, stream) : launch_one<6, 20, 2, true>(cfg, dcfg, a, stream));
@@ -2449,6 +2933,7 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
                                             : (kernel_variant == 6 ? launch_one<5, 40, 2, true>(cfg, dcfg, a, stream) : launch_one<5, 40, 4, true>(cfg, dcfg, a, stream));
     if (!generic && cfg.N == 20) return dpp ? launch_one<5, 20, 2>(cfg, dcfg, a, stream) : launch_one<5, 20, 2, true>(cfg, dcfg, a, stream);     // the planner half of configs[3]
     return launch_one<5, 0, 1>(cfg, dcfg, a, stream);
+#endif
 }
 
 }  // namespace lpvmpc

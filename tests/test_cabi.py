@@ -125,5 +125,24 @@ def test_device_assembly_has_no_copy_in_front_of_an_exec_restore(ffi):
             fh.write("_Zk:\n.LBB0_1:\n\tv_mov_b32_e32 v33, 0x58\n\ts_or_saveexec_b64 s[12:13], s[20:21]\n"
                      "\tv_mov_b32_e32 v33, v234\n\ts_or_b64 exec, exec, s[12:13]\n\tds_write_b64 v1, v[2:3]\n")
         assert len(chk.scan(bad)) == 1
+        # the else side of a structurised if / else (s_or_saveexec + s_xor exec): its phi copy is legitimate when the then side, in
+        # front of the label, wrote the same register for its own lanes -- and flagged when it did not
+        with open(bad, "w") as fh:
+            fh.write("_Zk:\n\tv_lshlrev_b32_e32 v46, 3, v1\n\tds_write_b64 v46, v[2:3]\n.LBB0_1:\n\ts_or_saveexec_b64 s[0:1], s[2:3]\n"
+                     "\tv_lshlrev_b32_e32 v30, 3, v1\n\ts_xor_b64 exec, exec, s[0:1]\n\tv_mov_b32_e32 v46, v30\n\ts_or_b64 exec, exec, s[0:1]\n\tds_write_b64 v1, v[2:3]\n")
+        assert chk.scan(bad) == []
+        with open(bad, "w") as fh:
+            fh.write("_Zk:\n\tv_lshlrev_b32_e32 v45, 3, v1\n\tds_write_b64 v45, v[2:3]\n.LBB0_1:\n\ts_or_saveexec_b64 s[0:1], s[2:3]\n"
+                     "\tv_lshlrev_b32_e32 v30, 3, v1\n\ts_xor_b64 exec, exec, s[0:1]\n\tv_mov_b32_e32 v46, v30\n\ts_or_b64 exec, exec, s[0:1]\n\tds_write_b64 v1, v[2:3]\n")
+        assert len(chk.scan(bad)) == 1
+        # the same for the short form of the else entry (s_andn2_saveexec as the block's first instruction)
+        with open(bad, "w") as fh:
+            fh.write("_Zk:\n\tv_lshlrev_b32_e32 v15, 3, v1\n\tds_write_b64 v15, v[2:3]\n.LBB0_1:\n\ts_andn2_saveexec_b64 s[0:1], s[6:7]\n"
+                     "\tv_mov_b32_e32 v15, v88\n\ts_or_b64 exec, exec, s[0:1]\n\tds_write_b64 v1, v[2:3]\n")
+        assert chk.scan(bad) == []
+        with open(bad, "w") as fh:
+            fh.write("_Zk:\n\tv_lshlrev_b32_e32 v14, 3, v1\n\tds_write_b64 v14, v[2:3]\n.LBB0_1:\n\ts_andn2_saveexec_b64 s[0:1], s[6:7]\n"
+                     "\tv_mov_b32_e32 v15, v88\n\ts_or_b64 exec, exec, s[0:1]\n\tds_write_b64 v1, v[2:3]\n")
+        assert len(chk.scan(bad)) == 1
     finally:
         os.remove(bad)

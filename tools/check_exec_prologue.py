@@ -48,7 +48,7 @@ def reads(instrs, reg):
     return False
 
 
-def scan(path, window=8):
+def scan(path, window=8, lookback=2000):
     suspects = []
     kernel = None
     lines = open(path).read().split("\n")
@@ -84,11 +84,38 @@ def scan(path, window=8):
                     # mask earlier in this block: otherwise the lanes outside the region reach the join with a stale register)
                     opened = [i_ for i_, b_ in enumerate(body[:k]) if re.match(r"s_(and|andn2)_saveexec_b64|s_and_b64\s+exec,\s*exec,|s_andn2_b64\s+exec,\s*exec,", b_)]
                     first_open = opened[0] if opened else k
+                    # the ELSE entry of a structurised if / else: `s_or_saveexec_b64 sX, sY` (all lanes of the construct) followed by
+                    # `s_xor_b64 exec, exec, sX` (the lanes that skipped the THEN side).  A copy behind that pair is the else side's
+                    # value of a phi: legitimate when the then side, the straight-line code in front of the label, wrote the same
+                    # destination for its own lanes (looked up in the `lookback` instructions in front of the label)
+                    else_open = None
+                    for i_, b_ in enumerate(body[:k]):
+                        m_ = re.match(r"s_or_saveexec_b64\s+(s\[\d+:\d+\])", b_)
+                        if m_:
+                            for i2, b2 in enumerate(body[i_ + 1:k], i_ + 1):
+                                if re.match(r"s_xor_b64\s+exec,\s*exec,\s*" + re.escape(m_.group(1)), b2):
+                                    else_open = i2
+                                    break
+                            break
+                    # ... or, in its shorter form, `s_andn2_saveexec_b64 sX, sY` as the block's first instruction (the lanes of the construct
+                    # that are not in the then side's mask sY)
+                    if else_open is None and body and re.match(r"s_andn2_saveexec_b64\s", body[0]):
+                        else_open = 0
+                    then_side = []
+                    if else_open is not None:
+                        j2 = i - 1
+                        while j2 >= 0 and len(then_side) < lookback and not re.match(r"^_Z\w+:", lines[j2]):
+                            t2 = lines[j2].strip()
+                            j2 -= 1
+                            if t2 and not t2.startswith((";", ".")):
+                                then_side.append(t2)
                     for idx, b in enumerate(body[:k]):
                         if idx > first_open and re.match(r"(v_mov_b32_e32\s+v\d+,\s*v\d+$|v_mov_b64_e32\s+v\[[\d:]+\],\s*v\[|v_accvgpr_(read|write)_b32)", b):
                             if all(any(writes(early, d) for early in body[:first_open]) for d in dest_regs(b)):
                                 continue
                         if not re.match(r"(v_mov_b32_e32\s+v\d+,\s*v\d+$|v_mov_b64_e32\s+v\[[\d:]+\],\s*v\[|v_accvgpr_(read|write)_b32)", b):
+                            continue
+                        if else_open is not None and idx > else_open and all(any(writes(t2, d) for t2 in then_side) for d in dest_regs(b)):
                             continue
                         # a copy whose destination is consumed again before the mask restore is a temporary of the branch
                         # that falls through into the join (e.g. the halves of a 64-bit address product feeding a store

@@ -13,9 +13,10 @@ import lpvmpc
 from lpvmpc import workloads
 dev = torch.device("cuda", 0)
 t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+CHK = int(sys.argv[1]) if len(sys.argv) > 1 else 25       # termination-check interval (a large one shows the bare phases: no check in flight)
 for B in (1, 64):
     w = workloads.controller_batch(B, N=20, seed=0)
-    eng = workloads.make_solver(w, adaptive_rho=0, polish=0, check_termination=25, max_iter=2025, eps_abs=1e-30, eps_rel=1e-30, eps_prim_inf=1e-30, eps_dual_inf=1e-30)
+    eng = workloads.make_solver(w, adaptive_rho=0, polish=0, check_termination=CHK, max_iter=2025, eps_abs=1e-30, eps_rel=1e-30, eps_prim_inf=1e-30, eps_dual_inf=1e-30)
     eng.reserve(B); eng.set_option("defer_pool", 64); eng.set_option("defer_after", 25); eng.set_option("defer_budget", 0)
     st = 0
     o = dict(xPred=torch.zeros((B, 21, 6), dtype=torch.float64, device=dev), uPred=torch.zeros((B, 20, 2), dtype=torch.float64, device=dev),
@@ -25,6 +26,9 @@ for B in (1, 64):
                   o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"], stream=st)
     eng.join(st); torch.cuda.synchronize()
     r = o["resid"].cpu().numpy(); it = o["iters"].cpu().numpy()
-    print("join B=%d iters %s | cycles per iteration (sum over the tail's iterations / all iterations): build_rhs %.0f | dense_apply %.0f | - %.0f | update %.0f | total %.0f"
-          % (B, np.unique(it), *np.median(r, axis=0), np.median(r.sum(1))))
+    print("check every %d: join B=%d iters %s | cycles per iteration (sum over the tail's iterations / all iterations): dense_apply %.0f | fused element phase %.0f | - %.0f | - %.0f | total %.0f"
+          % (CHK, B, np.unique(it), *np.median(r, axis=0), np.median(r.sum(1))))
+    if os.environ.get("STAMPS4"):
+        x = o["xPred"].cpu().numpy().reshape(B, -1)[:, :8]
+        print("   STAMPS=4 (wavefront 0; cycles per iteration): barrier after dense %.0f | barrier after fused %.0f | dense: loads arrived %.0f, products + stores %.0f | fused: first loads arrived %.0f, compute + store %.0f" % tuple(np.median(x, axis=0)[:6]))
     eng.close()
