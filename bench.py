@@ -227,10 +227,19 @@ def main():
     for e in engines:
         e.set_timing(True)            # HIP events on the launch stream around every solve-kernel launch
     fence()
+    # device-time marks for config.region_breakdown_ms: the region's start, and -- behind the last step enqueued on each stream -- the end of
+    # that stream's steps (main launches and the bounded passes that follow them); what remains of the region is the closing passes
+    # of lpvmpc_join, i.e. the tail kernel on whatever is still parked
+    ev_start = torch.cuda.Event(enable_timing=True)
+    ev_steps = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+    ev_start.record(streams[0])
     t0 = time.perf_counter()
     timed_slots = [step(args.warmup + j) for j in my_steps]      # (global index: the warm-up steps come first in the sequence)
+    for i in range(S):
+        ev_steps[i].record(streams[i])
     fence()
     elapsed = time.perf_counter() - t0
+    main_phase_ms = max(ev_start.elapsed_time(ev) for ev in ev_steps)
     k_ms = k_n = 0
     r_ms = r_n = 0
     for e in engines:
@@ -384,6 +393,9 @@ def main():
                             # this run where the extras ran: config.lone_instance_iteration_us; else the figures of DESIGN.md section 5)
                             "slowest_instance_floor_ms": slowest_floor_ms(int(max(it_slot[i].max() for i in used)), planner, args.defer, extras),
                             "timed_region_ms": elapsed * 1e3,
+                            # main_phase: until the last stream has finished its steps (main launches + bounded resume passes); tail_only: the rest
+                            # of the region, when only the closing passes (the whole-CU tail kernel on the still-parked stragglers) are resident
+                            "region_breakdown_ms": {"main_phase": main_phase_ms, "tail_only": max(elapsed * 1e3 - main_phase_ms, 0.0)},
                             "solved_fraction": agg[1] / total}, **info, **extras),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -503,7 +515,7 @@ def other_workloads(args, rank, local_rank, world, dev):
             continue
         r = o["roofline"]
         res[name] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "steps": o["steps"], "warmup": o["warmup"], "ms_per_step": o["ms_per_step"],
-                     "frac": r.get("frac"), "kernel": r.get("kernel"), "kernel_avg_ms": r.get("kernel_avg_ms"), "launches": r.get("launches"),
+                     "frac": r.get("frac"), "aggregate_frac": r.get("aggregate_frac"), "kernel": r.get("kernel"), "kernel_avg_ms": r.get("kernel_avg_ms"), "launches": r.get("launches"),
                      "workload": o["config"]["workload"], "leg_wall_s": time.perf_counter() - t1}
         for k in ("mean_admm_iters", "mean_admm_iters_controller", "mean_admm_iters_planner", "solved_fraction", "alive_fraction", "real_time_factor",
                   "all_vehicles_ticks_per_s", "planner_mean_admm_iters"):
@@ -557,6 +569,9 @@ def bench_planner_leg(args, rank, local_rank, world, dev):
                        "mean_admm_iters": float(it.mean()), "solved_fraction": float((stt == 1).mean())},
             "roofline": {"bound": "hbm", "frac": bl / k_avg_s / 1e9 / HBM_PEAK_GBS, "kernel": "admm_solve_kernel<5, 30, 4, MFMA sweeps, chains relayed over four wavefronts>",
                          "kernel_avg_ms": kms / max(kn, 1), "launches": kn, "algorithmic_bytes_per_launch": bl, "bytes_per_admm_iteration": bi,
+                         # what the chip does: every launch's algorithmic bytes over the leg's wall time (the per-launch figure above divides one
+                         # launch's bytes by its duration while the other streams' launches share the chip)
+                         "aggregate_frac": bl * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
                          "note": "launches of the %d streams overlap: kernel_avg_ms is a launch sharing the chip" % S}}
 
 
@@ -695,11 +710,17 @@ def dry_run(args):
     g_u0, g_status, g_iters = gather_results(u0, status, iters, total)
     ok = bool(g_u0.shape == (total, 2) and np.array_equal(g_u0[:, 0], np.arange(total)) and int(g_iters.sum()) == int(agg[0])
               and int(agg[1]) == total and g_status.shape == (total,))
+    # every rank's shard, gathered: the line shows that the shards tile the global batch
+    shards = [[a, b]]
+    if world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, [a, b])
+        shards = box
     if rank == 0:
         strong = args.scaling == "strong" and world > 1 and args.workload == "cfg2"
         print(json.dumps({"metric": "MPC solves/sec (N=20, nx=6, nu=2)", "value": None, "unit": "solves/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": "strong" if strong else "weak",
-                          "config": {"workload": args.workload, "global_instances": total, "shard_rank0": [a, b],
+                          "config": {"workload": args.workload, "global_instances": total, "shard_rank0": [a, b], "shards": shards,
                                      "steps_rank0": list(shard_range(args.steps, 0, world)) if strong else [0, args.steps], "rccl_world": world,
                                      "max_elapsed_s": elapsed, "gather_ok": ok}}), flush=True)
     if world > 1:
@@ -819,6 +840,7 @@ def bench_mixed(args, rank, local_rank, world, dev):
                             "traffic": None, "kernel": "admm_solve_kernel<5, 20, 2, MFMA sweeps>", "kernel_avg_ms": kms[1] / max(kn[1], 1), "launches": kn[1],
                             "algorithmic_bytes_per_launch": bl_p, "bytes_per_admm_iteration": bi_p,
                             "aggregate_algorithmic_GBps": (bl_c + bl_p) * args.steps * world / elapsed / 1e9,
+                            "aggregate_frac": (bl_c + bl_p) * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,      # per GPU: both halves' launches over the wall time
                             "note": "dominant kernel = the planner half (about 12x the controller's iterations)"}}
     for pair in lanes:
         for e, _, _ in pair:
@@ -939,6 +961,9 @@ def bench_cascade(args, rank, local_rank, world, dev):
                "roofline": {"bound": "hbm", "achieved": bytes_launch / k_avg_s / 1e9 if pn else float("nan"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": (bytes_launch / k_avg_s / 1e9 / HBM_PEAK_GBS) if pn else float("nan"), "traffic": None,
                             "kernel": "admm_solve_kernel<5, 40, 4, MFMA sweeps, chains relayed over four wavefronts>", "kernel_avg_ms": pms / max(pn, 1), "launches": pn,
+                            # the planner launches of the timed region (the last tick's iteration counts stand for all: a thinning fleet makes this an
+                            # under-estimate for the earlier ticks) over the wall time; the controller's launches add about a twentieth
+                            "aggregate_frac": (bytes_launch * pn / elapsed / 1e9 / HBM_PEAK_GBS) if pn else float("nan"),
                             "note": "planner solve kernel (95 % of a tick); algorithmic bytes from the iteration counts of the last planner tick; the sub-fleets' launches overlap, so kernel_avg_ms is the duration of a launch sharing the chip"}}
     for ct, pl in fleets:
         ct.close(); pl.close()

@@ -1,0 +1,104 @@
+"""Test infrastructure: the stated float tolerance of the QP stage (include/lpvmpc.h) as code.
+
+Against the CPU oracle on identical data, status and iteration count are EQUAL (the one documented exception: a run that ends at
+max_iter, where OSQP's "solved inaccurate" test -- 10 eps -- is decided by round-off: MAX_ITER_REACHED on one side,
+SOLVED_INACCURATE on the other, same iteration count) and the solution falls in one of three classes:
+
+  A  polished (status SOLVED, polish flag 1): both sit on the active-set optimum            -> |dx|, |du| <= 1e-6
+  B  un-polished, converged (SOLVED without a successful polish, SOLVED_INACCURATE before the cap): the two implementations run
+     the same ADMM recursion and differ by the round-off of equivalent KKT factorisations   -> <= 2e-4 (observed <= 1e-6)
+  C  ran to the iteration cap (max_iter = 4000: MAX_ITER_REACHED, or SOLVED_INACCURATE by the 10 eps test at the cap): the returned
+     point is an UNCONVERGED ADMM iterate of an ill-conditioned planner QP (P has 31 near-zero eigenvalues; the
+     forward-Euler model grows like 2^N); 4000 iterations amplify the round-off difference of the two implementations.  OSQP
+     guarantees nothing for such a point and the reference uses it as it comes (CTRL:322-324, PLAN:214-216).  Held: same iteration
+     count (the cap), statuses within {MAX_ITER_REACHED, SOLVED_INACCURATE}, |du| <= 5e-2 (observed over 110 202 instances: 42 in
+     this class, |du| <= 1.01e-2, 40 of them with the objective within 1e-3 and the primal residual inside the status's tolerance;
+     profiles/r05_parity_sweep.txt lists every one).
+Every instance of the wide sweep (tests/diagnostics/seed_sweep.py) beyond 1e-6 is in class C.
+"""
+import numpy as np
+
+from oracle import lpv_ref as L
+
+P = dict(L.DEFAULT_PARAMS)
+SOLVED, SOLVED_INACC, MAX_ITER = 1, 2, -2
+
+
+def instance_qp(w, kind, j):
+    """(P, q, A, l, u) of instance j of a workload dict, assembled on the host as the reference does."""
+    N = int(w["N"]); p = dict(P)
+    if kind == "controller":
+        S, A, B = L.ctrl_lpv_prediction(p, w["dt"], N, w["track"], w["x0"][j], w["u_prev"][j], w["vel_ref"][j],
+                                        None if w["curv_s"] is None else w["curv_s"][j], w["cf_new"], w["lap"])
+        x0 = w["x0"][j] if int(w["lap"]) == 0 else w["x0"][j]
+        return L.ctrl_build_qp(w["Q"], w["R"], w["dR"], N, A, B, x0, w["u_old"][j], w["vel_ref"][j], p["max_vel"])
+    S, A, B = L.plan_lpv_prediction(p, w["dt"], N, w["track"], w["x0"][j], w["curv_s"][j], w["u_prev"][j])
+    mey = float(np.broadcast_to(w["max_ey"], (w["x0"].shape[0],))[j])
+    return L.plan_build_qp(w["Q"], w["R"], w["dR"], w["L_cf"], N, A, B, w["x0"][j], w["u_old"][j], mey, p["max_vel"], p["min_vel"])
+
+
+def primal_residual(qp, z, eps=1e-3):
+    """OSQP's unscaled primal residual of the point z (with its own z_c = clip(Az)) and the tolerance eps (1 + max(|Az|, |z_c|))."""
+    A = np.asarray(qp.A.todense() if hasattr(qp.A, "todense") else qp.A, float)
+    Az = A @ z
+    zc = np.clip(Az, qp.l, qp.u)
+    inf = lambda v: float(np.max(np.abs(v), initial=0.0))
+    return inf(Az - zc), eps + eps * max(inf(Az), inf(zc))
+
+
+def objective(qp, z):
+    Pm = np.asarray(qp.P.todense() if hasattr(qp.P, "todense") else qp.P, float)
+    return float(0.5 * z @ Pm @ z + np.asarray(qp.q, float) @ z)
+
+
+def outlier_report(w, kind, j, out, ref):
+    """Class-C evidence for instance j: a dict with the fields the sweep prints and `class` in {"C", "FAIL: ..."}."""
+    st, st_ref = int(out["status"][j]), int(ref["status"][j])
+    pol = int(out["polish"][j]) if "polish" in out else 0
+    du = float(np.max(np.abs(out["uPred"][j] - ref["uPred"][j])))
+    qp = instance_qp(w, kind, j)
+    zd = np.concatenate([out["xPred"][j].reshape(-1), out["uPred"][j].reshape(-1)])
+    zr = np.concatenate([ref["xPred"][j].reshape(-1), ref["uPred"][j].reshape(-1)])
+    fd, fr = objective(qp, zd), objective(qp, zr)
+    gap = abs(fd - fr) / max(1.0, abs(fr))
+    pri, tol = primal_residual(qp, zd)
+    pri_ref, _ = primal_residual(qp, zr)
+    capped = int(out["iters"][j]) == int(ref["iters"][j]) == int(w.get("max_iter", 4000))
+    why = []
+    if not ({st, st_ref} <= {SOLVED_INACC, MAX_ITER}):
+        why.append("status (only runs that end at the cap may differ beyond class B)")
+    if not capped:
+        why.append("iterations (not at the cap)")
+    if du > 5e-2:
+        why.append("|du|")
+    lim = tol if st == SOLVED else (10.0 * tol if st == SOLVED_INACC else float("inf"))      # (informative: a MAX_ITER point met no rule)
+    return dict(status=st, status_ref=st_ref, polish=pol, iters=int(out["iters"][j]), iters_ref=int(ref["iters"][j]), du=du, obj_gap=gap,
+                pri=pri, pri_tol=lim, pri_ref=pri_ref, **{"class": "C" if not why else "FAIL: " + ", ".join(why)})
+
+
+def check_batch(w, kind, out, ref, allow_status_flip_at_max_iter=True):
+    """The whole rule set on a batch; returns counts per class and raises AssertionError on the first violation."""
+    sane = (ref["status"] != -10) & ~(np.isnan(ref["uPred"]).any(axis=(1, 2)) & (ref["status"] == 1))
+    counts = dict(A=0, B=0, C=0, no_solution=0, flips=0)
+    for j in np.nonzero(sane)[0]:
+        st, sr = int(out["status"][j]), int(ref["status"][j])
+        if st != sr:
+            assert allow_status_flip_at_max_iter and {st, sr} <= {SOLVED_INACC, MAX_ITER} and int(out["iters"][j]) == int(ref["iters"][j]), (int(j), st, sr)
+            counts["flips"] += 1
+        assert int(out["iters"][j]) == int(ref["iters"][j]), (int(j), int(out["iters"][j]), int(ref["iters"][j]))
+        fo, fr = np.isfinite(out["uPred"][j]).all(), np.isfinite(ref["uPred"][j]).all()
+        assert fo == fr, (int(j), "finite", fo, fr)
+        if not fo:
+            counts["no_solution"] += 1
+            continue
+        d = max(float(np.max(np.abs(out["uPred"][j] - ref["uPred"][j]))), float(np.max(np.abs(out["xPred"][j] - ref["xPred"][j])) / max(1.0, float(np.max(np.abs(ref["xPred"][j]))))))
+        polished = st == SOLVED and "polish" in out and int(out["polish"][j]) == 1
+        if d <= 1e-6:
+            counts["A" if polished else "B"] += 1
+        elif not polished and d <= 2e-4:
+            counts["B"] += 1
+        else:
+            r = outlier_report(w, kind, int(j), out, ref)
+            assert r["class"] == "C", (int(j), r)
+            counts["C"] += 1
+    return counts

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 # (test infrastructure: uses the oracle as a checker; lives under tests/ for that reason)
-"""Seed / track sweep on a GPU box: default kernels against the C oracle tick on many random batches."""
+"""Seed / track sweep on a GPU box: default kernels against the C oracle tick on many random batches.
+Every instance whose uPred differs from the oracle's by more than 1e-6 is listed (round 5): device status, polish flag, iteration
+count, |du|, and -- on the instance's own QP, rebuilt on the host -- the objective of both points relative to each other and
+the primal residual of the device's point against OSQP's tolerance (tests/_tolerance.py holds the same rules for the suite)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -8,8 +11,10 @@ import numpy as np
 import lpvmpc
 from lpvmpc import workloads
 from oracle import osqp_ref as O
+from tests import _tolerance as T
 
 tot = dict(n=0, st=0, it=0, close=0, fin=0)
+cls = {}
 worst = 0.0
 for shape in ("oval", "L_shape", "3110", "Euge_Track"):
     for seed in range(6):
@@ -33,6 +38,13 @@ for shape in ("oval", "L_shape", "3110", "Euge_Track"):
             st = int(np.sum(a["status"][sane] == ref["status"][sane])); it = int(np.sum(a["iters"][sane] == ref["iters"][sane]))
             tot["n"] += int(sane.sum()); tot["st"] += st; tot["it"] += it; tot["close"] += int(np.sum(d <= 1e-6)); tot["fin"] += int(fin.sum())
             worst = max(worst, float(d.max()) if d.size else 0.0)
+            idx = np.nonzero(fin)[0]
+            for j in idx[d > 1e-6]:
+                r = T.outlier_report(w, kind, int(j), a, ref)
+                key = (r["status"], r["polish"], r["class"])
+                cls[key] = cls.get(key, 0) + 1
+                print("OUTLIER %s seed %d %s N=%d lap=%d #%d: status %d/%d polish %d iters %d/%d |du| %.2e  obj gap %.2e  pri %.2e (tol %.2e)  -> %s"
+                      % (shape, seed, kind, N, lap, j, r["status"], r["status_ref"], r["polish"], r["iters"], r["iters_ref"], r["du"], r["obj_gap"], r["pri"], r["pri_tol"], r["class"]), flush=True)
             if st != sane.sum() or it < 0.995 * sane.sum() or (d.size and np.mean(d <= 1e-6) < 0.98):
                 print("ATTENTION %s seed %d %s N=%d lap=%d: status %d/%d iters %d/%d close %d/%d max %.2e" % (shape, seed, kind, N, lap, st, sane.sum(), it, sane.sum(), np.sum(d <= 1e-6), fin.sum(), d.max() if d.size else 0), flush=True)
-    print(shape, "done", tot, "worst du %.2e" % worst, flush=True)
+    print(shape, "done", tot, "worst du %.2e" % worst, "outlier classes (status, polish, class): %s" % cls, flush=True)

@@ -1,0 +1,116 @@
+"""GPU: the stated float tolerance of the QP stage, held where round 4's review found it open (DESIGN.md
+section 2; tests/_tolerance.py holds the rules): planner batches on the tracks the suite did not cover (TRACK:28-81: "3110",
+"Euge_Track"), the one instance of the wide sweep whose status differs from the oracle's (a run that ends at max_iter), and the
+boundary's "thread-safe across handles" (SURVEY section 8b)."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import osqp_ref as O
+from tests import _tolerance as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", ["3110", "Euge_Track"])
+@pytest.mark.parametrize("N", [30, 40])
+def test_planner_on_the_other_tracks_against_oracle(shape, N):
+    """2 seeds x 256 planner instances per (track, horizon): status and iteration count equal to the oracle's, every solution in
+    one of the three stated classes (polished 1e-6; un-polished 2e-4; beyond that an eps-iterate of an ill-conditioned planner QP,
+    held to OSQP's own guarantee -- objective within 1e-3 of the oracle's point, primal residual within the status's tolerance)."""
+    from lpvmpc import workloads
+    total = dict(A=0, B=0, C=0, no_solution=0, flips=0)
+    for seed in (200, 201):
+        w = workloads.planner_batch(256, N=N, seed=seed, shape=shape)
+        eng = workloads.make_solver(w)
+        out = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+        eng.close()
+        ref = O.plan_tick_batch(w, nthreads=16)
+        c = T.check_batch(w, "planner", out, ref)
+        for k in total:
+            total[k] += c[k]
+    assert total["A"] + total["B"] >= 0.9 * (total["A"] + total["B"] + total["C"]), total      # class C is the exception, not the rule
+    assert total["A"] > 0 and total["no_solution"] < 512, total
+
+
+def test_max_iter_status_decided_by_round_off_is_the_only_status_difference():
+    """`oval seed 200, planner N = 20` of the wide sweep (tests/diagnostics/seed_sweep.py): 511 of 512 statuses equal the oracle's;
+    the one that differs ends at max_iter = 4000 on both sides, where OSQP's approximate test (10 eps) is decided by round-off --
+    MAX_ITER_REACHED on one side, SOLVED_INACCURATE on the other.  The reference treats both as feasible (CTRL:322-324, PLAN:214-216);
+    everything else about the batch follows the stated classes."""
+    from lpvmpc import workloads
+    w = workloads.planner_batch(512, N=20, seed=200, shape="oval")
+    eng = workloads.make_solver(w)
+    out = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+    eng.close()
+    ref = O.plan_tick_batch(w, nthreads=16)
+    c = T.check_batch(w, "planner", out, ref, allow_status_flip_at_max_iter=True)
+    assert c["flips"] <= 1, c
+    sane = ref["status"] != -10
+    diff = np.nonzero((out["status"] != ref["status"]) & sane)[0]
+    for j in diff:
+        assert int(out["iters"][j]) == int(ref["iters"][j]) == 4000 and {int(out["status"][j]), int(ref["status"][j])} == {2, -2}, (int(j), out["status"][j], ref["status"][j])
+
+
+def test_two_handles_on_two_host_threads():
+    """one handle per (device, stream), not thread-safe per handle, thread-safe ACROSS handles.  Two Python
+    threads, each with its own controller / planner handle on device 0 and its own stream, interleave deferred and plain solve
+    calls (ctypes releases the GIL inside the library); every result equals the serial run of the same calls, word for word where
+    the same kernel finishes the instance (status, iterations, polish flag always)."""
+    import torch
+    from lpvmpc import workloads
+    dev = torch.device("cuda", 0)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    jobs = [("controller", workloads.controller_batch(512, N=20, seed=s)) for s in (16, 3)] + \
+           [("planner", workloads.planner_batch(256, N=20, seed=s, shape="oval")) for s in (1, 2)]
+
+    def run(kind, w, stream, rounds, defer):
+        planner = kind == "planner"
+        B, N, nx = w["x0"].shape[0], w["N"], (5 if planner else 6)
+        eng = workloads.make_solver(w)
+        eng.reserve(B)
+        if defer:
+            eng.set_option("defer_after", 100); eng.set_option("defer_budget", 100)
+        ins = dict(x0=t(w["x0"]), u_prev=t(w["u_prev"]), vel=t(w["vel_ref"]), curv=t(w["curv_s"]), u_old=t(w["u_old"]), mey=t(w["max_ey"]))
+        outs = []
+        for _ in range(rounds):
+            o = dict(xPred=torch.empty((B, N + 1, nx), dtype=torch.float64, device=dev), uPred=torch.empty((B, N, 2), dtype=torch.float64, device=dev),
+                     status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev),
+                     resid=torch.zeros((B, 4), dtype=torch.float64, device=dev), polish=torch.zeros(B, dtype=torch.int32, device=dev))
+            eng.solve_dev(B, ins["x0"], ins["u_prev"], ins["vel"], ins["curv"], ins["u_old"], ins["mey"], o["xPred"], o["uPred"], o["status"], o["iters"],
+                          o["resid"], o["polish"], cf_new=w["cf_new"], lap=w["lap"], stream=stream.cuda_stream)
+            outs.append(o)
+        eng.join(stream.cuda_stream)
+        stream.synchronize()
+        res = [{k: v.cpu().numpy() for k, v in o.items()} for o in outs]
+        eng.close()
+        return res
+
+    # (deferral on the first controller job only: which instances of an OVERFLOWING pool are parked depends on timing, and a planner
+    # batch parks more than a default pool holds -- the tail kernel and the two-wavefront kernel agree to round-off, not bit for bit)
+    serial = [run(kind, w, torch.cuda.Stream(device=dev), 3, defer=(i == 0)) for i, (kind, w) in enumerate(jobs)]
+    results = [None] * len(jobs)
+    errors = []
+
+    def worker(ids):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream(device=dev)
+            for i in ids:
+                results[i] = run(jobs[i][0], jobs[i][1], st, 3, defer=(i == 0))
+        except Exception as e:          # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(ids,)) for ids in ((0, 3), (2, 1))]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+    for i in range(len(jobs)):
+        for a, b in zip(results[i], serial[i]):
+            for k in ("status", "iters", "polish"):
+                assert np.array_equal(a[k], b[k]), (i, k)
+            for k in ("xPred", "uPred"):
+                assert np.array_equal(a[k], b[k], equal_nan=True), (i, k)

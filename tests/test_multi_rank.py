@@ -72,6 +72,32 @@ def test_bench_launcher_spawns_one_rank_per_gpu():
         assert out["config"]["max_elapsed_s"] == pytest.approx(2e-3)
 
 
+@pytest.mark.timeout(600)
+def test_bench_launcher_at_the_target_size_of_eight_ranks():
+    """north_star's split is over the 8 GPUs of a node: the launcher path (`python bench.py --gpus 8`: a subprocess.Popen parent, never an
+    exec of a process that touched a GPU), shard_range and the closing all-gather at WORLD 8 on gloo -- configs[1] (8 x 1024), configs[3]
+    (65 536 = 8 x 8192) and configs[4] (8192 vehicles = 8 x 1024): the eight shards are contiguous, equal and tile the global batch."""
+    import sys
+    for wl, total in (("cfg2", 8 * 1024), ("cfg4", 65536), ("cfg5", 8192)):
+        out = _bench_line([sys.executable, "bench.py", "--gpus", "8", "--dry-run", "--workload", wl])
+        c = out["config"]
+        assert out["n_gpus"] == 8 and out["dry_run"] is True and c["rccl_world"] == 8 and c["gather_ok"] is True
+        assert c["global_instances"] == total
+        assert c["shards"] == [[r * total // 8, (r + 1) * total // 8] for r in range(8)]
+        assert c["max_elapsed_s"] == pytest.approx(8e-3)          # MAX over the eight ranks
+
+
+def test_shard_range_tiles_every_batch_size_over_eight_ranks():
+    """lpvmpc.distributed.shard_range at world 8 for ragged totals: contiguous, ordered, sizes differ by at most one, nothing lost."""
+    from lpvmpc.distributed import shard_range
+    for total in (0, 1, 7, 8, 9, 1000, 8191, 8192, 65535, 65536):
+        cuts = [shard_range(total, r, 8) for r in range(8)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == total
+        assert all(cuts[r][1] == cuts[r + 1][0] for r in range(7))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1 and sum(sizes) == total
+
+
 @pytest.mark.timeout(300)
 def test_bench_strong_scaling_cuts_the_steps_over_the_ranks():
     """--scaling strong: ONE sequence of steps is split contiguously over the ranks (the line says so); the default stays weak."""
