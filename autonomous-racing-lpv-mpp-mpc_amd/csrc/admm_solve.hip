@@ -2000,7 +2000,7 @@ struct Solver {
     //   stop (any status)  -> the arrays still hold iteration k: the solve ends there, iteration count k,
     //   new rho            -> back to the snapshot: registers from the arrays, re-factorisation, on from iteration k + 1.
     // Every result is what the check-then-iterate order gives; only the clock differs.
-    static constexpr int CK_IDLE = 0, CK_YD = 1, CK_YDX = 17, CK_AX = 2, CK_PX = 3, CK_AT = 4, CK_RES = 5, CK_RR0 = 6, CK_RR1 = 7, CK_DEC = 8,
+    static constexpr int CK_IDLE = 0, CK_YD = 1, CK_YDX = 17, CK_RESD = 18, CK_AX = 2, CK_PX = 3, CK_AT = 4, CK_RES = 5, CK_RR0 = 6, CK_RR1 = 7, CK_DEC = 8,
                          CK_PI1 = 9, CK_PI2 = 10, CK_PI3 = 11, CK_DI0 = 12, CK_DI1 = 13, CK_DI2 = 14, CK_DI3 = 15, CK_FIN = 16;
     __device__ __forceinline__ static bool uni(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
     __device__ __forceinline__ static double unid(double v) {
@@ -2059,9 +2059,10 @@ struct Solver {
             STAMP4(4);
             double sblk[3];
             auto blockdot = [&](const double *tt, const double2 *uu) {      // (the row of T lives in the registers dm[kTR ..]: down, diagonal, up block)
-                const double p0 = (tt[0] * uu[0].x + tt[1] * uu[0].y) + (tt[2] * uu[1].x + tt[3] * uu[1].y);
-                const double p1 = (tt[4] * uu[2].x + tt[5] * uu[2].y) + (tt[6] * uu[3].x + tt[7] * uu[3].y);
-                return p0 + p1;
+                double p = tt[0] * uu[0].x;        // one chain of fused multiply-adds per block (three independent chains in flight)
+                p = fma(tt[1], uu[0].y, p); p = fma(tt[2], uu[1].x, p); p = fma(tt[3], uu[1].y, p);
+                p = fma(tt[4], uu[2].x, p); p = fma(tt[5], uu[2].y, p); p = fma(tt[6], uu[3].x, p); p = fma(tt[7], uu[3].y, p);
+                return p;
             };
             sblk[0] = blockdot(dm + kTR, ua);
 #pragma unroll
@@ -2231,28 +2232,30 @@ struct Solver {
             if (act) CK[24 * NS + e] = av;
             ck_next_round(CK_RES);
         } else if (cs == CK_RES) {
-            // the element loop of residuals(), maxima per lane
-            const double eid = CK[40 * NS + 512 + e], eib = CK[48 * NS + 512 + e], di = CK[56 * NS + 512 + e];      // 1 / Ed, 1 / Eb, 1 / D (dense_build)
-            const double axd = CK[e], axb = CK[8 * NS + e], px = CK[16 * NS + e], aty = CK[24 * NS + e];
-            const double zd = Zd[e], zb = Zb[e], q = Qv[e];
+            // the element loop of residuals(), maxima per lane: the four primal norms ...
+            const double eid = CK[40 * NS + 512 + e], eib = CK[48 * NS + 512 + e];      // 1 / Ed, 1 / Eb (dense_build)
+            const double axd = CK[e], axb = CK[8 * NS + e];
+            const double zd = Zd[e], zb = Zb[e];
             const double rd = axd - zd, rb = axb - zb;
-            double m_[8];
-            m_[4] = fmax(fabs(rd), fabs(rb));
-            m_[0] = fmax(fabs(eid * rd), fabs(eib * rb));
-            m_[6] = fmax(fmax(fabs(axd), fabs(axb)), fmax(fabs(zd), fabs(zb)));
-            m_[2] = fmax(fmax(fabs(eid * axd), fabs(eib * axb)), fmax(fabs(eid * zd), fabs(eib * zb)));
+            ck_max_acc(4, ln, act ? fmax(fabs(rd), fabs(rb)) : 0.0);
+            ck_max_acc(0, ln, act ? fmax(fabs(eid * rd), fabs(eib * rb)) : 0.0);
+            ck_max_acc(6, ln, act ? fmax(fmax(fabs(axd), fabs(axb)), fmax(fabs(zd), fabs(zb))) : 0.0);
+            ck_max_acc(2, ln, act ? fmax(fmax(fabs(eid * axd), fabs(eib * axb)), fmax(fabs(eid * zd), fabs(eib * zb))) : 0.0);
+            ck_next_round(CK_RESD);
+        } else if (cs == CK_RESD) {
+            // ... and the four dual ones
+            const double di = CK[56 * NS + 512 + e], px = CK[16 * NS + e], aty = CK[24 * NS + e], q = Qv[e];
             const double dr = q + px + aty;
-            m_[5] = fabs(dr); m_[1] = fabs(di * dr);
-            m_[7] = fmax(fmax(fabs(px), fabs(aty)), fabs(q));
-            m_[3] = fmax(fmax(fabs(di * px), fabs(di * aty)), fabs(di * q));
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ck_max_acc(i, ln, act ? m_[i] : 0.0);
+            ck_max_acc(5, ln, act ? fabs(dr) : 0.0);
+            ck_max_acc(1, ln, act ? fabs(di * dr) : 0.0);
+            ck_max_acc(7, ln, act ? fmax(fmax(fabs(px), fabs(aty)), fabs(q)) : 0.0);
+            ck_max_acc(3, ln, act ? fmax(fmax(fabs(di * px), fabs(di * aty)), fabs(di * q)) : 0.0);
             ck_next_round(CK_RR0);
-        } else if (cs == CK_RR0 || cs == CK_RR1) {
-            const int i0 = cs == CK_RR0 ? 0 : 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { const double v = wave_max(CK[32 * NS + (i0 + i) * 64 + ln]); if (ln == 0) RT[64 + i0 + i] = v; }
-            cs = cs == CK_RR0 ? CK_RR1 : CK_DEC;
+        } else if (cs == CK_RR0) {
+            // the eight cross-lane maxima, two per step (cr = 0 .. 3)
+            const double v0 = wave_max(CK[32 * NS + (2 * cr) * 64 + ln]), v1 = wave_max(CK[32 * NS + (2 * cr + 1) * 64 + ln]);
+            if (ln == 0) { RT[64 + 2 * cr] = v0; RT[64 + 2 * cr + 1] = v1; }
+            if (cr == 3) { cr = 0; cs = CK_DEC; } else ++cr;
         } else if (cs == CK_DEC) {
             const double pri = unid(RT[64]), dua = cinv * unid(RT[65]), nAxz = unid(RT[66]), nPAq = cinv * unid(RT[67]);
             int fl = 0, nxt = CK_FIN;
