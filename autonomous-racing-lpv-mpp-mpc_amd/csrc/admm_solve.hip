@@ -2442,6 +2442,10 @@ struct Solver {
         const int n = (int)image_doubles(N);
         const double *src = a.pool_in + (size_t)entry * a.pool_stride;
         for (int i = tid; i < n; i += kStride) tA[i] = src[i];
+        // the MFMA sweeps read their zeros from SINK: an image parked by a kernel that uses the area otherwise (the DPP two-wavefront
+        // factorisation hands a tile through it) must not bring its contents along -- lpvmpc_set_option joins parked work before a
+        // kernel_variant change, this makes the kernel itself safe
+        if constexpr (kMf) { sync(); for (int i = tid; i < 64 + 8 * NS; i += kStride) SINK[i] = 0.0; }
         const double *sc = src + n;
         if constexpr (TAIL) {       // (uniform values: scalar registers -- the tail kernel's vector registers hold K^-1)
             c = unid(sc[0]); cinv = unid(sc[1]);

@@ -145,12 +145,21 @@ int lpvmpc_last_error_code(void);
  * are not parked (they finish inside the launch that holds them).
  * "defer_tail" (0 | 1, default 1): the passes that run parked instances to completion (lpvmpc_join, the synchronous entry
  * points, "defer_budget" 0) use the whole-CU tail kernel where one exists for the handle (controller or planner, N = 20): a 512-thread
- * workgroup per instance that applies K^-1 as a dense matrix held in registers, 1.65x faster per iteration for an instance that
- * has the GPU to itself.  Statuses, iteration counts and polish flags have been OBSERVED equal to the other kernel's on every
- * instance compared so far (196 608 over four tracks; the seeds of tests/test_gpu_deferral.py are regression fixtures for this
- * build) -- an observation, not a guarantee: the two kernels round differently, and a termination test that is decided by
- * round-off can move by one check (25 iterations) on another toolchain or device.  Solutions agree to round-off (1e-7 polished,
- * 1e-6 for an un-polished iterate; observed 1.4e-8 / 7e-10), so bit-identity with the plain call holds with 0 only. */
+ * workgroup per instance that applies K^-1 as a dense matrix held in registers, runs two phases per ADMM iteration and evaluates the
+ * termination checks beside the iterations (round 5: 1.08 us per iteration against 2.1 us for an instance that has the GPU to
+ * itself).  Handles with steering_delay > 0 keep the two-wavefront kernel for these passes.  Statuses, iteration counts and polish
+ * flags have been OBSERVED equal to the other kernel's on every instance compared so far (196 608 over four tracks,
+ * profiles/r05_tail_parity_sweep.txt; the seeds of tests/test_gpu_deferral.py are regression fixtures for this build) -- an
+ * observation, not a guarantee: the two kernels round differently, and a termination test that is decided by round-off can move by
+ * one check (25 iterations) on another toolchain or device.  Solutions agree to round-off (1e-7 polished, 1e-6 for an un-polished
+ * iterate; observed 3.1e-9 / 1.1e-7), so bit-identity with the plain call holds with 0 only.
+ *
+ * FLOAT TOLERANCE of the QP stage against the reference algorithm (the CPU oracle on identical data; tests/_tolerance.py,
+ * DESIGN.md section 2): status and iteration count equal -- except a run that ends at max_iter, where OSQP's 10 eps "solved
+ * inaccurate" test is decided by round-off (MAX_ITER_REACHED <-> SOLVED_INACCURATE, same iteration count) -- and xPred / uPred in one of
+ * three classes: (A) polished: 1e-6; (B) un-polished, converged: 2e-4 (observed <= 1e-6); (C) ran to the max_iter cap (an unconverged
+ * ADMM iterate, which OSQP guarantees nothing for and the reference uses as it comes): same iteration count, |du| <= 5e-2 (observed
+ * <= 1.01e-2 on 42 of 110 202 instances, all of them planner QPs at 4000 iterations). */
 int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value);
 /* Straggler deferral (see "defer_after"): enqueues on `stream` (a hipStream_t; ordered behind the stream of the handle's last
  * deferred call if it is another one) the resume pass that runs every parked instance to completion.  No-op without deferral. */
