@@ -52,6 +52,10 @@ struct Solver {
     // LDS-tile code of the run-time-horizon kernel.  It only ever resumes pool entries: its LDS begins with the image of the
     // kernel that parked them (the compile-time-horizon layout).
     static constexpr bool kTail = TAIL;
+#ifndef LPVMPC_UNI_SCALARS
+#define LPVMPC_UNI_SCALARS 1
+#endif
+    static constexpr bool kUniScalars = TAIL || (LPVMPC_UNI_SCALARS != 0);   // c, rho and their kin are the same in every lane: keep them in scalar registers
     static constexpr bool kFixN = (NT > 0);         // horizon known at compile time
     static constexpr bool kReg = kFixN && !TAIL;    // factor tiles in registers
     static constexpr bool kTwo = (NW == 2);         // two wavefronts per instance: two-sided ("twisted") elimination
@@ -281,7 +285,7 @@ struct Solver {
     }
     __device__ __forceinline__ void set_rho(double r) {
         rho = r; rho_eq = kRhoEqOverIneq * r; rinv = 1.0 / rho; rinv_eq = 1.0 / rho_eq;
-        if constexpr (TAIL) { rho = unid(rho); rho_eq = unid(rho_eq); rinv = unid(rinv); rinv_eq = unid(rinv_eq); }
+        if constexpr (kUniScalars) { rho = unid(rho); rho_eq = unid(rho_eq); rinv = unid(rinv); rinv_eq = unid(rinv_eq); }
     }
     // weight of a box row / dynamics row in K = P + sig I + A' diag(W) A
     __device__ __forceinline__ double w_box(int e) const { return pol ? fabs(DYb[e]) : rho_of(Lo[e], Hi[e], rho); }
@@ -554,6 +558,7 @@ struct Solver {
             sync();
         }
         cinv = 1.0 / c;
+        if constexpr (kUniScalars) { c = unid(c); cinv = unid(cinv); }
         // A <- E A D on the stored [A|B] tiles, four stages per trip (all loads before the stores)
         for (int k0 = 4 * wv; k0 < N; k0 += 4 * NW) {
             double v[4];
@@ -1962,7 +1967,9 @@ struct Solver {
             if constexpr (SET != 1) { const int e = elem_set2(t0); if (e < NS * 8) element(e, true, wbx[1], wbxi[1]); }
             if constexpr (SET != 0) return;
         } else if constexpr (kCacheW) {
-            const int t0 = opaque(tid);
+            // (round 5: with the uniform scalars in SGPRs and the post-loop addresses laundered, the two-wavefront MFMA kernels have the
+            // registers to let this loop's addresses be hoisted: -24 instructions per iteration in the headline kernel)
+            const int t0 = (kUniScalars && kMf && kTwo) ? tid : opaque(tid);
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
                 const int e = t0 + r * kStride;
@@ -2447,7 +2454,7 @@ struct Solver {
         // kernel_variant change, this makes the kernel itself safe
         if constexpr (kMf) { sync(); for (int i = tid; i < 64 + 8 * NS; i += kStride) SINK[i] = 0.0; }
         const double *sc = src + n;
-        if constexpr (TAIL) {       // (uniform values: scalar registers -- the tail kernel's vector registers hold K^-1)
+        if constexpr (kUniScalars) {       // (uniform values: scalar registers -- the tail kernel's vector registers hold K^-1)
             c = unid(sc[0]); cinv = unid(sc[1]);
             set_rho(unid(sc[2]));
         } else {
@@ -2645,6 +2652,7 @@ struct Solver {
                 if (checked && defer_after > 0 && iter >= defer_after && iter < max_iter && try_park(a, entry, inst, iter, to_chk, to_adp)) return;
             }
         }
+        if constexpr (kUniScalars && !TAIL) launder_ids();      // (the post-loop code's addresses are formed behind the loop: see launder_ids)
         if (iter > max_iter) iter = max_iter;
         if (!checked) {
             R = residuals(X, Zd, Zb, Yd, Yb); pri_res = R.pri; dua_res = R.dua;
@@ -2910,8 +2918,10 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
     // the reference runs delay 0 (CMAIN:49); such handles finish their parked instances with the two-wavefront kernel)
     if (a.resume && a.tail && a.defer_after == 0 && !generic && cfg.N == 20 && cfg.steering_delay == 0)
         return cfg.kind == 0 ? launch_one<6, 20, 8, false, false, true>(cfg, dcfg, a, stream) : launch_one<5, 20, 8, false, false, true>(cfg, dcfg, a, stream);
-#ifdef LPVMPC_DEV_TAIL_ONLY
+#if defined(LPVMPC_DEV_TAIL_ONLY)
     return hipErrorInvalidValue;       // development builds (seconds instead of minutes): the tail kernels only, for looking at their assembly
+#elif defined(LPVMPC_DEV_MAIN_ONLY)
+    return launch_one<6, 20, 2, true>(cfg, dcfg, a, stream);      // ... or the headline kernel only
 #else
     if (cfg.kind == 0) {
         if (!generic && cfg.N == 20) return one_wave ? launch_one<6, 20, 1>(cfg, dcfg, a, stream)

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 from lpvmpc import workloads
 dev = torch.device("cuda", 0)
+EPS_INF = float(os.environ.get("EPS_INF", "1e-30"))     # 1e-30: every infeasibility stage of a check runs (the longest path); 1e30: the shortest
 w = workloads.controller_batch(8, N=20, seed=0)
 t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a[:1])).to(dev)
 ins = dict(x0=t(w["x0"]), u_prev=t(w["u_prev"]), vel=t(w["vel_ref"]), curv=t(w["curv_s"]), u_old=t(w["u_old"]))
@@ -17,7 +18,7 @@ o = dict(xPred=torch.empty((1, 21, 6), dtype=torch.float64, device=dev), uPred=t
 
 
 def run(mi, chk, tail, **kw):
-    e = workloads.make_solver(w, max_iter=mi, adaptive_rho=0, polish=0, check_termination=chk, eps_abs=1e-30, eps_rel=1e-30, eps_prim_inf=1e-30, eps_dual_inf=1e-30, **kw)
+    e = workloads.make_solver(w, max_iter=mi, adaptive_rho=0, polish=0, check_termination=chk, eps_abs=1e-30, eps_rel=1e-30, eps_prim_inf=EPS_INF, eps_dual_inf=EPS_INF, **kw)
     e.reserve(1); e.set_option("defer_after", 100); e.set_option("defer_budget", 0); e.set_option("defer_tail", tail)
     best = 1e9
     for _ in range(5):
