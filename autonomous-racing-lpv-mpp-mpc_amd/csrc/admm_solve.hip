@@ -157,7 +157,7 @@ struct Solver {
     // off-chain termination check (checker_tick): state of wavefront NW-1's coroutine -- wave-uniform, scalar registers
     int cs, cr, ckn, ckk;
     bool ckc, cka;
-    double ck_alpha;
+    double ck_alpha, ck_eps_abs, ck_eps_rel, ck_eps_p, ck_eps_d, ck_rho_tol;      // the settings the checker reads, fetched once (the configuration block is in global memory)
     double c, cinv;
     // row weights: ADMM rho classes (OSQP set_rho_vec) or, while polishing, |flag| = 1/delta on active rows
     bool pol;
@@ -233,7 +233,7 @@ struct Solver {
         Lo = p; p += V; Hi = p; p += V;
         beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; RED = p; p += kRedSize; SINK = p; p += 64 + 8 * NS;
         RT = WS = STG = TT = CK = nullptr;
-        cs = cr = ckn = ckk = 0; ckc = cka = false; ck_alpha = 0.0;
+        cs = cr = ckn = ckk = 0; ckc = cka = false; ck_alpha = ck_eps_abs = ck_eps_rel = ck_eps_p = ck_eps_d = ck_rho_tol = 0.0;
         if constexpr (TAIL) {   // behind the image: factor tiles, reduction slots, sweep scratch, staging
             tS = p; p += NS * kTS; tL = p; p += NS * kTS; RT = p; p += 96; WS = p; p += NW * 128; STG = p; p += kDenseRound * NS * 64;
             TT = STG; CK = STG + NS * 8 * 24;
@@ -1070,6 +1070,9 @@ struct Solver {
         }
         // the reciprocals of the equilibration vectors that the checker's residual evaluation needs (as residuals() forms them)
         for (int i = tid; i < NS * 8; i += kStride) { CK[40 * NS + 512 + i] = 1.0 / Ed[i]; CK[48 * NS + 512 + i] = 1.0 / Eb[i]; CK[56 * NS + 512 + i] = 1.0 / D[i]; }
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS == 4
+        if (tid < 40) CK[64 * NS + 512 + tid] = 0.0;
+#endif
         sync();
     }
     // XT <- K^-1 VT (the KKT solve of an ADMM iteration in the tail kernel; the caller places the barrier)
@@ -1394,6 +1397,9 @@ struct Solver {
     // steps: only this wavefront reads them) and updates them (after its backward steps: x~ and [A|B] x~ of these stages are its own).
     template <bool BOT, bool ELEM>
     __device__ __forceinline__ void outer4(const MfLane &m, double sigma, double alpha, bool want_delta) {
+        // (tools/check_kernel_resources.py counts the s_barrier instructions between the ROLE markers of a group: the four role paths of
+        // relay4 sit in wavefront-divergent control flow and must pass the same number of workgroup barriers)
+        asm volatile("; LPVMPC_ROLE_BEGIN relay4");
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         auto typeB = [](int p) constexpr { return (((P - 1 - p) & 1) == 0) != kFlip; };
@@ -1487,9 +1493,11 @@ struct Solver {
         }
         sync();             // B4
         STAMP(4);
+        asm volatile("; LPVMPC_ROLE_END relay4");
     }
     template <bool BOT, bool ELEM>
     __device__ __forceinline__ void inner4(const MfLane &m, double sigma, double alpha, bool want_delta) {
+        asm volatile("; LPVMPC_ROLE_BEGIN relay4");
         constexpr int P = kMid, J0 = kHO;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         auto typeB = [](int p) constexpr { return (((P - 1 - p) & 1) == 0) != kFlip; };
@@ -1596,6 +1604,7 @@ struct Solver {
         STAMP(6);           // update set 2
         sync();             // B4
         STAMP(7);           // waiting at B4
+        asm volatile("; LPVMPC_ROLE_END relay4");
     }
     // the four parts of one KKT solve of the four-wavefront kernel (the right-hand side is complete in XT, a barrier behind it)
     template <bool ELEM>
@@ -2158,13 +2167,24 @@ struct Solver {
                 // (the markers of tools/check_kernel_resources.py bracket the element side's trip; the checker's side is off the chain)
                 if constexpr (!CHK) asm volatile("; LPVMPC_HOT_BEGIN");
                 if constexpr (CHK) {
+                    asm volatile("; LPVMPC_ROLE_BEGIN tail_trip x2");      // (this side's loop body runs twice per trip)
 #pragma unroll 1
                     for (int sl = 0; sl < 2; ++sl) {
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS == 4
+                        const int st0_ = cs;
+                        const unsigned long long tk0_ = __builtin_amdgcn_s_memtime();
                         checker_tick(sl == 0);
+                        asm volatile("s_waitcnt lgkmcnt(0)");
+                        if (st0_ != CK_IDLE && lane == 0) { CK[64 * NS + 512 + 2 * st0_] += (double)(__builtin_amdgcn_s_memtime() - tk0_); CK[64 * NS + 512 + 2 * st0_ + 1] += 1.0; }
+#else
+                        checker_tick(sl == 0);
+#endif
                         sync();
                         if (sl == 0) vk = __builtin_amdgcn_readfirstlane((int)RT[83]);
                     }
+                    asm volatile("; LPVMPC_ROLE_END tail_trip");
                 } else {
+                    asm volatile("; LPVMPC_ROLE_BEGIN tail_trip");
                     if (work) dense_apply();
                     sync();
                     STAMP(0);
@@ -2173,6 +2193,7 @@ struct Solver {
                     vk = __builtin_amdgcn_readfirstlane((int)vkd);
                     sync();
                     STAMP(1);
+                    asm volatile("; LPVMPC_ROLE_END tail_trip");
                 }
                 if constexpr (!CHK) asm volatile("; LPVMPC_HOT_END");
                 if (work) ++n_acc;
@@ -2207,7 +2228,7 @@ struct Solver {
         const bool act = e_ < NS * 8;
         const int e = act ? e_ : NS * 8 - 1;             // (clamped: valid addresses, results masked)
         const int k = e >> 3;
-        const double eps_p = cfg.eps_prim_inf, eps_d = cfg.eps_dual_inf;
+        const double eps_p = ck_eps_p, eps_d = ck_eps_d;
         if (cs == CK_YD) {
             // y_d at the snapshot from the sum of x~ since the snapshot before (ZTb): y_d += rho_eq alpha (A_d S - n b)
             const LaneC lc = lane_consts();
@@ -2267,7 +2288,7 @@ struct Solver {
             const double pri = unid(RT[64]), dua = cinv * unid(RT[65]), nAxz = unid(RT[66]), nPAq = cinv * unid(RT[67]);
             int fl = 0, nxt = CK_FIN;
             if (ckc && !(pri > kInfty || dua > kInfty)) {
-                const bool prc = pri < cfg.eps_abs + cfg.eps_rel * nAxz, drc = dua < cfg.eps_abs + cfg.eps_rel * nPAq;
+                const bool prc = pri < ck_eps_abs + ck_eps_rel * nAxz, drc = dua < ck_eps_abs + ck_eps_rel * nPAq;
                 fl = (prc ? 1 : 0) | (drc ? 2 : 0);
                 nxt = !prc ? CK_PI1 : (!drc ? CK_DI1 : CK_FIN);
             }
@@ -2369,7 +2390,7 @@ struct Solver {
             if (st != LPVMPC_UNSOLVED_) code = 2;
             else if (cka) {
                 rn = rho_estimate(r, rho);
-                if (rn > rho * cfg.rho_tol || rn < rho / cfg.rho_tol) code = 3;
+                if (rn > rho * ck_rho_tol || rn < rho / ck_rho_tol) code = 3;
             }
             if (ln == 0) {
                 RT[80] = (double)code; RT[81] = (double)st; RT[82] = rn;
@@ -2587,7 +2608,7 @@ struct Solver {
             // the factorisation (which exists once in the kernel, above this loop's entry).
             TailCtl t;
             t.iter = iter0 - 1; t.to_chk = to_chk; t.to_adp = to_adp; t.status = LPVMPC_UNSOLVED_; t.rn = rho;
-            ck_alpha = alpha;
+            ck_alpha = alpha; ck_eps_abs = unid(cfg.eps_abs); ck_eps_rel = unid(cfg.eps_rel); ck_eps_p = unid(cfg.eps_prim_inf); ck_eps_d = unid(cfg.eps_dual_inf); ck_rho_tol = unid(cfg.rho_tol);
             const int role = __builtin_amdgcn_readfirstlane(wv);
             for (;;) {
                 if (tid == 0) RT[83] = -1.0;
@@ -2699,7 +2720,10 @@ struct Solver {
             if (tid == 128) for (int i = 0; i < 8; ++i) o_.xPred[(size_t)inst * NS * NX + 8 + i] = (double)stamp[i] / iter;
         }
 #if LPVMPC_STAMPS == 4
-        if constexpr (TAIL) { if (tid == 0) for (int i = 0; i < 8; ++i) o_.xPred[(size_t)inst * NS * NX + i] = (double)stamp[i] / iter; }
+        if constexpr (TAIL) {
+            if (tid == 0) for (int i = 0; i < 8; ++i) o_.xPred[(size_t)inst * NS * NX + i] = (double)stamp[i] / iter;
+            if (tid == 0) for (int i = 0; i < 40; ++i) o_.xPred[(size_t)inst * NS * NX + 8 + i] = CK[64 * NS + 512 + i];      // checker: cycles and steps per state
+        }
 #endif
         if (tid == 0 && o_.resid) {     // diagnostic build: resid carries per-iteration cycle counts instead
             double *o = o_.resid + (size_t)inst * 4;

@@ -146,3 +146,28 @@ def test_device_assembly_has_no_copy_in_front_of_an_exec_restore(ffi):
         assert len(chk.scan(bad)) == 1
     finally:
         os.remove(bad)
+
+
+def test_role_divergent_barrier_counts_are_checked(tmp_path):
+    """tools/check_kernel_resources.py: the role paths of a kernel (relay4's four parts of a KKT solve, the two sides of the tail kernel's
+    loop) sit in wavefront-divergent control flow with the workgroup's barriers inside; the build fails unless every path of a group
+    passes the same number of s_barrier instructions (xN on a BEGIN marker: a loop body that runs N times per pass)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_kernel_resources as ckr
+    good = tmp_path / "good.s"
+    good.write_text("_Zk:\n\t; LPVMPC_ROLE_BEGIN trip x2\n\tv_mov_b32_e32 v1, v2\n\ts_barrier\n\t; LPVMPC_ROLE_END trip\n"
+                    "\t; LPVMPC_ROLE_BEGIN trip\n\ts_barrier\n\tv_mov_b32_e32 v1, v2\n\ts_barrier\n\t; LPVMPC_ROLE_END trip\n.Lfunc_end0:\n")
+    assert ckr.role_barriers(str(good)) == {"_Zk": {"trip": [2, 2]}}
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Zk:\n\t; LPVMPC_ROLE_BEGIN relay\n\ts_barrier\n\ts_barrier\n\t; LPVMPC_ROLE_END relay\n"
+                   "\t; LPVMPC_ROLE_BEGIN relay\n\ts_barrier\n\t; LPVMPC_ROLE_END relay\n.Lfunc_end0:\n")
+    assert ckr.role_barriers(str(bad)) == {"_Zk": {"relay": [2, 1]}}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_kernel_resources.py"), str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "ROLES" in r.stdout
+    # the kept assembly of the build: every group of every kernel balanced
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "autonomous-racing-lpv-mpp-mpc_amd", "csrc", "build", "admm_solve-*-gfx950.s")):
+        for kname, groups in ckr.role_barriers(f).items():
+            for grp, counts in groups.items():
+                assert len(set(counts)) == 1 and counts[0] > 0, (kname, grp, counts)

@@ -46,6 +46,35 @@ def hot_path(path):
     return out
 
 
+def role_barriers(path):
+    """Per kernel and role group: the s_barrier instructions between each `; LPVMPC_ROLE_BEGIN <group> [xN]` / `; LPVMPC_ROLE_END <group>` pair
+    (text order; xN: the region is a loop body that runs N times per pass).  Role paths are pieces of one kernel that different wavefronts
+    of a workgroup execute INSTEAD of each other (relay4's four parts of a KKT solve; the two sides of the tail kernel's loop), each with
+    the workgroup's barriers inside: that is outside HIP's convergence rules and works because s_barrier counts wavefronts -- as long as
+    every path passes the same number.  Returns {kernel: {group: [count, ...]}}."""
+    out, name, open_ = {}, None, {}
+    for ln in open(path):
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            name, open_ = m.group(1), {}
+            continue
+        if name is None:
+            continue
+        m = re.search(r"LPVMPC_ROLE_(BEGIN|END)\s+(\w+)(?:\s+x(\d+))?", ln)
+        if m:
+            grp = m.group(2)
+            if m.group(1) == "BEGIN":
+                open_[grp] = [0, int(m.group(3) or 1)]
+            elif grp in open_:
+                cnt, mul = open_.pop(grp)
+                out.setdefault(name, {}).setdefault(grp, []).append(cnt * mul)
+            continue
+        if ln.startswith("\t") and ln.split() and ln.split()[0] == "s_barrier":
+            for v in open_.values():
+                v[0] += 1
+    return out
+
+
 def kernels(path):
     out, cur = [], None
     for ln in open(path):
@@ -104,4 +133,12 @@ if __name__ == "__main__":
             print("      per-iteration code (between the markers): %d instructions, %d scratch loads, %d scratch stores, %d SGPR-spill lane moves%s"
                   % (h["instructions"], loads, h["scratch_stores"], h["spill_lane_moves"], "  <-- FAIL" if hflag else ""))
             bad += hflag
+    # role-divergent barriers: every path of a group must pass the same number (see role_barriers)
+    for kname, groups in sorted(role_barriers(path).items()):
+        if pats and not any(p in kname for p in pats):
+            continue
+        for grp, counts in sorted(groups.items()):
+            ok = len(set(counts)) == 1 and counts[0] > 0
+            print("%s %-70s role group %-10s barriers per path %s%s" % ("ok   " if ok else "ROLES", kname[:70], grp, counts, "" if ok else "  <-- FAIL: the role paths pass different numbers of workgroup barriers"))
+            bad += not ok
     sys.exit(1 if bad else 0)

@@ -31,4 +31,8 @@ for B in (1, 64):
     if os.environ.get("STAMPS4"):
         x = o["xPred"].cpu().numpy().reshape(B, -1)[:, :8]
         print("   STAMPS=4 (wavefront 0; cycles per iteration): barrier after dense %.0f | barrier after fused %.0f | dense: loads arrived %.0f, products + stores %.0f | fused: first loads arrived %.0f, compute + store %.0f" % tuple(np.median(x, axis=0)[:6]))
+    if os.environ.get("STAMPS4"):
+        x = o["xPred"].cpu().numpy().reshape(B, -1)[0, 8:48].reshape(20, 2)
+        names = {1: "YD", 17: "YDX", 2: "AX", 3: "PX", 4: "AT", 5: "RES", 18: "RESD", 6: "RR", 8: "DEC", 9: "PI1", 10: "PI2", 11: "PI3", 12: "DI0", 13: "DI1", 14: "DI2", 15: "DI3", 16: "FIN"}
+        print("   checker steps (cycles per step, steps): " + ", ".join("%s %.0f (%d)" % (names.get(i, str(i)), x[i, 0] / max(x[i, 1], 1), x[i, 1]) for i in range(20) if x[i, 1] > 0))
     eng.close()
