@@ -337,6 +337,32 @@ def test_tail_kernel_for_the_planner_at_n20():
     eng.close()
 
 
+@pytest.mark.parametrize("settings", [dict(check_termination=5), dict(check_termination=10, adaptive_rho_interval=50),
+                                      dict(check_termination=25, max_iter=1010), dict(check_termination=7, max_iter=333, adaptive_rho_interval=21),
+                                      dict(check_termination=25, adaptive_rho=0), dict(check_termination=100, adaptive_rho_interval=100)])
+def test_tail_kernel_off_chain_checks_under_other_schedules(settings):
+    """The tail kernel evaluates a termination check BESIDE the iterations (round 5): snapshot at the check iteration, verdict some
+    iterations later, roll-back on a rho change.  Schedules other than OSQP's defaults stress that machinery: a check interval shorter
+    than a check's flight (every pending verdict is then waited for before the next snapshot), rho updates that are not on every check,
+    a max_iter that is not a check iteration (the closing evaluation), no rho adaptation at all.  Against the plain launch of the same
+    settings: every status, iteration count and polish flag equal; solutions to the tail path's tolerance."""
+    import torch
+    from lpvmpc import workloads
+    B = 1024
+    w = workloads.controller_batch(B, N=20, seed=16)
+    plain = workloads.make_solver(w, **settings); plain.reserve(B)
+    _, o = _dev_call(torch, plain, w, B, False); torch.cuda.synchronize(); ref = _host(o); plain.close()
+    park = min(5 * settings["check_termination"], 200)
+    assert np.sum(ref["iters"] > park) >= 3
+    eng = workloads.make_solver(w, **settings); eng.reserve(B)
+    eng.set_option("defer_after", park); eng.set_option("defer_budget", -1); eng.set_option("defer_pool", 1024)
+    _, o = _dev_call(torch, eng, w, B, False)
+    eng.join(0); torch.cuda.synchronize()
+    got = _host(o)
+    _close_to(got, ref, tol_polished=1e-7, tol_iterate=1e-6)
+    eng.close()
+
+
 def test_tail_parity_sweep_slice():
     """A slice of tests/diagnostics/tail_sweep.py inside the suite (four tracks x two seeds x lap 1 / lap 0 x 2048 controller
     instances = 32 768): the deferred call finished by the whole-CU tail kernel against the plain launch of the same batch --
