@@ -1077,7 +1077,7 @@ struct Solver {
     }
     // XT <- K^-1 VT (the KKT solve of an ADMM iteration in the tail kernel; the caller places the barrier)
     __device__ __forceinline__ void dense_apply() {
-        const int t0 = opaque(tid), s_ = t0 & 7;
+        const int t0 = tid, s_ = t0 & 7;
         if (t0 < 64 * (NW - 1)) {
             // The right-hand side slice of this thread's column slot (kDC values, 16-byte loads) in three batches: the first two are
             // issued up front, the third behind the first batch's products -- all of it in flight at once would be 2 kDC registers on
@@ -2061,7 +2061,7 @@ struct Solver {
     }
     // the fused element phase: x+, G+, the variable's box rows, the next right-hand side; want: also file the snapshot and the deltas
     __device__ __forceinline__ void tail_fused(double sigma, double alpha, bool want) {
-        const int e = opaque(tid);
+        const int e = tid;
         if (e < NS * 8) {
             const int k = e >> 3, km = k > 0 ? k - 1 : 0, kp = k < N ? k + 1 : N;
             const double2 *xa = reinterpret_cast<const double2 *>(XT + km * 8), *xb = reinterpret_cast<const double2 *>(XT + k * 8),
