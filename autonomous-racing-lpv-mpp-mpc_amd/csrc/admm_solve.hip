@@ -1136,10 +1136,14 @@ struct Solver {
                 red_j2(a_[0], a_[1]); red_j2(a_[2], a_[3]);
                 const int g = (t0 - 64 * kActW) >> 3, r = kRowsA + 4 * g;
                 if (s_ == 0 && g < kGroupsB) {
-                    XT[r] = a_[0];
-                    if (r + 1 < NS * 8) XT[r + 1] = a_[1];
-                    if (r + 2 < NS * 8) XT[r + 2] = a_[2];
-                    if (r + 3 < NS * 8) XT[r + 3] = a_[3];
+                    if constexpr (kRowsA + 4 * kGroupsB == (NT + 1) * 8) {      // (the heavy groups' rows end exactly at the last row: no guards)
+                        XT[r] = a_[0]; XT[r + 1] = a_[1]; XT[r + 2] = a_[2]; XT[r + 3] = a_[3];
+                    } else {
+                        XT[r] = a_[0];
+                        if (r + 1 < NS * 8) XT[r + 1] = a_[1];
+                        if (r + 2 < NS * 8) XT[r + 2] = a_[2];
+                        if (r + 3 < NS * 8) XT[r + 3] = a_[3];
+                    }
                 }
             }
         }
