@@ -1256,7 +1256,7 @@ struct Solver {
     };
     __device__ __forceinline__ MfLane mf_lane() const {
         MfLane m;
-        m.ln = opaque(lane);
+        m.ln = lane;           // (round 5: not opaque any more: the sweeps' LDS addresses may be hoisted out of the ADMM loop now that the kernels have the registers -- see launder_ids; -9 % instructions per iteration)
         const int r = m.ln >> 4, b = (m.ln >> 2) & 3;
         m.eA = 4 * (b >> 1) + r; m.eB = 4 * (b & 1) + r;
         m.stA = (b & 1) == 0; m.stB = b < 2;
@@ -1915,7 +1915,8 @@ struct Solver {
     template <int SET>
     __device__ __forceinline__ void build_rhs_set(double sigma) {
         const LaneC lc = lane_consts();
-        const int t0 = opaque(tid);
+        const int t0 = tid;        // (round 5: not opaque any more -- with the uniform scalars in SGPRs and the post-loop addresses laundered the
+                                   // four-wavefront kernels have the registers to let the element phases' addresses be hoisted: -10 % instructions per iteration)
         const int e = SET == 1 ? elem_set1(t0) : elem_set2(t0);
         if (e < NS * 8) XT[e] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
     }
@@ -1975,7 +1976,7 @@ struct Solver {
             if (want_delta) { DYd[e] = dyd; DYb[e] = dyb; DX[e] = xn - xo; }
         };
         if constexpr (kFour) {
-            const int t0 = opaque(tid);
+            const int t0 = tid;
             if constexpr (SET != 2) { const int e = elem_set1(t0); if (e < NS * 8) element(e, true, wbx[0], wbxi[0]); }
             if constexpr (SET != 1) { const int e = elem_set2(t0); if (e < NS * 8) element(e, true, wbx[1], wbxi[1]); }
             if constexpr (SET != 0) return;
@@ -2950,6 +2951,8 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
     return hipErrorInvalidValue;       // development builds (seconds instead of minutes): the tail kernels only, for looking at their assembly
 #elif defined(LPVMPC_DEV_MAIN_ONLY)
     return launch_one<6, 20, 2, true>(cfg, dcfg, a, stream);      // ... or the headline kernel only
+#elif defined(LPVMPC_DEV_P30_ONLY)
+    return cfg.N == 30 ? launch_one<5, 30, 4, true>(cfg, dcfg, a, stream) : launch_one<5, 40, 4, true>(cfg, dcfg, a, stream);      // ... or the four-wavefront planner kernels
 #else
     if (cfg.kind == 0) {
         if (!generic && cfg.N == 20) return one_wave ? launch_one<6, 20, 1>(cfg, dcfg, a, stream)
