@@ -1906,6 +1906,15 @@ struct Solver {
             // run (16-byte loads, half the LDS instructions of the broadcast reads at stride 8); the last slots spill a few words into AT,
             // which only the termination checks use
             for (int e = opaque(tid); e < NS * 8; e += kStride) VT[(e & 7) * kRhsPitch + (e >> 3)] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
+        } else if constexpr (kUniScalars && kMf && kTwo) {
+            // (round 5: the rounds unrolled from the plain thread index, like update(): their LDS addresses are loop invariants the
+            // compiler may keep in registers now)
+            constexpr int kRounds = ((NT + 1) * 8 + kStride - 1) / kStride;
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                const int e = tid + r * kStride;
+                if (e < NS * 8) XT[e] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
+            }
         } else {
             for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
         }
