@@ -22,6 +22,7 @@
 // padded to 8 per stage so that index = 8*stage + component): 37.7 KB at N = 20, i.e. 4 instances per
 // CU (one wavefront per SIMD), which is exactly BASELINE configs[1] (1024 instances) in one residency.
 #include <atomic>
+#include <type_traits>
 
 #include "lpvmpc_device.hpp"
 #include "wave_ops.hpp"
@@ -684,13 +685,24 @@ struct Solver {
     // the Cholesky / inversion below is the same DPP code with the row index renamed.
     __device__ __forceinline__ static constexpr int dgroup(int i) { return 2 * (i & 3) + (i >> 2); }
     // c + A B, given at = D form of A' and b = D form of B: two MFMAs (k = 0..3, 4..7); the operand quads are replicated by
-    // DPP moves -- A operand of block (I, J): block (K, I) of at, B operand: block (K, J) of b
-    __device__ __forceinline__ static double mm8(double at, double b, double c) {
-        const double a0 = dpp_into<0x118, 0x8>(dpp_into<0x114, 0x6>(at, at), at);      // quads (0, 0, 1, 1) of at
-        const double a1 = dpp_into<0x108, 0x1>(dpp_into<0x104, 0x6>(at, at), at);      // quads (2, 2, 3, 3)
-        const double b0 = dpp_into<0x128, 0xC>(b, b), b1 = dpp_into<0x128, 0x3>(b, b); // quads (0, 1, 0, 1) / (2, 3, 2, 3) of b
-        return mfma4(a1, b1, mfma4(a0, b0, c));
+    // DPP moves -- A operand of block (I, J): block (K, I) of at, B operand: block (K, J) of b.  The replicas are values of their
+    // own (rep_a / rep_b): a matrix that enters several products of an elimination step is replicated once (G' four times as
+    // three replicas, W of the previous stage comes replicated from the step that formed it), and a product that is to be
+    // subtracted negates its A operand inside the MFMA (mm8r<true>) instead of replicating a negated copy.
+    struct Rep2 { double x0, x1; };
+    __device__ __forceinline__ static Rep2 rep_a(double at) {
+        return Rep2{dpp_into<0x118, 0x8>(dpp_into<0x114, 0x6>(at, at), at),       // quads (0, 0, 1, 1) of at
+                    dpp_into<0x108, 0x1>(dpp_into<0x104, 0x6>(at, at), at)};      // quads (2, 2, 3, 3)
     }
+    __device__ __forceinline__ static Rep2 rep_b(double b) {
+        return Rep2{dpp_into<0x128, 0xC>(b, b), dpp_into<0x128, 0x3>(b, b)};      // quads (0, 1, 0, 1) / (2, 3, 2, 3) of b
+    }
+    template <bool NEG = false>
+    __device__ __forceinline__ static double mm8r(const Rep2 &a, const Rep2 &b, double c) {
+        if constexpr (NEG) return mfma4_nega(a.x1, b.x1, mfma4_nega(a.x0, b.x0, c));
+        else return mfma4(a.x1, b.x1, mfma4(a.x0, b.x0, c));
+    }
+    __device__ __forceinline__ static double mm8(double at, double b, double c) { return mm8r(rep_a(at), rep_b(b), c); }
     __device__ __forceinline__ double transpose_d(double v) const { return __shfl(v, tlane); }
     // Cholesky S = C C' merged with the forward substitution C W = I, in D form (see chol_inverse)
     __device__ __forceinline__ double chol_inverse_d(double s) const {
@@ -779,17 +791,22 @@ struct Solver {
             const int chain = wv & 1;
             const bool inner = wv >= 2;
             double wd = 0.0, wtd = 0.0, sinv = 0.0;       // D forms of W, W' and S^-1 of the stage eliminated last
-            auto step = [&](int p, int j0) {
-                const int k = chain ? N - p : p;
+            Rep2 Awd{0.0, 0.0}, Bwd{0.0, 0.0};           // W replicated as an A / a B operand (formed with S^-1 = W' W, used again by the next step)
+            // (the parity of p is a compile-time argument -- the loops below run two steps per trip: which operand forms a step leaves
+            // for the sweeps, and so which tiles take a quad swap, depends on it alone)
+            auto step = [&](const int p, const int j0, auto odd_c) {
+                constexpr bool odd = decltype(odd_c)::value;
+                const int k = __builtin_amdgcn_readfirstlane(chain ? N - p : p);
                 const double kd = kd_d(k, sig, WDv, WBv);
                 double sk = kd;
-                if (p >= 1) {
+                if (odd || p >= 1) {
                     const double kot = chain ? ko_up_at(k, lj, li, WDv) : ko_down_at(k, lj, li, WDv);     // D form of Ko'
-                    const double gt = mm8(wtd, kot, 0.0);          // G' = W Ko'
-                    sk = mm8(-gt, gt, kd);                         // S = Kd - G G'
-                    const double ltn = -mm8(wd, gt, 0.0);          // -L' = -W' G'
-                    const double ln = -mm8(gt, wd, 0.0);           // -L  = -G W
-                    const bool fa = (p & 1) != 0, bb = (((P - p) & 1) == 0) != kFlip;      // (operand forms: see the two-wavefront branch)
+                    const double gt = mm8r(rep_a(wtd), rep_b(kot), 0.0);    // G' = W Ko'
+                    const Rep2 Agt = rep_a(gt), Bgt = rep_b(gt);
+                    sk = mm8r<true>(Agt, Bgt, kd);                          // S = Kd - G G'
+                    const double ltn = mm8r<true>(Awd, Bgt, 0.0);           // -L' = -W' G'
+                    const double ln = mm8r<true>(Agt, Bwd, 0.0);            // -L  = -G W
+                    constexpr bool fa = odd, bb = (((P - (odd ? 1 : 0)) & 1) == 0) != kFlip;      // (operand forms: see the two-wavefront branch)
                     const double fc = fa ? ltn : qswap(ltn), fv = fa ? sinv : qswap(sinv);
                     const double bc = bb ? qswap(ln) : ln, ba = ab_entry(k, bb ? gB : gA);
 #pragma unroll
@@ -797,17 +814,30 @@ struct Solver {
                 }
                 wd = chol_inverse_d(sk);
                 wtd = transpose_d(wd);
-                sinv = mm8(wd, wd, 0.0);                           // S^-1 = W' W
+                Awd = rep_a(wd); Bwd = rep_b(wd);
+                sinv = mm8r(Awd, Bwd, 0.0);                                 // S^-1 = W' W
             };
+            constexpr std::false_type even_c{};
+            constexpr std::true_type odd_c{};
             if (!inner) {
-                for (int p = 0; p <= kHO; ++p) step(p, 0);
+                int p = 0;
+#pragma unroll 1
+                for (; p + 1 <= kHO; p += 2) { step(p, 0, even_c); step(p + 1, 0, odd_c); }
+                if constexpr ((kHO & 1) == 0) step(kHO, 0, even_c);
                 PUB[chain * 128 + lane] = wd; PUB[chain * 128 + 64 + lane] = sinv;
             }
             sync();
             if (inner) {
                 wd = PUB[chain * 128 + lane]; sinv = PUB[chain * 128 + 64 + lane];
                 wtd = transpose_d(wd);
-                for (int p = kHO + 1; p < P; ++p) step(p, kHO);
+                Awd = rep_a(wd); Bwd = rep_b(wd);
+                constexpr int p0 = kHO + 1;
+                constexpr std::integral_constant<bool, (p0 & 1) != 0> first_c{};
+                constexpr std::integral_constant<bool, (p0 & 1) == 0> second_c{};
+                int p = p0;
+#pragma unroll 1
+                for (; p + 1 < P; p += 2) { step(p, kHO, first_c); step(p + 1, kHO, second_c); }
+                if constexpr (((P - p0) & 1) != 0) step(P - 1, kHO, std::integral_constant<bool, ((P - 1) & 1) != 0>{});
                 if (chain == 1) { PUB[256 + lane] = wd; PUB[320 + lane] = wtd; }
             }
             sync();
@@ -815,12 +845,14 @@ struct Solver {
             if (wv == 2) {      // middle stage: S_m = K_mm - G_t G_t' - G_b G_b' with both neighbours' W
                 const double kd = kd_d(kMid, sig, WDv, WBv);
                 const double gtt = mm8(wtd, ko_down_at(kMid, lj, li, WDv), 0.0);
-                double sk = mm8(-gtt, gtt, kd);
-                ltn = -mm8(wd, gtt, 0.0); ln = -mm8(gtt, wd, 0.0);
+                const Rep2 Agtt = rep_a(gtt), Bgtt = rep_b(gtt);
+                double sk = mm8r<true>(Agtt, Bgtt, kd);
+                ltn = mm8r<true>(Awd, Bgtt, 0.0); ln = mm8r<true>(Agtt, Bwd, 0.0);
                 const double wd1 = PUB[256 + lane], wtd1 = PUB[320 + lane];
                 const double gtb = mm8(wtd1, ko_up_at(kMid, lj, li, WDv), 0.0);
-                sk = mm8(-gtb, gtb, sk);
-                PUB[lane] = -mm8(wd1, gtb, 0.0); PUB[64 + lane] = -mm8(gtb, wd1, 0.0);
+                const Rep2 Agtb = rep_a(gtb), Bgtb = rep_b(gtb);
+                sk = mm8r<true>(Agtb, Bgtb, sk);
+                PUB[lane] = mm8r<true>(rep_a(wd1), Bgtb, 0.0); PUB[64 + lane] = mm8r<true>(Agtb, rep_b(wd1), 0.0);
                 const double wm = chol_inverse_d(sk);
                 sm = mm8(wm, wm, 0.0);
                 PUB[128 + lane] = sm;
@@ -848,24 +880,29 @@ struct Solver {
             sync();
             constexpr int P = kMid;
             double wd = 0.0, wtd = 0.0, sinv = 0.0;       // D forms of W, W' and S^-1 of the stage eliminated last
-            for (int p = 0; p < P; ++p) {
-                const int k = wv ? N - p : p;
+            Rep2 Awd{0.0, 0.0}, Bwd{0.0, 0.0};           // W replicated as an A / a B operand (formed with S^-1 = W' W, used again by the next step)
+            // (the parity of p is a compile-time argument -- the loop runs two steps per trip: which operand forms a step leaves for the
+            // sweeps, and so which tiles take a quad swap, depends on it alone)
+            auto step = [&](const int p, auto odd_c) {
+                constexpr bool odd = decltype(odd_c)::value;
+                const int k = __builtin_amdgcn_readfirstlane(wv ? N - p : p);
 #ifdef LPVMPC_STAMPS
                 tlast = __builtin_amdgcn_s_memtime();
 #endif
                 const double kd = kd_d(k, sig, WDv, WBv);
                 STAMP(4);
                 double sk = kd;
-                if (p >= 1) {
+                if (odd || p >= 1) {
                     const double kot = wv ? ko_up_at(k, lj, li, WDv) : ko_down_at(k, lj, li, WDv);     // D form of Ko'
-                    const double gt = mm8(wtd, kot, 0.0);          // G' = W Ko'
-                    sk = mm8(-gt, gt, kd);                         // S = Kd - G G'
-                    const double ltn = -mm8(wd, gt, 0.0);          // -L' = -W' G'
-                    const double ln = -mm8(gt, wd, 0.0);           // -L  = -G W
+                    const double gt = mm8r(rep_a(wtd), rep_b(kot), 0.0);    // G' = W Ko'
+                    const Rep2 Agt = rep_a(gt), Bgt = rep_b(gt);
+                    sk = mm8r<true>(Agt, Bgt, kd);                          // S = Kd - G G'
+                    const double ltn = mm8r<true>(Awd, Bgt, 0.0);           // -L' = -W' G'
+                    const double ln = mm8r<true>(Agt, Bwd, 0.0);            // -L  = -G W
                     // forward step p consumes y_{p-1} (layout A for odd p): tiles -L_p and S_{p-1}^-1; backward step p - 1
                     // consumes x at chain position p (layout B when P - p is even): tiles -L_p' and [A|B] of stage k.
                     // A type A operand is the D form of the tile's transpose, a type B operand the same with quads 1, 2 swapped.
-                    const bool fa = (p & 1) != 0, bb = (((P - p) & 1) == 0) != kFlip;
+                    constexpr bool fa = odd, bb = (((P - (odd ? 1 : 0)) & 1) == 0) != kFlip;
                     const double fc = fa ? ltn : qswap(ltn), fv = fa ? sinv : qswap(sinv);
                     const double bc = bb ? qswap(ln) : ln, ba = ab_entry(k, bb ? gB : gA);
 #pragma unroll
@@ -875,8 +912,15 @@ struct Solver {
                 wd = chol_inverse_d(sk);
                 wtd = transpose_d(wd);
                 STAMP(6);
-                sinv = mm8(wd, wd, 0.0);                           // S^-1 = W' W
+                Awd = rep_a(wd); Bwd = rep_b(wd);
+                sinv = mm8r(Awd, Bwd, 0.0);                                 // S^-1 = W' W
                 STAMP(7);
+            };
+            {
+                int p = 0;
+#pragma unroll 1
+                for (; p + 1 < P; p += 2) { step(p, std::false_type{}); step(p + 1, std::true_type{}); }
+                if constexpr ((P & 1) != 0) step(P - 1, std::false_type{});
             }
             if (wv == 1) { PUB[lane] = wd; PUB[64 + lane] = wtd; }
             sync();
@@ -884,12 +928,14 @@ struct Solver {
             if (wv == 0) {      // middle stage: S_m = K_mm - G_t G_t' - G_b G_b' with both neighbours' W
                 const double kd = kd_d(kMid, sig, WDv, WBv);
                 const double gtt = mm8(wtd, ko_down_at(kMid, lj, li, WDv), 0.0);
-                double sk = mm8(-gtt, gtt, kd);
-                ltn = -mm8(wd, gtt, 0.0); ln = -mm8(gtt, wd, 0.0);
+                const Rep2 Agtt = rep_a(gtt), Bgtt = rep_b(gtt);
+                double sk = mm8r<true>(Agtt, Bgtt, kd);
+                ltn = mm8r<true>(Awd, Bgtt, 0.0); ln = mm8r<true>(Agtt, Bwd, 0.0);
                 const double wd1 = PUB[lane], wtd1 = PUB[64 + lane];
                 const double gtb = mm8(wtd1, ko_up_at(kMid, lj, li, WDv), 0.0);
-                sk = mm8(-gtb, gtb, sk);
-                PUB[128 + lane] = -mm8(wd1, gtb, 0.0); PUB[192 + lane] = -mm8(gtb, wd1, 0.0);
+                const Rep2 Agtb = rep_a(gtb), Bgtb = rep_b(gtb);
+                sk = mm8r<true>(Agtb, Bgtb, sk);
+                PUB[128 + lane] = mm8r<true>(rep_a(wd1), Bgtb, 0.0); PUB[192 + lane] = mm8r<true>(Agtb, rep_b(wd1), 0.0);
                 const double wm = chol_inverse_d(sk);
                 sm = mm8(wm, wm, 0.0);
                 PUB[256 + lane] = sm;

@@ -95,17 +95,16 @@ __device__ inline double bcast_lane(double v) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC), hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
     return __hiloint2double(hi, lo);
 }
-// tile element [i][T] in every lane (i, .): broadcast lane T of each 8-lane group, two DPP moves per dword
+// tile element [i][T] in every lane (i, .): broadcast lane T of each 8-lane group.  gfx90a+ moves 64 bits per DPP instruction under
+// the row_newbcast controls (lane N of every 16-lane row to the whole row): one v_mov_b64_dpp per half row, bank-masked to its own
+// 8 lanes -- two instructions where quad_perm + row_half_mirror on the two dwords took four (tools/microbench/dpp64_neg_probe.hip
+// checks the move against the old form on the device)
 template <int T>
 __device__ inline double bcast_row(double v) {
-    constexpr int q = T & 3, QP = q | (q << 2) | (q << 4) | (q << 6);
-    constexpr int BM = (T >> 2) ? 0x5 : 0xA;          // banks (quads of a row) that still hold the other quad's value
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, QP, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, QP, 0xF, 0xF, true);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, BM, false);     // row_half_mirror into the masked banks
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, BM, false);
-    return __hiloint2double(hi, lo);
+    const long x = __double_as_longlong(v);
+    long y = __builtin_amdgcn_update_dpp(x, x, 0x150 + T, 0xF, 0x3, false);         // row_newbcast:T     -> lanes 0..7 of the row
+    y = __builtin_amdgcn_update_dpp(y, x, 0x158 + T, 0xF, 0xC, false);              // row_newbcast:8 + T -> lanes 8..15
+    return __longlong_as_double(y);
 }
 // two independent all-reduces of the same kind, interleaved step by step (fills the DPP hazard slots
 // and the dependent-add latency of one with the other)
@@ -133,6 +132,9 @@ __device__ inline void red_i2(double &a, double &b) {
 // A stage vector v[0..7] lives in "V layout": lane (r, b, c) holds v[4 (b & 1) + r] -- replicated over c and over b >> 1 --
 // so it is at once a B operand (every column j carries the vector) and, coming out as D, the next step's operand.
 __device__ inline double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+// c - A B: the f64 MFMAs of gfx940+ read the BLGP field as NEG[2:0] (bit 0: the A operand) -- the negation costs no instruction
+// and no second copy of a replicated operand (checked against a negated operand on the device: tools/microbench/dpp64_neg_probe.hip)
+__device__ inline double mfma4_nega(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 1); }
 template <int CTRL, int BANK>
 __device__ inline double dpp_into(double old, double src) {          // src moved by CTRL into the quads of BANK, other quads keep old
     int ol = __double2loint(old), oh = __double2hiint(old);
