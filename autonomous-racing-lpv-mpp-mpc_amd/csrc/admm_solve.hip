@@ -304,6 +304,7 @@ struct Solver {
     // out of the iteration loop as one live address register per (array, access pattern) pair -- those registers, not the
     // arithmetic, are what pushed the kernel into scratch spills.
     __device__ __forceinline__ static int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+    __device__ __forceinline__ static int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }      // the same for a uniform value (scalar register)
     // wave-local ordering of LDS traffic (one wavefront executes its DS instructions in order; this only stops
     // the compiler from moving them across)
     __device__ __forceinline__ void wsync() const {
@@ -737,45 +738,80 @@ struct Solver {
         return dpp_into<0x114, 0x4>(dpp_into<0x104, 0x2>(v, v), v);     // row_shl:4 into quad 1, row_shr:4 into quad 2
 #endif
     }
-    // diagonal block K_kk in D form; WDv / WBv: row weights of the dynamics / box rows (filled by factor())
-    __device__ __forceinline__ double kd_d(int k, double sig, const double *WDv, const double *WBv) const {
-        const int nv = nvar(k);
-        const bool inside = li < nv && lj < nv, dg = li == lj;
-        const int a = inside ? li : 0, b = inside ? lj : 0;
-        double kd = Pc(k, a, b) * c * D[k * 8 + a] * D[k * 8 + b];
-        // diagonal: sigma + the box rows acting on the variable + the identity part of its dynamics row (lj = tj: r0, r1, r2 apply)
+    // ---- the inputs of an elimination step that do not depend on the chain: K_kk and the coupling block, in D form ----------------
+    // An elimination step is a chain of dependent products and an 8-pivot Cholesky (latency bound: a stage took ~2 700 cycles whether one
+    // or four instances shared the CU); the diagonal block K_kk and the coupling block Ko' of a stage depend on the problem data alone.
+    // fac_in() forms them for the NEXT stage -- branch-free (conditional loads become loads from a safe address + a select; the
+    // Hessian entry, the slew-rate entry and the lane's index pair are per-lane constants of the factorisation: fac_lane) so that the
+    // scheduler may place its loads and arithmetic into the stalls of the current stage's chain.  Values and operation order are those
+    // of the former kd_d / ko_down_at / ko_up_at (bitwise: tools/ab_equal.py).
+    struct FacLane {
+        double pmc, pmlc;      // c P[li][lj] of a stage block / of the last input block (one dR less on its diagonal)
+        double m2dr;           // -2 dR of the slew-rate entry of a coupling block (li == lj >= NX), else 0
+        int idx, oth;          // coupling block: variable index of the dynamics row / of the other stage's variable (li, lj by the chain's direction)
+        int r0, r1, r2;        // box rows acting on variable lj
+        bool up;               // the chain runs from stage N downwards: its coupling block is K_{k,k+1}
+    };
+    struct FacIn { double kd, kot; };
+    __device__ __forceinline__ FacLane fac_lane(bool up) const {
+        FacLane f;
+        const double pm = Pm[li * 8 + lj];
+        const bool din = li == lj && li >= NX;
+        const double dr = dRl[din ? li - NX : 0];
+        const double pml = din ? pm - 2.0 * dr : pm;
+        f.pmc = pm * c; f.pmlc = pml * c;
+        f.m2dr = din ? -2.0 * dr : 0.0;
+        f.idx = up ? li : lj; f.oth = up ? lj : li;
         const LaneC lc = lane_consts();
-        const int r0 = lc.r0, r1 = lc.r1, r2 = lc.r2;
-        const double sb0 = Sb(k, r0), sb1 = Sb(k, r1), sb2 = Sb(k, r2), ei = Eid(k, lj);
-        double dd = sig + WBv[k * 8 + r0] * sb0 * sb0 + WBv[k * 8 + r1] * sb1 * sb1 + WDv[k * 8 + lj] * ei * ei;
-        if (kCtrl && delay > 0) dd += WBv[k * 8 + r2] * sb2 * sb2;
-        kd = inside ? (dg ? kd + dd : kd) : (dg ? 1.0 : 0.0);
-        if (k < N) {        // + [A|B]_k' diag(w_{k+1}) [A|B]_k
-            const double ab = li < NX ? tA[k * kTS + li * 8 + lj] : 0.0;
-            kd = mm8(ab, WDv[(k + 1) * 8 + (li < NX ? li : 0)] * ab, kd);
-        }
-        return kd;
+        f.r0 = lc.r0; f.r1 = lc.r1; f.r2 = lc.r2; f.up = up;
+        return f;
     }
-    // element [a][b] of the coupling blocks (rows: variables of stage k; columns: variables of stage k-1 / k+1)
-    __device__ __forceinline__ double ko_down_at(int k, int a, int b, const double *WDv) const {
-        double ko = 0.0;
-        if (b < NB) {
-            if (a < NX) ko = -WDv[k * 8 + a] * Eid(k, a) * tA[(k - 1) * kTS + a * 8 + b];
-            else if (a == b && a < nvar(k)) ko = c * D[k * 8 + a] * (-2.0 * dRl[a - NX]) * D[(k - 1) * 8 + a];
+    // k: the stage (uniform); KO: with the coupling block to the stage eliminated before it (k - 1, or k + 1 on the chain that runs downwards)
+    template <bool KO>
+    __device__ __forceinline__ FacIn fac_in(const FacLane &f, int k, double sig, const double *WDv, const double *WBv) const {
+        FacIn r;
+        // (every select below chooses between values that are already formed: written with an expression as an operand, or with &&, the
+        // front end emits a branch and the optimiser sinks the operand's loads into it -- the basic block ends there)
+        const int nv = nvar(k);
+        const bool inside = (li < nv) & (lj < nv), dg = li == lj;
+        const double pc = k == N - 1 ? f.pmlc : f.pmc;
+        const double kdp = pc * D[k * 8 + li] * D[k * 8 + lj];
+        // diagonal: sigma + the box rows acting on the variable + the identity part of its dynamics row
+        const double sb0 = Sb(k, f.r0), sb1 = Sb(k, f.r1), sb2 = Sb(k, f.r2), ei = Eid(k, lj);
+        double dd = sig + WBv[k * 8 + f.r0] * sb0 * sb0 + WBv[k * 8 + f.r1] * sb1 * sb1 + WDv[k * 8 + lj] * ei * ei;
+        if constexpr (kCtrl) { const double w2l = WBv[k * 8 + f.r2]; const double w2 = delay > 0 ? w2l : 0.0; dd += w2 * sb2 * sb2; }    // pinned-steering row
+        const double kdd = kdp + dd, ident = dg ? 1.0 : 0.0;
+        const double kin = dg ? kdd : kdp;
+        double kd = inside ? kin : ident;
+        {   // + [A|B]_k' diag(w_{k+1}) [A|B]_k   (stage N has no successor: a zero operand adds nothing)
+            const int kn = k < N ? k + 1 : N, rl = li < NX ? li : 0;
+            const double abl = tA[k * kTS + rl * 8 + lj];
+            const bool abm = (li < NX) & (k < N);
+            const double ab = abm ? abl : 0.0;
+            const double wab = WDv[kn * 8 + rl] * ab;
+            kd = mm8(ab, wab, kd);
         }
-        return ko;
-    }
-    __device__ __forceinline__ double ko_up_at(int k, int a, int b, const double *WDv) const {
-        double ko = 0.0;
-        if (a < NB) {
-            if (b < NX) ko = -WDv[(k + 1) * 8 + b] * Eid(k + 1, b) * tA[k * kTS + b * 8 + a];
-            else if (a == b && b < nvar(k + 1)) ko = c * D[(k + 1) * 8 + b] * (-2.0 * dRl[b - NX]) * D[k * 8 + b];
+        r.kd = kd;
+        r.kot = 0.0;
+        if constexpr (KO) {     // D form of Ko': element [lj][li] of the block whose rows are the variables of stage k
+            const int hi = f.up ? k + 1 : k, lo = hi - 1;       // the dynamics rows of stage hi couple the two stages
+            const bool rowd = f.idx < NX;
+            const int ia = rowd ? f.idx : 0;
+            const double t1 = -WDv[hi * 8 + ia] * Eid(hi, ia) * tA[lo * kTS + ia * 8 + f.oth];
+            const double t2 = c * D[hi * 8 + f.idx] * f.m2dr * D[lo * 8 + f.idx];
+            const bool m1 = (f.oth < NB) & rowd, m2 = (f.oth < NB) & !rowd & (li == lj) & (f.idx < nvar(hi));
+            const double kz = m2 ? t2 : 0.0;
+            r.kot = m1 ? t1 : kz;
         }
-        return ko;
+        return r;
     }
     // entry g (row-major offset) of the scaled [A|B] tile of stage k as an MFMA operand: dynamics rows only (rows 6, 7 of the
     // LDS tile cache row coefficients)
-    __device__ __forceinline__ double ab_entry(int k, int g) const { return (g >> 3) < NX ? tA[k * kTS + g] : 0.0; }
+    __device__ __forceinline__ double ab_entry(int k, int g) const {
+        const bool in = (g >> 3) < NX;
+        const double v = tA[k * kTS + (in ? g : 0)];        // (loaded by every lane, then selected: no branch around the load)
+        return in ? v : 0.0;
+    }
     __device__ __forceinline__ void factor(double sig) {
         sync();
         if constexpr (kFour) {
@@ -784,7 +820,7 @@ struct Solver {
             // inner one (wv >= 2) through LDS, which goes on to position kMid-1 (operand tiles kHO .. kMid-2) and takes the link tile
             // kMid-1 from the middle stage (wavefront 2).  Every value is the one the two-wavefront kernel computes.
             double *const WDv = XT, *const WBv = DX, *const PUB = VT;       // free vectors: row weights, hand-over area (VT + AT)
-            static_assert(2 * (NT + 1) * 8 >= 384, "four wavefronts: the hand-over area of the factorisation does not fit VT + AT");
+            static_assert(2 * (NT + 1) * 8 >= 448, "four wavefronts: the hand-over area of the factorisation does not fit VT + AT");
             for (int e = opaque(tid); e < NS * 8; e += kStride) { WDv[e] = w_dyn(e); WBv[e] = w_box(e); }
             sync();
             constexpr int P = kMid;
@@ -792,64 +828,91 @@ struct Solver {
             const bool inner = wv >= 2;
             double wd = 0.0, wtd = 0.0, sinv = 0.0;       // D forms of W, W' and S^-1 of the stage eliminated last
             Rep2 Awd{0.0, 0.0}, Bwd{0.0, 0.0};           // W replicated as an A / a B operand (formed with S^-1 = W' W, used again by the next step)
+            const bool up = __builtin_amdgcn_readfirstlane(chain) != 0;
+            const FacLane fl = fac_lane(up);
+            auto stage_of = [&](int p) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(up ? N - p : p); };
+            FacIn cur{0.0, 0.0};                          // K_kk and Ko' of the step about to run (formed one step ahead: fac_in)
+            // first position of a chain: no predecessor
+            auto head = [&]() __attribute__((always_inline)) {
+                const FacIn nxt = fac_in<true>(fl, stage_of(1), sig, WDv, WBv);
+                wd = chol_inverse_d(cur.kd);
+                wtd = transpose_d(wd);
+                Awd = rep_a(wd); Bwd = rep_b(wd);
+                sinv = mm8r(Awd, Bwd, 0.0);
+                cur = nxt;
+            };
             // (the parity of p is a compile-time argument -- the loops below run two steps per trip: which operand forms a step leaves
-            // for the sweeps, and so which tiles take a quad swap, depends on it alone)
-            auto step = [&](const int p, const int j0, auto odd_c) {
-                constexpr bool odd = decltype(odd_c)::value;
-                const int k = __builtin_amdgcn_readfirstlane(chain ? N - p : p);
-                const double kd = kd_d(k, sig, WDv, WBv);
-                double sk = kd;
-                if (odd || p >= 1) {
-                    const double kot = chain ? ko_up_at(k, lj, li, WDv) : ko_down_at(k, lj, li, WDv);     // D form of Ko'
-                    const double gt = mm8r(rep_a(wtd), rep_b(kot), 0.0);    // G' = W Ko'
-                    const Rep2 Agt = rep_a(gt), Bgt = rep_b(gt);
-                    sk = mm8r<true>(Agt, Bgt, kd);                          // S = Kd - G G'
-                    const double ltn = mm8r<true>(Awd, Bgt, 0.0);           // -L' = -W' G'
-                    const double ln = mm8r<true>(Agt, Bwd, 0.0);            // -L  = -G W
-                    constexpr bool fa = odd, bb = (((P - (odd ? 1 : 0)) & 1) == 0) != kFlip;      // (operand forms: see the two-wavefront branch)
-                    const double fc = fa ? ltn : qswap(ltn), fv = fa ? sinv : qswap(sinv);
-                    const double bc = bb ? qswap(ln) : ln, ba = ab_entry(k, bb ? gB : gA);
+            // for the sweeps, and so which tiles take a quad swap, depends on it alone; FETCH: form the next step's inputs)
+            auto step = [&](const int p, const int j0, auto odd_c, auto fetch_c) __attribute__((always_inline)) {
+                constexpr bool odd = decltype(odd_c)::value, fetch = decltype(fetch_c)::value;
+                const int k = stage_of(p);
+                const double gt = mm8r(rep_a(wtd), rep_b(cur.kot), 0.0);    // G' = W Ko'
+                const Rep2 Agt = rep_a(gt), Bgt = rep_b(gt);
+                const double sk = mm8r<true>(Agt, Bgt, cur.kd);             // S = Kd - G G'
+                const double ltn = mm8r<true>(Awd, Bgt, 0.0);               // -L' = -W' G'
+                const double ln = mm8r<true>(Agt, Bwd, 0.0);                // -L  = -G W
+                constexpr bool fa = odd, bb = (((P - (odd ? 1 : 0)) & 1) == 0) != kFlip;      // (operand forms: see the two-wavefront branch)
+                const double fc = fa ? ltn : qswap(ltn), fv = fa ? sinv : qswap(sinv);
+                const double bc = bb ? qswap(ln) : ln, ba = ab_entry(k, bb ? gB : gA);
+                // (two levels of comparisons, each against a value the optimiser cannot trace: compared against ONE traceable index -- as a
+                // chain or as a switch -- the assignment becomes an indexed store and the tile arrays leave the registers for scratch memory)
+                {
+                    const int ix = p - 1 - j0;
 #pragma unroll
-                    for (int pp = 0; pp < kMP; ++pp) if (pp == p - 1 - j0) { fC[pp] = fc; fV[pp] = fv; bC[pp] = bc; bA[pp] = ba; }
+                    for (int ph = 0; ph < (kMP + 3) / 4; ++ph) if (ph == opaque_s(ix >> 2)) {
+#pragma unroll
+                        for (int pl = 0; pl < 4; ++pl) if (4 * ph + pl < kMP && pl == opaque_s(ix & 3)) {
+                            fC[4 * ph + pl] = fc; fV[4 * ph + pl] = fv; bC[4 * ph + pl] = bc; bA[4 * ph + pl] = ba;
+                        }
+                    }
                 }
+                FacIn nxt{0.0, 0.0};
+                if constexpr (fetch) nxt = fac_in<true>(fl, stage_of(p + 1), sig, WDv, WBv);
                 wd = chol_inverse_d(sk);
                 wtd = transpose_d(wd);
                 Awd = rep_a(wd); Bwd = rep_b(wd);
                 sinv = mm8r(Awd, Bwd, 0.0);                                 // S^-1 = W' W
+                if constexpr (fetch) cur = nxt;
             };
-            constexpr std::false_type even_c{};
-            constexpr std::true_type odd_c{};
-            if (!inner) {
-                int p = 0;
+            // steps PA .. PB, two per trip; the last one forms the inputs of step PB + 1 only with FETCH_LAST
+            auto run_steps = [&](auto pa_c, auto pb_c, const int j0, auto fetch_last_c) __attribute__((always_inline)) {
+                constexpr int PA = decltype(pa_c)::value, PB = decltype(pb_c)::value;
+                constexpr bool fetch_last = decltype(fetch_last_c)::value;
+                constexpr int PE = fetch_last ? PB : PB - 1;
+                constexpr std::integral_constant<bool, (PA & 1) != 0> first_c{};
+                constexpr std::integral_constant<bool, (PA & 1) == 0> second_c{};
+                int p = PA;
 #pragma unroll 1
-                for (; p + 1 <= kHO; p += 2) { step(p, 0, even_c); step(p + 1, 0, odd_c); }
-                if constexpr ((kHO & 1) == 0) step(kHO, 0, even_c);
+                for (; p + 1 <= PE; p += 2) { step(p, j0, first_c, std::true_type{}); step(p + 1, j0, second_c, std::true_type{}); }
+                if constexpr (PE >= PA && ((PE - PA) & 1) == 0) step(PE, j0, std::integral_constant<bool, (PE & 1) != 0>{}, std::true_type{});
+                if constexpr (!fetch_last) step(PB, j0, std::integral_constant<bool, (PB & 1) != 0>{}, std::false_type{});
+            };
+            if (!inner) {
+                cur = fac_in<false>(fl, stage_of(0), sig, WDv, WBv);
+                head();
+                run_steps(std::integral_constant<int, 1>{}, std::integral_constant<int, kHO>{}, 0, std::false_type{});
                 PUB[chain * 128 + lane] = wd; PUB[chain * 128 + 64 + lane] = sinv;
+            } else {
+                cur = fac_in<true>(fl, stage_of(kHO + 1), sig, WDv, WBv);     // (while the outer wavefront eliminates its positions)
             }
             sync();
             if (inner) {
                 wd = PUB[chain * 128 + lane]; sinv = PUB[chain * 128 + 64 + lane];
                 wtd = transpose_d(wd);
                 Awd = rep_a(wd); Bwd = rep_b(wd);
-                constexpr int p0 = kHO + 1;
-                constexpr std::integral_constant<bool, (p0 & 1) != 0> first_c{};
-                constexpr std::integral_constant<bool, (p0 & 1) == 0> second_c{};
-                int p = p0;
-#pragma unroll 1
-                for (; p + 1 < P; p += 2) { step(p, kHO, first_c); step(p + 1, kHO, second_c); }
-                if constexpr (((P - p0) & 1) != 0) step(P - 1, kHO, std::integral_constant<bool, ((P - 1) & 1) != 0>{});
-                if (chain == 1) { PUB[256 + lane] = wd; PUB[320 + lane] = wtd; }
+                run_steps(std::integral_constant<int, kHO + 1>{}, std::integral_constant<int, P - 1>{}, kHO, std::true_type{});
+                // (cur: K_mm and the coupling block of this chain to the middle stage)
+                if (chain == 1) { PUB[256 + lane] = wd; PUB[320 + lane] = wtd; PUB[384 + lane] = cur.kot; }
             }
             sync();
             double ltn = 0.0, ln = 0.0, sm = 0.0;                  // -L_link', -L_link of this wave's chain; S_m^-1
             if (wv == 2) {      // middle stage: S_m = K_mm - G_t G_t' - G_b G_b' with both neighbours' W
-                const double kd = kd_d(kMid, sig, WDv, WBv);
-                const double gtt = mm8(wtd, ko_down_at(kMid, lj, li, WDv), 0.0);
+                const double gtt = mm8(wtd, cur.kot, 0.0);
                 const Rep2 Agtt = rep_a(gtt), Bgtt = rep_b(gtt);
-                double sk = mm8r<true>(Agtt, Bgtt, kd);
+                double sk = mm8r<true>(Agtt, Bgtt, cur.kd);
                 ltn = mm8r<true>(Awd, Bgtt, 0.0); ln = mm8r<true>(Agtt, Bwd, 0.0);
-                const double wd1 = PUB[256 + lane], wtd1 = PUB[320 + lane];
-                const double gtb = mm8(wtd1, ko_up_at(kMid, lj, li, WDv), 0.0);
+                const double wd1 = PUB[256 + lane], wtd1 = PUB[320 + lane], kot1 = PUB[384 + lane];
+                const double gtb = mm8(wtd1, kot1, 0.0);
                 const Rep2 Agtb = rep_a(gtb), Bgtb = rep_b(gtb);
                 sk = mm8r<true>(Agtb, Bgtb, sk);
                 PUB[lane] = mm8r<true>(rep_a(wd1), Bgtb, 0.0); PUB[64 + lane] = mm8r<true>(Agtb, rep_b(wd1), 0.0);
@@ -881,58 +944,71 @@ struct Solver {
             constexpr int P = kMid;
             double wd = 0.0, wtd = 0.0, sinv = 0.0;       // D forms of W, W' and S^-1 of the stage eliminated last
             Rep2 Awd{0.0, 0.0}, Bwd{0.0, 0.0};           // W replicated as an A / a B operand (formed with S^-1 = W' W, used again by the next step)
+            const bool up = __builtin_amdgcn_readfirstlane(wv) != 0;
+            const FacLane fl = fac_lane(up);
+            auto stage_of = [&](int p) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(up ? N - p : p); };
+            FacIn cur = fac_in<false>(fl, stage_of(0), sig, WDv, WBv);      // K_kk and Ko' of the step about to run (formed one step ahead: fac_in)
+#ifdef LPVMPC_STAMPS
+            tlast = __builtin_amdgcn_s_memtime();
+#endif
+            {   // first position of the chain: no predecessor
+                const FacIn nxt = fac_in<true>(fl, stage_of(1), sig, WDv, WBv);
+                STAMP(4);
+                wd = chol_inverse_d(cur.kd);
+                wtd = transpose_d(wd);
+                STAMP(6);
+                Awd = rep_a(wd); Bwd = rep_b(wd);
+                sinv = mm8r(Awd, Bwd, 0.0);
+                STAMP(7);
+                cur = nxt;
+            }
             // (the parity of p is a compile-time argument -- the loop runs two steps per trip: which operand forms a step leaves for the
             // sweeps, and so which tiles take a quad swap, depends on it alone)
-            auto step = [&](const int p, auto odd_c) {
+            auto step = [&](const int p, auto odd_c) __attribute__((always_inline)) {
                 constexpr bool odd = decltype(odd_c)::value;
-                const int k = __builtin_amdgcn_readfirstlane(wv ? N - p : p);
-#ifdef LPVMPC_STAMPS
-                tlast = __builtin_amdgcn_s_memtime();
-#endif
-                const double kd = kd_d(k, sig, WDv, WBv);
-                STAMP(4);
-                double sk = kd;
-                if (odd || p >= 1) {
-                    const double kot = wv ? ko_up_at(k, lj, li, WDv) : ko_down_at(k, lj, li, WDv);     // D form of Ko'
-                    const double gt = mm8r(rep_a(wtd), rep_b(kot), 0.0);    // G' = W Ko'
-                    const Rep2 Agt = rep_a(gt), Bgt = rep_b(gt);
-                    sk = mm8r<true>(Agt, Bgt, kd);                          // S = Kd - G G'
-                    const double ltn = mm8r<true>(Awd, Bgt, 0.0);           // -L' = -W' G'
-                    const double ln = mm8r<true>(Agt, Bwd, 0.0);            // -L  = -G W
-                    // forward step p consumes y_{p-1} (layout A for odd p): tiles -L_p and S_{p-1}^-1; backward step p - 1
-                    // consumes x at chain position p (layout B when P - p is even): tiles -L_p' and [A|B] of stage k.
-                    // A type A operand is the D form of the tile's transpose, a type B operand the same with quads 1, 2 swapped.
-                    constexpr bool fa = odd, bb = (((P - (odd ? 1 : 0)) & 1) == 0) != kFlip;
-                    const double fc = fa ? ltn : qswap(ltn), fv = fa ? sinv : qswap(sinv);
-                    const double bc = bb ? qswap(ln) : ln, ba = ab_entry(k, bb ? gB : gA);
+                const int k = stage_of(p);
+                const double gt = mm8r(rep_a(wtd), rep_b(cur.kot), 0.0);    // G' = W Ko'
+                const Rep2 Agt = rep_a(gt), Bgt = rep_b(gt);
+                const double sk = mm8r<true>(Agt, Bgt, cur.kd);             // S = Kd - G G'
+                const double ltn = mm8r<true>(Awd, Bgt, 0.0);               // -L' = -W' G'
+                const double ln = mm8r<true>(Agt, Bwd, 0.0);                // -L  = -G W
+                // forward step p consumes y_{p-1} (layout A for odd p): tiles -L_p and S_{p-1}^-1; backward step p - 1
+                // consumes x at chain position p (layout B when P - p is even): tiles -L_p' and [A|B] of stage k.
+                // A type A operand is the D form of the tile's transpose, a type B operand the same with quads 1, 2 swapped.
+                constexpr bool fa = odd, bb = (((P - (odd ? 1 : 0)) & 1) == 0) != kFlip;
+                const double fc = fa ? ltn : qswap(ltn), fv = fa ? sinv : qswap(sinv);
+                const double bc = bb ? qswap(ln) : ln, ba = ab_entry(k, bb ? gB : gA);
 #pragma unroll
-                    for (int pp = 0; pp < kMP; ++pp) if (pp == p - 1) { fC[pp] = fc; fV[pp] = fv; bC[pp] = bc; bA[pp] = ba; }
-                }
+                for (int pp = 0; pp < kMP; ++pp) if (pp == p - 1) { fC[pp] = fc; fV[pp] = fv; bC[pp] = bc; bA[pp] = ba; }
                 STAMP(5);
+                // the next step's inputs (behind the last step: the middle stage's) beside this step's Cholesky, in one basic block
+                const FacIn nxt = fac_in<true>(fl, stage_of(p + 1), sig, WDv, WBv);
+                STAMP(4);
                 wd = chol_inverse_d(sk);
                 wtd = transpose_d(wd);
                 STAMP(6);
                 Awd = rep_a(wd); Bwd = rep_b(wd);
                 sinv = mm8r(Awd, Bwd, 0.0);                                 // S^-1 = W' W
                 STAMP(7);
+                cur = nxt;
             };
             {
-                int p = 0;
+                int p = 1;
 #pragma unroll 1
-                for (; p + 1 < P; p += 2) { step(p, std::false_type{}); step(p + 1, std::true_type{}); }
-                if constexpr ((P & 1) != 0) step(P - 1, std::false_type{});
+                for (; p + 1 <= P - 1; p += 2) { step(p, std::true_type{}); step(p + 1, std::false_type{}); }
+                if constexpr (((P - 1) & 1) != 0) step(P - 1, std::true_type{});
             }
-            if (wv == 1) { PUB[lane] = wd; PUB[64 + lane] = wtd; }
+            // (cur: K_mm and this chain's coupling block to the middle stage)
+            if (wv == 1) { PUB[lane] = wd; PUB[64 + lane] = wtd; PUB[128 + lane] = cur.kot; }
             sync();
             double ltn = 0.0, ln = 0.0, sm = 0.0;                  // -L_link', -L_link of this wave's chain; S_m^-1
             if (wv == 0) {      // middle stage: S_m = K_mm - G_t G_t' - G_b G_b' with both neighbours' W
-                const double kd = kd_d(kMid, sig, WDv, WBv);
-                const double gtt = mm8(wtd, ko_down_at(kMid, lj, li, WDv), 0.0);
+                const double gtt = mm8(wtd, cur.kot, 0.0);
                 const Rep2 Agtt = rep_a(gtt), Bgtt = rep_b(gtt);
-                double sk = mm8r<true>(Agtt, Bgtt, kd);
+                double sk = mm8r<true>(Agtt, Bgtt, cur.kd);
                 ltn = mm8r<true>(Awd, Bgtt, 0.0); ln = mm8r<true>(Agtt, Bwd, 0.0);
-                const double wd1 = PUB[lane], wtd1 = PUB[64 + lane];
-                const double gtb = mm8(wtd1, ko_up_at(kMid, lj, li, WDv), 0.0);
+                const double wd1 = PUB[lane], wtd1 = PUB[64 + lane], kot1 = PUB[128 + lane];
+                const double gtb = mm8(wtd1, kot1, 0.0);
                 const Rep2 Agtb = rep_a(gtb), Bgtb = rep_b(gtb);
                 sk = mm8r<true>(Agtb, Bgtb, sk);
                 PUB[128 + lane] = mm8r<true>(rep_a(wd1), Bgtb, 0.0); PUB[192 + lane] = mm8r<true>(Agtb, rep_b(wd1), 0.0);
