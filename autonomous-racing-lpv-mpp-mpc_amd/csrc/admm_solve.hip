@@ -53,6 +53,9 @@ struct Solver {
     // LDS-tile code of the run-time-horizon kernel.  It only ever resumes pool entries: its LDS begins with the image of the
     // kernel that parked them (the compile-time-horizon layout).
     static constexpr bool kTail = TAIL;
+#ifndef LPVMPC_BLOCK_LAUNDER
+#define LPVMPC_BLOCK_LAUNDER 2     // 0: off; 2: the lane indices of the factorisation; 1: the thread index too (un-hoists the iteration's own addresses: loses)
+#endif
 #ifndef LPVMPC_UNI_SCALARS
 #define LPVMPC_UNI_SCALARS 1
 #endif
@@ -298,6 +301,19 @@ struct Solver {
     __device__ __forceinline__ void launder_ids() {
         tid = opaque(tid); wv = tid >> 6; lane = tid & 63; ti = lane >> 3; tj = tid & 7;
         lpack = opaque(lpack);
+        gA = opaque(gA); gB = opaque(gB); li = opaque(li); lj = opaque(lj); tlane = opaque(tlane);
+    }
+    // The termination checks, the rho update and the re-factorisation sit INSIDE the iteration loop and run once in 25 iterations or
+    // less; what they compute from the lane indices (addresses, lane masks -- the factorisation's above all) is loop invariant, so the
+    // optimiser forms it in front of the loop and keeps it in registers through every iteration: scalar register pairs for the masks,
+    // which the loop does not have -- they are spilled to lanes of a vector register and cost the per-iteration code two v_readlane
+    // per use of ITS OWN masks.  That block therefore works on laundered copies of the factorisation's lane indices (its arithmetic
+    // stays inside it) and puts the loop's values back when it ends.  (Laundering the thread index as well un-hoists the iteration's
+    // own addresses -- the loop header's phi is no longer folded: 639 -> 709 instructions per iteration in the headline kernel.)
+    struct Ids { int tid, wv, lane, ti, tj, lpack, gA, gB, li, lj, tlane; };
+    __device__ __forceinline__ Ids ids_save() const { return Ids{tid, wv, lane, ti, tj, lpack, gA, gB, li, lj, tlane}; }
+    __device__ __forceinline__ void ids_restore(const Ids &k) {
+        tid = k.tid; wv = k.wv; lane = k.lane; ti = k.ti; tj = k.tj; lpack = k.lpack; gA = k.gA; gB = k.gB; li = k.li; lj = k.lj; tlane = k.tlane;
     }
     // The same value, opaque to the optimiser.  The element loops of the ADMM iteration start from it so that their LDS
     // addresses are formed inside the loop as (one per-lane base) + (immediate offset of the array) instead of being hoisted
@@ -766,44 +782,65 @@ struct Solver {
         f.r0 = lc.r0; f.r1 = lc.r1; f.r2 = lc.r2; f.up = up;
         return f;
     }
-    // k: the stage (uniform); KO: with the coupling block to the stage eliminated before it (k - 1, or k + 1 on the chain that runs downwards)
+    // k: the stage (uniform); KO: with the coupling block to the stage eliminated before it (k - 1, or k + 1 on the chain that runs downwards).
+    // Two halves: fac_fetch issues the LDS loads (at the top of the step that runs one stage earlier: the values arrive while that step's
+    // products run), fac_form does the arithmetic (beside the Cholesky).
+    struct FacRaw { double di, dj, sb0, sb1, sb2, ei, wb0, wb1, wb2, wdj, abl, wkn, wdh, eih, tal, dh, dl; };
     template <bool KO>
-    __device__ __forceinline__ FacIn fac_in(const FacLane &f, int k, double sig, const double *WDv, const double *WBv) const {
+    __device__ __forceinline__ FacRaw fac_fetch(const FacLane &f, int k, const double *WDv, const double *WBv) const {
+        FacRaw q;
+        q.di = D[k * 8 + li]; q.dj = D[k * 8 + lj];
+        q.sb0 = Sb(k, f.r0); q.sb1 = Sb(k, f.r1); q.sb2 = kCtrl ? Sb(k, f.r2) : 0.0; q.ei = Eid(k, lj);
+        q.wb0 = WBv[k * 8 + f.r0]; q.wb1 = WBv[k * 8 + f.r1]; q.wb2 = kCtrl ? WBv[k * 8 + f.r2] : 0.0; q.wdj = WDv[k * 8 + lj];
+        const int kn = k < N ? k + 1 : N, rl = li < NX ? li : 0;
+        q.abl = tA[k * kTS + rl * 8 + lj]; q.wkn = WDv[kn * 8 + rl];
+        q.wdh = q.eih = q.tal = q.dh = q.dl = 0.0;
+        if constexpr (KO) {
+            const int hi = f.up ? k + 1 : k, lo = hi - 1;       // the dynamics rows of stage hi couple the two stages
+            const int ia = f.idx < NX ? f.idx : 0;
+            q.wdh = WDv[hi * 8 + ia]; q.eih = Eid(hi, ia); q.tal = tA[lo * kTS + ia * 8 + f.oth];
+            q.dh = D[hi * 8 + f.idx]; q.dl = D[lo * 8 + f.idx];
+        }
+        return q;
+    }
+    template <bool KO>
+    __device__ __forceinline__ FacIn fac_form(const FacLane &f, int k, const FacRaw &q, double sig) const {
         FacIn r;
         // (every select below chooses between values that are already formed: written with an expression as an operand, or with &&, the
         // front end emits a branch and the optimiser sinks the operand's loads into it -- the basic block ends there)
         const int nv = nvar(k);
         const bool inside = (li < nv) & (lj < nv), dg = li == lj;
         const double pc = k == N - 1 ? f.pmlc : f.pmc;
-        const double kdp = pc * D[k * 8 + li] * D[k * 8 + lj];
+        const double kdp = pc * q.di * q.dj;
         // diagonal: sigma + the box rows acting on the variable + the identity part of its dynamics row
-        const double sb0 = Sb(k, f.r0), sb1 = Sb(k, f.r1), sb2 = Sb(k, f.r2), ei = Eid(k, lj);
-        double dd = sig + WBv[k * 8 + f.r0] * sb0 * sb0 + WBv[k * 8 + f.r1] * sb1 * sb1 + WDv[k * 8 + lj] * ei * ei;
-        if constexpr (kCtrl) { const double w2l = WBv[k * 8 + f.r2]; const double w2 = delay > 0 ? w2l : 0.0; dd += w2 * sb2 * sb2; }    // pinned-steering row
+        const double sb0 = q.sb0, sb1 = q.sb1, sb2 = q.sb2, ei = q.ei;
+        double dd = sig + q.wb0 * sb0 * sb0 + q.wb1 * sb1 * sb1 + q.wdj * ei * ei;
+        if constexpr (kCtrl) { const double w2l = q.wb2; const double w2 = delay > 0 ? w2l : 0.0; dd += w2 * sb2 * sb2; }    // pinned-steering row
         const double kdd = kdp + dd, ident = dg ? 1.0 : 0.0;
         const double kin = dg ? kdd : kdp;
         double kd = inside ? kin : ident;
         {   // + [A|B]_k' diag(w_{k+1}) [A|B]_k   (stage N has no successor: a zero operand adds nothing)
-            const int kn = k < N ? k + 1 : N, rl = li < NX ? li : 0;
-            const double abl = tA[k * kTS + rl * 8 + lj];
             const bool abm = (li < NX) & (k < N);
-            const double ab = abm ? abl : 0.0;
-            const double wab = WDv[kn * 8 + rl] * ab;
+            const double ab = abm ? q.abl : 0.0;
+            const double wab = q.wkn * ab;
             kd = mm8(ab, wab, kd);
         }
         r.kd = kd;
         r.kot = 0.0;
         if constexpr (KO) {     // D form of Ko': element [lj][li] of the block whose rows are the variables of stage k
-            const int hi = f.up ? k + 1 : k, lo = hi - 1;       // the dynamics rows of stage hi couple the two stages
+            const int hi = f.up ? k + 1 : k;
             const bool rowd = f.idx < NX;
-            const int ia = rowd ? f.idx : 0;
-            const double t1 = -WDv[hi * 8 + ia] * Eid(hi, ia) * tA[lo * kTS + ia * 8 + f.oth];
-            const double t2 = c * D[hi * 8 + f.idx] * f.m2dr * D[lo * 8 + f.idx];
+            const double t1 = -q.wdh * q.eih * q.tal;
+            const double t2 = c * q.dh * f.m2dr * q.dl;
             const bool m1 = (f.oth < NB) & rowd, m2 = (f.oth < NB) & !rowd & (li == lj) & (f.idx < nvar(hi));
             const double kz = m2 ? t2 : 0.0;
             r.kot = m1 ? t1 : kz;
         }
         return r;
+    }
+    template <bool KO>
+    __device__ __forceinline__ FacIn fac_in(const FacLane &f, int k, double sig, const double *WDv, const double *WBv) const {
+        return fac_form<KO>(f, k, fac_fetch<KO>(f, k, WDv, WBv), sig);
     }
     // entry g (row-major offset) of the scaled [A|B] tile of stage k as an MFMA operand: dynamics rows only (rows 6, 7 of the
     // LDS tile cache row coefficients)
@@ -867,7 +904,7 @@ struct Solver {
                     }
                 }
                 FacIn nxt{0.0, 0.0};
-                if constexpr (fetch) nxt = fac_in<true>(fl, stage_of(p + 1), sig, WDv, WBv);
+                if constexpr (fetch) nxt = fac_in<true>(fl, stage_of(p + 1), sig, WDv, WBv);     // (loads and arithmetic here: fetched at the top of the step, as the two-wavefront kernels do, the 17 values cost these kernels registers their iteration loop pays for)
                 wd = chol_inverse_d(sk);
                 wtd = transpose_d(wd);
                 Awd = rep_a(wd); Bwd = rep_b(wd);
@@ -966,7 +1003,8 @@ struct Solver {
             // sweeps, and so which tiles take a quad swap, depends on it alone)
             auto step = [&](const int p, auto odd_c) __attribute__((always_inline)) {
                 constexpr bool odd = decltype(odd_c)::value;
-                const int k = stage_of(p);
+                const int k = stage_of(p), kx = stage_of(p + 1);
+                const FacRaw raw = fac_fetch<true>(fl, kx, WDv, WBv);       // the next step's data (behind the last step: the middle stage's): in flight during the products
                 const double gt = mm8r(rep_a(wtd), rep_b(cur.kot), 0.0);    // G' = W Ko'
                 const Rep2 Agt = rep_a(gt), Bgt = rep_b(gt);
                 const double sk = mm8r<true>(Agt, Bgt, cur.kd);             // S = Kd - G G'
@@ -981,8 +1019,8 @@ struct Solver {
 #pragma unroll
                 for (int pp = 0; pp < kMP; ++pp) if (pp == p - 1) { fC[pp] = fc; fV[pp] = fv; bC[pp] = bc; bA[pp] = ba; }
                 STAMP(5);
-                // the next step's inputs (behind the last step: the middle stage's) beside this step's Cholesky, in one basic block
-                const FacIn nxt = fac_in<true>(fl, stage_of(p + 1), sig, WDv, WBv);
+                // the next step's inputs beside this step's Cholesky, in one basic block
+                const FacIn nxt = fac_form<true>(fl, kx, raw, sig);
                 STAMP(4);
                 wd = chol_inverse_d(sk);
                 wtd = transpose_d(wd);
@@ -2797,6 +2835,9 @@ struct Solver {
             asm volatile("; LPVMPC_HOT_END");
             STAMP(3);
             if (checked || adapt) {
+                const Ids loop_ids = ids_save();
+                if constexpr (kUniScalars && LPVMPC_BLOCK_LAUNDER == 1) launder_ids();       // (see ids_save)
+                if constexpr (kUniScalars && LPVMPC_BLOCK_LAUNDER == 2) { gA = opaque(gA); gB = opaque(gB); li = opaque(li); lj = opaque(lj); tlane = opaque(tlane); }
                 R = residuals(X, Zd, Zb, Yd, Yb);
                 pri_res = R.pri; dua_res = R.dua;
                 if (checked) { status = check_termination(R, false); if (status != LPVMPC_UNSOLVED_) break; }
@@ -2807,6 +2848,7 @@ struct Solver {
                 recompute_w();              // the residual evaluation used ZT* as scratch (and rho may have changed)
                 // straggler deferral: unsolved at this check and past the budget -> park and end the workgroup (block-uniform)
                 if (checked && defer_after > 0 && iter >= defer_after && iter < max_iter && try_park(a, entry, inst, iter, to_chk, to_adp)) return;
+                if constexpr (kUniScalars) ids_restore(loop_ids);
             }
         }
         if constexpr (kUniScalars && !TAIL) launder_ids();      // (the post-loop code's addresses are formed behind the loop: see launder_ids)
