@@ -205,6 +205,8 @@ struct Solver {
                 }
                 wbx[r] = w; wbxi[r] = wi;
             }
+            // (kFuse2: a lane without an element in the second round repeats its first one there -- with the first one's weights)
+            if constexpr (MF && NW == 2 && kRnd == 2) { if (!(tid + kStride < NS * 8)) { wbx[1] = wbx[0]; wbxi[1] = wbxi[0]; } }
         }
     }
     int lpack;                // r0 | r1 << 4 | r2 << 8 | bvar << 12 | (tj < NX) << 16: one register for the whole solve, unpacked where used
@@ -428,6 +430,7 @@ struct Solver {
         }
     }
     // value of (A' (srcD, srcB))[e]
+    template <bool DELAY_ROW = true>
     __device__ __forceinline__ double At_elem(int e, const double *srcD, const double *srcB, const LaneC &lc) const {
         const int k = e >> 3, kn = k < N ? k + 1 : N;         // the stage-N tile is all zero
         const double *col = tA + k * kTS + tj, *sd = srcD + kn * 8;
@@ -439,7 +442,7 @@ struct Solver {
 #pragma unroll
         for (int r = 4; r < NX; ++r) acc0 += c_[r] * d_[r];
         double boxes = sb0 * w0 + sb1 * w1;
-        if (kCtrl && delay > 0) boxes += Sb(k, lc.r2) * srcB[k * 8 + lc.r2];        // pinned-steering row (uniform branch)
+        if constexpr (DELAY_ROW) { if (kCtrl && delay > 0) boxes += Sb(k, lc.r2) * srcB[k * 8 + lc.r2]; }       // pinned-steering row (uniform branch; DELAY_ROW false: the caller has excluded it)
         return boxes + (ei * wd - (acc0 + acc1));
     }
     // dst = A' * (srcD, srcB)
@@ -2070,6 +2073,20 @@ struct Solver {
             // (round 5: the rounds unrolled from the plain thread index, like update(): their LDS addresses are loop invariants the
             // compiler may keep in registers now)
             constexpr int kRounds = ((NT + 1) * 8 + kStride - 1) / kStride;
+            if constexpr (kFuse2) {
+                // both rounds of a wavefront in one basic block (see update(); the pinned-steering row is a uniform branch inside At_elem)
+                if (!(kCtrl && delay > 0) && fuse2_wave()) {
+                    const int e0 = tid, e1 = tid + kStride;
+                    const bool on1 = e1 < NS * 8;
+                    const int e1c = on1 ? e1 : e0;
+                    const RhsIn a0 = rhs_load(e0, lc), a1 = rhs_load(e1c, lc);       // (all loads of both rounds first, in the source too)
+                    const double v0 = rhs_form(a0, sigma), v1 = rhs_form(a1, sigma);
+                    XT[e0] = v0;
+                    XT[e1c] = v1;               // (no second element: v1 == v0, stored again)
+                    if constexpr (SYNC) sync();
+                    return;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < kRounds; ++r) {
                 const int e = tid + r * kStride;
@@ -2107,6 +2124,61 @@ struct Solver {
         update<1>(alpha, want_delta);
         sync();             // B5
         STAMP(5);
+    }
+    // ---- the element phases of the two-wavefront MFMA kernels with both rounds in one basic block (kFuse2) ----
+    static constexpr bool kFuse2 = kUniScalars && MF && NW == 2 && kCacheW && kRnd == 2;
+    // this wavefront owns elements in the second round (uniform; N = 20: wavefront 0 only)
+    __device__ __forceinline__ bool fuse2_wave() const { return __builtin_amdgcn_readfirstlane(kStride + 64 * wv) < NS * 8; }
+    // right-hand side element: At_elem (without the pinned-steering row) + sigma x - q, loads and arithmetic apart
+    struct RhsIn { double c_[NX], d_[NX], sb0, sb1, w0, w1, ei, wd, x, q; };
+    __device__ __forceinline__ RhsIn rhs_load(int e, const LaneC &lc) const {
+        RhsIn r;
+        const int k = e >> 3, kn = k < N ? k + 1 : N;         // the stage-N tile is all zero
+        const double *col = tA + k * kTS + tj, *sd = ZTd + kn * 8;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { r.c_[i] = col[i * 8]; r.d_[i] = sd[i]; }
+        r.sb0 = Sb(k, lc.r0); r.sb1 = Sb(k, lc.r1); r.w0 = ZTb[k * 8 + lc.r0]; r.w1 = ZTb[k * 8 + lc.r1]; r.ei = Eid(k, tj); r.wd = ZTd[e];
+        r.x = X[e]; r.q = Qv[e];
+        return r;
+    }
+    __device__ __forceinline__ double rhs_form(const RhsIn &r, double sigma) const {
+        double acc0 = r.c_[0] * r.d_[0] + r.c_[1] * r.d_[1], acc1 = r.c_[2] * r.d_[2] + r.c_[3] * r.d_[3];
+#pragma unroll
+        for (int i = 4; i < NX; ++i) acc0 += r.c_[i] * r.d_[i];
+        const double boxes = r.sb0 * r.w0 + r.sb1 * r.w1;
+        return (boxes + (r.ei * r.wd - (acc0 + acc1))) + (sigma * r.x - r.q);
+    }
+    struct ElIn { double xt, xo, zd, yd, zb, yb, lo, hi, b, sb, xv, ei, dot; };
+    struct ElOut { double ynd, znd, wtd, ynb, znb, wtb, xn; };
+    // (the same loads, operations and operation order as update()'s element(); every load unconditional)
+    __device__ __forceinline__ ElIn el_load(int e, int bvar) const {
+        const int k = e >> 3;
+        ElIn q;
+        q.xt = XT[e]; q.xo = X[e]; q.zd = Zd[e]; q.yd = Yd[e]; q.zb = Zb[e]; q.yb = Yb[e]; q.lo = Lo[e]; q.hi = Hi[e];
+        q.b = dyn_bound(e); q.sb = Sb(k, tj); q.xv = XT[k * 8 + bvar]; q.ei = Eid(k, tj);
+        const double d0 = AT[e], d1 = kRawV ? VT[e] : 0.0;
+        const double dsum = kRawV ? d0 + d1 : d0;
+        q.dot = k > 0 ? dsum : 0.0;
+        return q;
+    }
+    __device__ __forceinline__ ElOut el_form(const ElIn &q, double alpha, double oma, double rmask, double w, double winv) const {
+        ElOut o;
+        const double ztd = rmask * (q.ei * q.xt - q.dot);
+        const double zrd = alpha * ztd + oma * q.zd;
+        const double znd = q.b;
+        const double dyd = rho_eq * (zrd - znd), ynd = q.yd + dyd;
+        const double zrb = alpha * (q.sb * q.xv) + oma * q.zb;
+        const double znb = clipd(zrb + winv * q.yb, q.lo, q.hi);
+        const double dyb = w * (zrb - znb), ynb = q.yb + dyb;
+        o.xn = alpha * q.xt + oma * q.xo;
+        o.ynd = ynd; o.znd = znd; o.wtd = rho_eq * znd - ynd;
+        o.ynb = ynb; o.znb = znb; o.wtb = w * znb - ynb;
+        return o;
+    }
+    __device__ __forceinline__ void el_store(int e, const ElOut &o) {
+        Yd[e] = o.ynd; Zd[e] = o.znd; ZTd[e] = o.wtd;
+        Yb[e] = o.ynb; Zb[e] = o.znb; ZTb[e] = o.wtb;
+        X[e] = o.xn;
     }
     // z~ = A x~ fused with OSQP update_x / update_z / update_y; leaves rho z - y in ZT*.
     // All LDS reads of a round are issued before any of its writes.
@@ -2153,6 +2225,22 @@ struct Solver {
             // (round 5: with the uniform scalars in SGPRs and the post-loop addresses laundered, the two-wavefront MFMA kernels have the
             // registers to let this loop's addresses be hoisted: -24 instructions per iteration in the headline kernel)
             const int t0 = (kUniScalars && kMf && kTwo) ? tid : opaque(tid);
+            if constexpr (kFuse2) {
+                // A wavefront that owns elements in both rounds runs them as ONE basic block (plain iterations only: want_delta is a
+                // uniform branch inside element()): both rounds' loads, both rounds' arithmetic, then the stores -- one LDS round trip is
+                // exposed instead of two.  A lane without a second element repeats its first one (same values, stored twice).
+                if (!want_delta && fuse2_wave()) {
+                    const int e0 = t0, e1 = t0 + kStride;
+                    const bool on1 = e1 < NS * 8;
+                    const int e1c = on1 ? e1 : e0;
+                    const ElIn a0 = el_load(e0, bvar), a1 = el_load(e1c, bvar);
+                    const ElOut o0 = el_form(a0, alpha, oma, rmask, wbx[0], wbxi[0]), o1 = el_form(a1, alpha, oma, rmask, wbx[1], wbxi[1]);
+                    el_store(e0, o0);
+                    el_store(e1c, o1);          // (no second element: the first one's values once more -- no exec mask for the optimiser to sink the round into)
+                    sync();
+                    return;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
                 const int e = t0 + r * kStride;
