@@ -3067,59 +3067,67 @@ struct Solver {
         pol = true;
         factor(delta);
         // px (DX), py (Yd/Yb are overwritten: ADMM duals are no longer needed)
+        // Element loops that only hand a value from one loop to the next THROUGH THE ELEMENT'S OWN SLOT are one loop here (round 5:
+        // 13 of the polish's ~45 barriers and as many exposed LDS round trips less -- the phases are latency bound).  The operations and
+        // their order are those of the separate loops; a value that used to pass through LDS between two of them is fenced, so that the
+        // compiler cannot contract its last multiplication with the next loop's first addition.
+        const LaneC lc = lane_consts();
+        auto fence = [](double v) { asm volatile("" : "+v"(v)); return v; };
+        auto A_elem = [&](int e, const double *src, double &vd, double &vb) {       // row e of A * src (see A_mul)
+            const int k = e >> 3;
+            vd = fence(lc.rmask * (Eid(k, tj) * src[e] - prev_stage_dot(k, src)));
+            vb = fence(Sb(k, tj) * src[k * 8 + lc.bvar]);
+        };
+        auto bound_of = [&](int e) { const double f = DYb[e]; return f > 0 ? Hi[e] : (f < 0 ? Lo[e] : 0.0); };
         // initial solve: rhs = -q + A'(W b)
         for (int e = opaque(tid); e < NS * 8; e += kStride) {
             ZTd[e] = fabs(DYd[e]) * dyn_bound(e);
-            ZTb[e] = fabs(DYb[e]) * (DYb[e] > 0 ? Hi[e] : (DYb[e] < 0 ? Lo[e] : 0.0));
+            ZTb[e] = fabs(DYb[e]) * bound_of(e);
         }
         sync();
-        At_mul(ZTd, ZTb, XT);
-        sync();
-        for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] -= Qv[e];
+        for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] = At_elem(e, ZTd, ZTb, lc) - Qv[e];
         sync();
         kkt_solve();
-        for (int e = opaque(tid); e < NS * 8; e += kStride) DX[e] = XT[e];
-        sync();
-        A_mul(DX, ZTd, ZTb);
-        sync();
         for (int e = opaque(tid); e < NS * 8; e += kStride) {
-            Yd[e] = fabs(DYd[e]) * (ZTd[e] - dyn_bound(e));
-            Yb[e] = fabs(DYb[e]) * (ZTb[e] - (DYb[e] > 0 ? Hi[e] : (DYb[e] < 0 ? Lo[e] : 0.0)));
+            double vd, vb;
+            A_elem(e, XT, vd, vb);
+            DX[e] = XT[e];
+            Yd[e] = fabs(DYd[e]) * (vd - dyn_bound(e));
+            Yb[e] = fabs(DYb[e]) * (vb - bound_of(e));
         }
         sync();
         for (int it = 0; it < cfg.polish_refine_iter; ++it) {
             // r1 = -q - P px - A' py ; r2 = b - A px (active rows)
-            P_mul(DX, VT);
-            At_mul(Yd, Yb, AT);
-            A_mul(DX, ZTd, ZTb);
-            sync();
             for (int e = opaque(tid); e < NS * 8; e += kStride) {
-                const double r2d = (DYd[e] != 0.0) ? dyn_bound(e) - ZTd[e] : 0.0;
-                const double r2b = (DYb[e] != 0.0) ? (DYb[e] > 0 ? Hi[e] : Lo[e]) - ZTb[e] : 0.0;
+                VT[e] = P_row<false>(e >> 3, DX);
+                AT[e] = At_elem(e, Yd, Yb, lc);
+                double vd, vb;
+                A_elem(e, DX, vd, vb);
+                const double fd = DYd[e], fb = DYb[e];
+                const double r2d = (fd != 0.0) ? dyn_bound(e) - vd : 0.0;
+                const double r2b = (fb != 0.0) ? (fb > 0 ? Hi[e] : Lo[e]) - vb : 0.0;
                 ZTd[e] = r2d; ZTb[e] = r2b;
-                Zd[e] = fabs(DYd[e]) * r2d; Zb[e] = fabs(DYb[e]) * r2b;
+                Zd[e] = fabs(fd) * r2d; Zb[e] = fabs(fb) * r2b;
             }
             sync();
-            At_mul(Zd, Zb, XT);
-            sync();
-            for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] += -Qv[e] - VT[e] - AT[e];
+            for (int e = opaque(tid); e < NS * 8; e += kStride) XT[e] = At_elem(e, Zd, Zb, lc) + (-Qv[e] - VT[e] - AT[e]);
             sync();
             kkt_solve();
-            A_mul(XT, Zd, Zb);
-            sync();
             for (int e = opaque(tid); e < NS * 8; e += kStride) {
+                double vd, vb;
+                A_elem(e, XT, vd, vb);
                 DX[e] += XT[e];
-                Yd[e] += fabs(DYd[e]) * (Zd[e] - ZTd[e]);
-                Yb[e] += fabs(DYb[e]) * (Zb[e] - ZTb[e]);
+                Yd[e] += fabs(DYd[e]) * (vd - ZTd[e]);
+                Yb[e] += fabs(DYb[e]) * (vb - ZTb[e]);
             }
             sync();
         }
         // pol_z = A px, project (z, y) on the normal cone
-        A_mul(DX, Zd, Zb);
-        sync();
         for (int e = opaque(tid); e < NS * 8; e += kStride) {
-            { const double b = dyn_bound(e), t = Zd[e] + Yd[e]; Zd[e] = b; Yd[e] = t - b; }         // projection on [b, b]
-            { const double t = Zb[e] + Yb[e], z = clipd(t, Lo[e], Hi[e]); Zb[e] = z; Yb[e] = t - z; }
+            double vd, vb;
+            A_elem(e, DX, vd, vb);
+            { const double b = dyn_bound(e), t = vd + Yd[e]; Zd[e] = b; Yd[e] = t - b; }         // projection on [b, b]
+            { const double t = vb + Yb[e], z = clipd(t, Lo[e], Hi[e]); Zb[e] = z; Yb[e] = t - z; }
         }
         sync();
         const double pobj = objective(DX);
