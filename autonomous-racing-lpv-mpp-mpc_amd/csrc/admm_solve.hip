@@ -29,10 +29,15 @@
 
 namespace lpvmpc {
 
-#ifdef LPVMPC_STAMPS
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS != 5
 #define STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[slot] += t_ - tlast; tlast = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(slot) do { } while (0)
+#endif
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS == 5     // the parts of a whole solve: set-up, equilibration, first factorisation, iterations, checks + rho updates, polish factorisation, polish, output (tools/gpu_stamps_solve.py)
+#define STAMP5(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[slot] += t_ - tlast; tlast = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP5(slot) do { } while (0)
 #endif
 #if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS == 4
 #define STAMP4(slot) do { asm volatile("s_waitcnt lgkmcnt(0)"); STAMP(slot); } while (0)      // (tail kernel, inside the phases: everything issued so far has arrived)
@@ -495,6 +500,76 @@ struct Solver {
     // ---- Ruiz equilibration (OSQP scale_data) ----------------------------------------------------
     // D, E and c are accumulated while the [A|B] tiles stay UNSCALED (entries are multiplied by the current
     // E and D on the fly when the norms are taken); the tiles are scaled once at the end.
+    // ---- one equilibration pass with both element rounds of a wavefront in one basic block (see pass() in scale_data) ----
+    static constexpr bool kFuseS = kReg && NW == 2 && ((NT + 1) * 8 + kStride - 1) / kStride == 2 && !GS;
+    struct NormIn { double de, ede, ebe, col[NX], es[NX], row[NB], ds[NB], b0, b1, b2, dbv; };
+    struct NormOut { double d, e, b; };
+    __device__ __forceinline__ NormIn norm_load(int e, const double *Ds, const double *Es, const double *Bs, int r0, int r1, int r2, int bvar) const {
+        NormIn q;
+        const int k = e >> 3, a = tj, kn = k < N ? k + 1 : N, kp = k > 0 ? k - 1 : 0;
+        q.de = Ds[e]; q.ede = Es[e]; q.ebe = Bs[e];
+        const double *col = tA + k * kTS + a, *row = tA + kp * kTS + a * 8;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) { q.col[r] = col[r * 8]; q.es[r] = Es[kn * 8 + r]; }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { q.row[b] = row[b]; q.ds[b] = Ds[kp * 8 + b]; }
+        q.b0 = Bs[k * 8 + r0]; q.b1 = Bs[k * 8 + r1]; q.b2 = Bs[k * 8 + r2]; q.dbv = Ds[k * 8 + bvar];
+        return q;
+    }
+    __device__ __forceinline__ NormOut norm_form(int e, const NormIn &q, double pcol, int r0, int r1, int r2) const {
+        const int k = e >> 3, a = tj, nb = nbox(k);
+        double cmax = 0.0, rmax = 0.0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) cmax = fmax(cmax, fabs(q.col[r]) * q.es[r]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) rmax = fmax(rmax, fabs(q.row[b]) * q.ds[b]);
+        const double de = q.de, ede = q.ede, ebe = q.ebe;
+        const double t0 = q.b0 * de, t1 = q.b1 * de, t2 = q.b2 * de, td = ede * de, tr = rmax * ede, tb = ebe * q.dbv;
+        double dn = fmax(pcol, cmax * de);
+        dn = fmax(dn, r0 < nb ? t0 : 0.0);
+        dn = fmax(dn, r1 < nb ? t1 : 0.0);
+        dn = fmax(dn, r2 < nb ? t2 : 0.0);
+        dn = fmax(dn, a < NX ? td : 0.0);
+        dn = a < nvar(k) ? dn : 0.0;
+        double en = fmax(td, k >= 1 ? tr : 0.0);
+        en = a < NX ? en : 0.0;
+        const double bn = a < nb ? tb : 0.0;
+        NormOut o;
+        o.d = de * inv_sqrt(limit_scaling(dn));
+        o.e = ede * inv_sqrt(limit_scaling(en));
+        o.b = ebe * inv_sqrt(limit_scaling(bn));
+        return o;
+    }
+    // P_row_d<true, true>(k, Dn, Dn) -- the un-scaled column norm of the Hessian under the scaling Dn -- with the loads apart
+    struct CostIn { double pr[8], dr[8], dnx, dpv, de, qv; };
+    __device__ __forceinline__ CostIn cost_load(int e, const double *Dn) const {
+        CostIn q;
+        const int k = e >> 3, a = tj;
+        const double2 *pr = reinterpret_cast<const double2 *>(Pm + a * 8);
+        const double2 *dr = reinterpret_cast<const double2 *>(Dn + k * 8);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { const double2 p = pr[h], d = dr[h]; q.pr[2 * h] = p.x; q.pr[2 * h + 1] = p.y; q.dr[2 * h] = d.x; q.dr[2 * h + 1] = d.y; }
+        const int en = (k + 1 < N) ? e + 8 : e, ep = (k >= 1) ? e - 8 : e;
+        q.dnx = Dn[en]; q.dpv = Dn[ep]; q.de = Dn[e]; q.qv = Qv[e];
+        return q;
+    }
+    __device__ __forceinline__ double cost_form(int e, const CostIn &q) const {
+        const int k = e >> 3, a = tj;
+        const bool inp = a >= NX;
+        const double dr2 = 2.0 * dRl[inp ? a - NX : 0];
+        const double dadj = (inp & (k == N - 1)) ? dr2 : 0.0;     // last input block: one dR less
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double pa = q.pr[i] - dadj;
+            const double pv = i == a ? pa : q.pr[i];
+            acc = fmax(acc, fabs(pv) * q.dr[i]);
+        }
+        const double cpl = inp ? dr2 : 0.0;
+        const double dn = (k + 1 < N) ? q.dnx : 0.0, dp = (k >= 1) ? q.dpv : 0.0;
+        acc = fmax(acc, fabs(cpl) * dn); acc = fmax(acc, fabs(cpl) * dp);
+        return (inp & (k >= N)) ? 0.0 : acc;
+    }
     __device__ __forceinline__ void scale_data() {
         const int ntrue = NS * NX + N * 2;
         // rounds of the element loops; with a compile-time horizon the un-scaled Hessian column norms of the cost
@@ -533,6 +608,22 @@ struct Solver {
                 En[e] = ede * inv_sqrt(limit_scaling(en));
                 Bn[e] = ebe * inv_sqrt(limit_scaling(bn));
             };
+            // Two-wavefront kernels with two element rounds (N = 20), passes behind the first: a wavefront that owns elements in both
+            // rounds runs them as ONE basic block -- every load of both rounds first, the arithmetic branch-free (a maximum with a term
+            // that does not apply is a maximum with 0: all terms are >= 0), the stores unconditional (a lane without a second element
+            // repeats its first one).  The phases of the equilibration are latency bound: ten passes cost a ninth of a default solve.
+            // Values and operation order are those of norms() / the loops below.
+            bool fused = false;
+            if constexpr (kFuseS) fused = !first && fuse2_wave();
+            if constexpr (kFuseS) if (fused) {
+                const int e0 = tid, e1 = tid + kStride, e1c = e1 < NS * 8 ? e1 : e0;
+                const NormIn q0 = norm_load(e0, Ds, Es, Bs, r0, r1, r2, bvar), q1 = norm_load(e1c, Ds, Es, Bs, r0, r1, r2, bvar);
+                const double pa1 = e1 < NS * 8 ? pacc[1] : pacc[0];
+                const NormOut o0 = norm_form(e0, q0, pacc[0] * c * q0.de, r0, r1, r2), o1 = norm_form(e1c, q1, pa1 * c * q1.de, r0, r1, r2);
+                Dn[e0] = o0.d; En[e0] = o0.e; Bn[e0] = o0.b;
+                Dn[e1c] = o1.d; En[e1c] = o1.e; Bn[e1c] = o1.b;
+            }
+            if (!fused) {
             if constexpr (kReg) {
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) {
@@ -542,10 +633,26 @@ struct Solver {
             } else {
                 for (int e = opaque(tid); e < NS * 8; e += kStride) norms(e, P_row_d<true>(e >> 3, Ds, Ds));
             }
+            }
             sync();
             // cost normalisation (with the new D)
             double psum = 0.0, qmax = 0.0;
-            if constexpr (kReg) {
+            if constexpr (kFuseS) if (fuse2_wave()) {
+                const int e0 = tid, e1 = tid + kStride;
+                const bool on1 = e1 < NS * 8;
+                const int e1c = on1 ? e1 : e0;
+                const CostIn q0 = cost_load(e0, Dn), q1 = cost_load(e1c, Dn);
+                const double p0 = cost_form(e0, q0), p1 = cost_form(e1c, q1);
+                pacc[0] = p0; pacc[1] = p1;
+                psum += p0 * c * q0.de;
+                qmax = fmax(qmax, fabs(c * q0.de * q0.qv));
+                const double ps1 = psum + p1 * c * q1.de, m1 = fabs(c * q1.de * q1.qv);     // (the sum in the shape of the plain loop's: the same contraction)
+                psum = on1 ? ps1 : psum;
+                qmax = fmax(qmax, on1 ? m1 : 0.0);
+                fused = true;
+            } else fused = false;
+            if (fused) { }
+            else if constexpr (kReg) {
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) {
                     const int e = tid + r * kStride;
@@ -988,7 +1095,7 @@ struct Solver {
             const FacLane fl = fac_lane(up);
             auto stage_of = [&](int p) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(up ? N - p : p); };
             FacIn cur = fac_in<false>(fl, stage_of(0), sig, WDv, WBv);      // K_kk and Ko' of the step about to run (formed one step ahead: fac_in)
-#ifdef LPVMPC_STAMPS
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS != 5
             tlast = __builtin_amdgcn_s_memtime();
 #endif
             {   // first position of the chain: no predecessor
@@ -1114,7 +1221,7 @@ struct Solver {
             return;
         }
         double *const T = XT;
-#ifdef LPVMPC_STAMPS
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS != 5
         if constexpr (TAIL) tlast = __builtin_amdgcn_s_memtime();
 #endif
         if (!TAIL || wv == 0) {     // (tail kernel: wavefront 0 factors, the tiles go to LDS)
@@ -2423,7 +2530,7 @@ struct Solver {
                 more = m - 1;
             }
             for (;;) {
-#ifdef LPVMPC_STAMPS
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS != 5
                 tlast = __builtin_amdgcn_s_memtime();
 #endif
                 // (the markers of tools/check_kernel_resources.py bracket the element side's trip; the checker's side is off the chain)
@@ -2753,6 +2860,9 @@ struct Solver {
 
     // inst: instance index; entry: pool entry to continue (a.resume) or -1
     __device__ __forceinline__ void run(const SolveArgs &a, int inst, int entry = -1) {
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS == 5
+        tlast = __builtin_amdgcn_s_memtime();
+#endif
         bool bad = false;              // this thread saw a non-finite input word
         const bool resuming = TAIL || entry >= 0;     // (the tail kernel only ever resumes)
         if constexpr (GS) { D = a.scal + (size_t)inst * 3 * (NS * 8); Ed = D + NS * 8; Eb = Ed + NS * 8; }
@@ -2835,6 +2945,7 @@ struct Solver {
         }
 
         // ---------- setup: scaling, rho, factorisation ----------
+        STAMP5(0);
         if (cfg.scaling > 0) scale_data();
         for (int e = opaque(tid); e < NS * 8; e += kStride) { Qv[e] *= c * D[e]; Lo[e] *= Eb[e]; Hi[e] *= Eb[e]; }
         if (tid < 8) beq[tid] *= Ed[tid];
@@ -2843,7 +2954,9 @@ struct Solver {
         set_rho(fmin(fmax(cfg.rho, kRhoMin), kRhoMax));
         }
         cache_box_weights();
+        STAMP5(1);
         factor(cfg.sigma);                      // first factorisation, or the one that puts a restored instance back into its registers
+        STAMP5(2);
         if (!resuming) {
             if (a.warm && a.state) warm_start(a.state + (size_t)inst * 3 * NS * 8, a.warm == 2);
             recompute_w();                      // cold start: x = z = y = 0
@@ -2892,7 +3005,7 @@ struct Solver {
             const bool adapt = adp_every > 0 && --to_adp == 0;
             if (checked) to_chk = chk_every;
             if (adapt) to_adp = adp_every;
-#ifdef LPVMPC_STAMPS
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS != 5
             tlast = __builtin_amdgcn_s_memtime();
 #endif
             // (the two markers bracket the per-iteration code in the kept assembly: tools/check_kernel_resources.py counts the
@@ -2922,6 +3035,7 @@ struct Solver {
 #endif
             asm volatile("; LPVMPC_HOT_END");
             STAMP(3);
+            STAMP5(3);
             if (checked || adapt) {
                 const Ids loop_ids = ids_save();
                 if constexpr (kUniScalars && LPVMPC_BLOCK_LAUNDER == 1) launder_ids();       // (see ids_save)
@@ -2937,8 +3051,10 @@ struct Solver {
                 // straggler deferral: unsolved at this check and past the budget -> park and end the workgroup (block-uniform)
                 if (checked && defer_after > 0 && iter >= defer_after && iter < max_iter && try_park(a, entry, inst, iter, to_chk, to_adp)) return;
                 if constexpr (kUniScalars) ids_restore(loop_ids);
+                STAMP5(4);
             }
         }
+        STAMP5(4);
         if constexpr (kUniScalars && !TAIL) launder_ids();      // (the post-loop code's addresses are formed behind the loop: see launder_ids)
         if (iter > max_iter) iter = max_iter;
         if (!checked) {
@@ -2959,7 +3075,9 @@ struct Solver {
         if (st_out) save_duals(st_out);        // ADMM duals (the polish below reuses the y arrays)
         // ---------- polish ----------
         if (cfg.polish && status == LPVMPC_SOLVED_) {
+            STAMP5(4);
             const PolishOut po = polish(pri_res, dua_res, obj);
+            STAMP5(6);
             status_polish = po.flag; pri_res = po.pri; dua_res = po.dua; obj = po.obj;
             if (st_out && status_polish == 1) save_duals(st_out);
         }
@@ -2981,6 +3099,16 @@ struct Solver {
         if (st_out && !sol) {      // no solution: do not seed the next solve with garbage
             for (int e = opaque(tid); e < NS * 8; e += kStride) { st_out[NS * 8 + e] = 0.0; st_out[2 * NS * 8 + e] = 0.0; }
         }
+#if defined(LPVMPC_STAMPS) && LPVMPC_STAMPS == 5
+        STAMP5(7);
+        if (tid == 0) {
+            for (int i = 0; i < 8; ++i) o_.xPred[(size_t)inst * NS * NX + i] = (double)stamp[i];
+            if (o_.status) o_.status[inst] = status;
+            if (o_.iters) o_.iters[inst] = iter;
+            if (o_.polish) o_.polish[inst] = status_polish;
+        }
+        return;
+#endif
 #ifdef LPVMPC_STAMPS
         if constexpr (kFour) {          // the inner top wavefront's own eight segments (inner4) behind wavefront 0's six
             if (tid == 128) for (int i = 0; i < 8; ++i) o_.xPred[(size_t)inst * NS * NX + 8 + i] = (double)stamp[i] / iter;
@@ -3065,7 +3193,9 @@ struct Solver {
         }
         sync();
         pol = true;
+        STAMP5(6);
         factor(delta);
+        STAMP5(5);
         // px (DX), py (Yd/Yb are overwritten: ADMM duals are no longer needed)
         // Element loops that only hand a value from one loop to the next THROUGH THE ELEMENT'S OWN SLOT are one loop here (round 5:
         // 13 of the polish's ~45 barriers and as many exposed LDS round trips less -- the phases are latency bound).  The operations and
