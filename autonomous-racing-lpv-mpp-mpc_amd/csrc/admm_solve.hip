@@ -2013,31 +2013,44 @@ struct Solver {
     // reductions changes nothing but the number of reductions (8 instead of 14).
     struct Res { double pri, dua, nAxz, nPAq, s_pri, s_dua, s_Axz, s_PAq; };
 
-    // (xv, zd/zb, yd/yb) -> residual norms; leaves A x in ZT*, P x in VT, A'y in AT
+    // (xv, zd/zb, yd/yb) -> residual norms (the tail kernel leaves A x in ZT*, P x in VT, A'y in AT; the others form them per element)
     __device__ __forceinline__ Res residuals(const double *xv, const double *zd, const double *zb, const double *yd, const double *yb) {
         if constexpr (TAIL) {       // the three products side by side on different wavefronts
             const LaneC lc = lane_consts();
             eloop(0, kActW, [&](int e) { const int k = e >> 3; ZTd[e] = lc.rmask * (Eid(k, tj) * xv[e] - prev_stage_dot(k, xv)); ZTb[e] = Sb(k, tj) * xv[k * 8 + lc.bvar]; });
             eloop(kActW, kActW, [&](int e) { VT[e] = P_row<false>(e >> 3, xv); });
             eloop(2 * kActW, NW - 2 * kActW, [&](int e) { AT[e] = At_elem(e, yd, yb, lc); });
-        } else {
-            A_mul(xv, ZTd, ZTb);
-            P_mul(xv, VT);
-            At_mul(yd, yb, AT);
         }
-        sync();
         Res r = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int e = opaque(tid); e < NS * 8; e += kStride) {
+        auto norms_of = [&](int e, double axd, double axb, double px, double aty) {
             const double eid = 1.0 / Ed[e], eib = 1.0 / Eb[e], di = 1.0 / D[e];
-            const double rd = ZTd[e] - zd[e], rb = ZTb[e] - zb[e];
+            const double rd = axd - zd[e], rb = axb - zb[e];
             r.s_pri = fmax(r.s_pri, fmax(fabs(rd), fabs(rb)));
             r.pri = fmax(r.pri, fmax(fabs(eid * rd), fabs(eib * rb)));
-            r.s_Axz = fmax(r.s_Axz, fmax(fmax(fabs(ZTd[e]), fabs(ZTb[e])), fmax(fabs(zd[e]), fabs(zb[e]))));
-            r.nAxz = fmax(r.nAxz, fmax(fmax(fabs(eid * ZTd[e]), fabs(eib * ZTb[e])), fmax(fabs(eid * zd[e]), fabs(eib * zb[e]))));
-            const double dr = Qv[e] + VT[e] + AT[e];
+            r.s_Axz = fmax(r.s_Axz, fmax(fmax(fabs(axd), fabs(axb)), fmax(fabs(zd[e]), fabs(zb[e]))));
+            r.nAxz = fmax(r.nAxz, fmax(fmax(fabs(eid * axd), fabs(eib * axb)), fmax(fabs(eid * zd[e]), fabs(eib * zb[e]))));
+            const double dr = Qv[e] + px + aty;
             r.s_dua = fmax(r.s_dua, fabs(dr));       r.dua = fmax(r.dua, fabs(di * dr));
-            r.s_PAq = fmax(r.s_PAq, fmax(fmax(fabs(VT[e]), fabs(AT[e])), fabs(Qv[e])));
-            r.nPAq = fmax(r.nPAq, fmax(fmax(fabs(di * VT[e]), fabs(di * AT[e])), fabs(di * Qv[e])));
+            r.s_PAq = fmax(r.s_PAq, fmax(fmax(fabs(px), fabs(aty)), fabs(Qv[e])));
+            r.nPAq = fmax(r.nPAq, fmax(fmax(fabs(di * px), fabs(di * aty)), fabs(di * Qv[e])));
+        };
+        if constexpr (TAIL) {
+            sync();
+            for (int e = opaque(tid); e < NS * 8; e += kStride) norms_of(e, ZTd[e], ZTb[e], VT[e], AT[e]);
+        } else {
+            // (round 5: the three products of an element and its share of the norms in one loop -- they used to pass through the
+            // element's slots of ZT*, VT and AT and a barrier; fenced, so that no product's last operation contracts with the norms'
+            // first.  The products are no longer left in those arrays: nothing read them.)
+            const LaneC lc = lane_consts();
+            auto fence = [](double v) { asm volatile("" : "+v"(v)); return v; };
+            for (int e = opaque(tid); e < NS * 8; e += kStride) {
+                const int k = e >> 3;
+                const double axd = fence(lc.rmask * (Eid(k, tj) * xv[e] - prev_stage_dot(k, xv)));
+                const double axb = fence(Sb(k, tj) * xv[k * 8 + lc.bvar]);
+                const double px = fence(P_row<false>(k, xv));
+                const double aty = fence(At_elem(e, yd, yb, lc));
+                norms_of(e, axd, axb, px, aty);
+            }
         }
         double m_[8] = {r.pri, r.dua, r.nAxz, r.nPAq, r.s_pri, r.s_dua, r.s_Axz, r.s_PAq};
 #pragma unroll
