@@ -12,10 +12,12 @@ import sys
 
 
 def hot_path(path):
-    """Per kernel: what sits between the `; LPVMPC_HOT_BEGIN` / `; LPVMPC_HOT_END` markers the solve kernel puts around the
-    code of one ADMM iteration -- scratch accesses (VGPR spills), v_readlane / v_writelane on the VGPRs that hold spilled
-    SGPRs (the registers v_writelane targets anywhere in the kernel), and the instruction count.  The region is taken in text
-    order, so blocks the compiler laid out in between are included: the figure is an upper bound."""
+    """Per kernel: the code of one ADMM iteration -- everything that can execute between the `; LPVMPC_HOT_BEGIN` and `; LPVMPC_HOT_END`
+    markers the solve kernel puts around it -- scratch accesses (VGPR spills), v_readlane / v_writelane on the VGPRs that hold spilled
+    SGPRs (the registers v_writelane targets anywhere in the kernel), and the instruction count.  The region is followed along the
+    control flow (fall-through and branch targets, until the END marker, the next BEGIN marker or s_endpgm): blocks of the iteration
+    that the compiler laid out behind the loop are counted and checked, blocks of other code laid out in between are not (until
+    round 5 the region was taken in text order)."""
     out, name, body = {}, None, []
     for ln in open(path):
         m = re.match(r"^(_Z\w+):", ln)
@@ -27,20 +29,36 @@ def hot_path(path):
         body.append(ln)
         if ln.startswith(".Lfunc_end"):
             spill_regs = set(re.findall(r"v_writelane_b32\s+(v\d+)", "".join(body)))
-            hot, n_ins, scratch, stores, lanes = False, 0, 0, 0, 0
-            for b in body:
-                if "LPVMPC_HOT_BEGIN" in b:
-                    hot = True
-                elif "LPVMPC_HOT_END" in b:
-                    hot = False
-                elif hot and b.startswith("\t") and not b.strip().startswith((".", ";")):
-                    n_ins += 1
-                    op = b.split()[0]
-                    scratch += op.startswith("scratch_")
-                    stores += op.startswith("scratch_store")
-                    if op in ("v_readlane_b32", "v_writelane_b32") and re.search(r"\b(v\d+)\b", b.split(None, 1)[1]) and \
-                            set(re.findall(r"\bv\d+\b", b)) & spill_regs:
-                        lanes += 1
+            labels = {}
+            for i, b in enumerate(body):
+                m = re.match(r"^(\.LBB\d+_\d+):", b)
+                if m:
+                    labels[m.group(1)] = i
+            starts = [i + 1 for i, b in enumerate(body) if "LPVMPC_HOT_BEGIN" in b]
+            seen, n_ins, scratch, stores, lanes = set(), 0, 0, 0, 0
+            work = list(starts)
+            while work:
+                i = work.pop()
+                while i < len(body) and i not in seen:
+                    seen.add(i)
+                    b = body[i]
+                    if "LPVMPC_HOT_END" in b or "LPVMPC_HOT_BEGIN" in b:
+                        break
+                    if b.startswith("\t") and not b.strip().startswith((".", ";")):
+                        op = b.split()[0]
+                        n_ins += 1
+                        scratch += op.startswith("scratch_")
+                        stores += op.startswith("scratch_store")
+                        if op in ("v_readlane_b32", "v_writelane_b32") and set(re.findall(r"\bv\d+\b", b)) & spill_regs:
+                            lanes += 1
+                        if op == "s_endpgm":
+                            break
+                        m = re.search(r"(\.LBB\d+_\d+)", b) if op.startswith(("s_cbranch", "s_branch")) else None
+                        if m and m.group(1) in labels:
+                            work.append(labels[m.group(1)])
+                        if op == "s_branch":
+                            break
+                    i += 1
             out[name] = dict(instructions=n_ins, scratch=scratch, scratch_stores=stores, spill_lane_moves=lanes)
             name = None
     return out
@@ -130,7 +148,7 @@ if __name__ == "__main__":
             # the allowance covers RELOADS of loop-invariant values only: a scratch store between the markers always fails
             loads = h["scratch"] - h["scratch_stores"]
             hflag = loads > max([v for n, v in hot_scratch.items() if n in k["name"]] or [0]) or h["scratch_stores"] > 0 or h["spill_lane_moves"] > lanes_max
-            print("      per-iteration code (between the markers): %d instructions, %d scratch loads, %d scratch stores, %d SGPR-spill lane moves%s"
+            print("      per-iteration code (reachable between the markers): %d instructions, %d scratch loads, %d scratch stores, %d SGPR-spill lane moves%s"
                   % (h["instructions"], loads, h["scratch_stores"], h["spill_lane_moves"], "  <-- FAIL" if hflag else ""))
             bad += hflag
     # role-divergent barriers: every path of a group must pass the same number (see role_barriers)

@@ -44,7 +44,7 @@ SHIPS = [
 
 ks = {k["name"]: k for k in ckr.kernels(path)}
 hot = ckr.hot_path(path)
-print("| problem | `kernel_variant` | instantiation `<NX, NT, NW, MF, GS, TAIL>` | what it is | wavefronts | VGPRs | scratch (B) | LDS per instance | instances per CU | instructions per iteration (text between the markers) |")
+print("| problem | `kernel_variant` | instantiation `<NX, NT, NW, MF, GS, TAIL>` | what it is | wavefronts | VGPRs | scratch (B) | LDS per instance | instances per CU | instructions of an iteration (all role and round paths, reachable between the markers) |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 for kind, N, variant, targs, what in SHIPS:
     nx, nt, nw, mf, gs, tail = targs
