@@ -3373,24 +3373,33 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
         if (!generic && cfg.N == 8) return launch_one<6, 8, 1>(cfg, dcfg, a, stream);      // the launch file's controller horizon (MAIN_LAUNCH.launch:117)
         return launch_one<6, 0, 1>(cfg, dcfg, a, stream);
     }
-    const bool mf = kernel_variant == 4;      // diagnostic: the planner N = 30 kernel with two wavefronts and MFMA sweeps (two instances per CU)
-    // N = 30 and N = 40 (round 4): FOUR wavefronts per instance, the two chains relayed, MFMA sweeps and factorisation -- two instances
-    // per CU, two wavefronts per SIMD (Solver::kFour).  A lone instance iterates a quarter faster than on two wavefronts; on a saturated
-    // chip the four-wavefront kernels draw level with (N = 40: the two-wavefront MFMA kernel, kernel_variant 6) or pass (N = 30: 0.183
-    // against 0.180 M solves/s on configs[2]) what ran before, so they are the defaults for every batch size -- one arithmetic per (kind, N).
+    const bool mf = kernel_variant == 4;      // the planner N = 30 kernel with two wavefronts and MFMA sweeps (two instances per CU)
+    // N = 30 (and N = 40 through kernel_variant 6): two forms of ONE arithmetic (every output word equal: test_four_wavefront_planner_kernels_are_bit_identical...),
+    // chosen by what the launch is short of.  FOUR wavefronts per instance (round 4: the two chains relayed, two wavefronts per SIMD,
+    // Solver::kFour) iterate a quarter faster when an instance has its CU to itself: the form for batches that do not fill the chip, and
+    // for everything a handle with straggler deferral launches (the parked image is the four-wavefront one).  TWO wavefronts per
+    // instance (kernel_variant 4 / 6) issue fewer instructions per iteration and, since round 5, run both element rounds of a
+    // wavefront as one block: on a chip that is full either way -- a plain launch of 512 instances or more, two per CU -- they finish
+    // a batch sooner: N = 30, 2.11 against 2.52 us per iteration at B = 512, configs[2] 0.197 -> 0.215 M solves/s.  kernel_variant 8 = four
+    // wavefronts whatever the batch.
     // N = 30 kernel_variant 7 = round 3's default: the DPP two-wavefront kernel with its equilibration vectors in global memory (three
     // instances per CU) whenever the caller provides the room, nothing is parked or resumed and the batch exceeds 512 instances, the
-    // LDS form (kernel_variant 5) otherwise; 4 = two wavefronts with MFMA sweeps; N = 40 kernel_variant 3 = DPP sweeps.
+    // LDS form (kernel_variant 5) otherwise; N = 40 kernel_variant 3 = DPP sweeps.
+    const bool full_chip = kernel_variant != 8 && a.defer_after == 0 && !a.resume && a.B >= 512;
     const bool gs = kernel_variant == 7 && a.scal != nullptr && a.defer_after == 0 && !a.resume && a.B > 512;
     if (!generic && cfg.N == 30) {
         if (one_wave) return launch_one<5, 30, 1>(cfg, dcfg, a, stream);
         if (mf) return launch_one<5, 30, 2, true>(cfg, dcfg, a, stream);
         if (gs) return launch_one<5, 30, 2, false, true>(cfg, dcfg, a, stream);
         if (kernel_variant == 5 || kernel_variant == 7 || dpp) return launch_one<5, 30, 2>(cfg, dcfg, a, stream);
-        return launch_one<5, 30, 4, true>(cfg, dcfg, a, stream);
+        return full_chip ? launch_one<5, 30, 2, true>(cfg, dcfg, a, stream) : launch_one<5, 30, 4, true>(cfg, dcfg, a, stream);
     }
-    if (!generic && cfg.N == 40) return dpp ? launch_one<5, 40, 2>(cfg, dcfg, a, stream)
-                                            : (kernel_variant == 6 ? launch_one<5, 40, 2, true>(cfg, dcfg, a, stream) : launch_one<5, 40, 4, true>(cfg, dcfg, a, stream));
+    if (!generic && cfg.N == 40) {
+        if (dpp) return launch_one<5, 40, 2>(cfg, dcfg, a, stream);
+        // (N = 40 stays on four wavefronts at every size: its two-wavefront form has three element rounds, not two, and although a 512-batch
+        // of it iterates 5 % faster the cascade of configs[4] -- a thinning fleet, controller launches in between -- loses 7 % with it)
+        return kernel_variant == 6 ? launch_one<5, 40, 2, true>(cfg, dcfg, a, stream) : launch_one<5, 40, 4, true>(cfg, dcfg, a, stream);
+    }
     if (!generic && cfg.N == 20) return dpp ? launch_one<5, 20, 2>(cfg, dcfg, a, stream) : launch_one<5, 20, 2, true>(cfg, dcfg, a, stream);     // the planner half of configs[3]
     return launch_one<5, 0, 1>(cfg, dcfg, a, stream);
 #endif

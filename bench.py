@@ -407,8 +407,9 @@ def main():
                          # lives in LDS and registers, the counter traffic is a hundredth of the algorithmic bytes
                          "limiter": "valu_issue", "limiter_frac": (pmc.get("valu_timed") or {}).get("frac"),
                          "pmc_build": pmc.get("build"), "pmc_matches_build": pmc_matches_build(pmc),
-                         "kernel": ("admm_solve_kernel<%d, %d, 4, MFMA sweeps, chains relayed over four wavefronts>" % (nx, N) if planner and args.kernel_variant == 0 and N in (30, 40)
-                                    else "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, (", equilibration vectors in global memory (3 instances per CU)" if args.kernel_variant == 7 and args.defer == 0 else "")
+                         "kernel": ("admm_solve_kernel<%d, %d, 4, MFMA sweeps, chains relayed over four wavefronts>" % (nx, N) if planner and ((N == 40 and args.kernel_variant in (0, 8)) or (N == 30 and (args.kernel_variant == 8 or (args.kernel_variant == 0 and (B < 512 or args.defer > 0)))))
+                                    else "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, (", equilibration vectors in global memory (3 instances per CU)" if args.kernel_variant == 7 and args.defer == 0
+                                                                                     else (", MFMA sweeps" if args.kernel_variant in (0, 4, 6) else ""))
                                                                             if planner else ("" if args.kernel_variant == 3 else ", MFMA sweeps"))),
                          "kernel_avg_ms": k_ms / max(k_n, 1), "launches": k_n,
                          "all_launches_avg_ms": (k_ms + r_ms) / max(k_n + r_n, 1),     # main + resume launches: what a kernel trace averages under the one kernel name
@@ -567,7 +568,8 @@ def bench_planner_leg(args, rank, local_rank, world, dev):
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "config": {"workload": "configs[2]: batch=%d LPV-MPP planner solves (velocity-max cost), N=30, L-shape track, OSQP defaults + polish, cold start" % B,
                        "mean_admm_iters": float(it.mean()), "solved_fraction": float((stt == 1).mean())},
-            "roofline": {"bound": "hbm", "frac": bl / k_avg_s / 1e9 / HBM_PEAK_GBS, "kernel": "admm_solve_kernel<5, 30, 4, MFMA sweeps, chains relayed over four wavefronts>",
+            "roofline": {"bound": "hbm", "frac": bl / k_avg_s / 1e9 / HBM_PEAK_GBS, "kernel": ("admm_solve_kernel<5, 30, 2, MFMA sweeps> (plain launches of 512 instances or more; smaller ones take the four-wavefront form of the same arithmetic)" if B >= 512
+                                                                                                else "admm_solve_kernel<5, 30, 4, MFMA sweeps, chains relayed over four wavefronts>"),
                          "kernel_avg_ms": kms / max(kn, 1), "launches": kn, "algorithmic_bytes_per_launch": bl, "bytes_per_admm_iteration": bi,
                          # what the chip does: every launch's algorithmic bytes over the leg's wall time (the per-launch figure above divides one
                          # launch's bytes by its duration while the other streams' launches share the chip)

@@ -122,11 +122,13 @@ int lpvmpc_last_error_code(void);
  * "cascade_prefetch" (0/1, default 1): read by lpvmpc_cascade_init on the controller handle, see there.
  * "kernel_variant" 3 = the DPP two-wavefront kernels of round 1 for the controller at N = 20 and the planner at N = 20 / 30 / 40 (their
  * defaults run the KKT sweeps and the factorisation on the matrix cores; the planner at N = 30 / 40 with FOUR wavefronts per instance, the
- * two elimination chains relayed over two wavefronts each); 4 = the planner N = 30 kernel with two wavefronts and MFMA sweeps (diagnostic);
- * 5 = the planner N = 30 DPP kernel with every vector in LDS (two instances per CU); 6 = the planner N = 40 kernel with two wavefronts and
- * MFMA sweeps (round 3's default: bit-identical to today's); 7 = round 3's default at N = 30: the DPP kernel with its three equilibration
- * vectors in global memory (three instances per CU) for batches beyond 512 instances without deferral, variant 5 otherwise.  One kernel,
- * hence one arithmetic, per (kind, N) by default: an instance's result does not depend on the batch it is solved in.
+ * two elimination chains relayed over two wavefronts each -- at N = 30 for launches that leave compute units free and for handles with
+ * straggler deferral, while plain launches of 512 instances or more take the two-wavefront form of the same arithmetic: every output word
+ * is the same either way); 4 = the planner N = 30 kernel with two wavefronts and MFMA sweeps whatever the batch; 5 = the planner N = 30 DPP kernel
+ * with every vector in LDS (two instances per CU); 6 = the planner N = 40 kernel with two wavefronts and MFMA sweeps whatever the batch;
+ * 7 = round 3's default at N = 30: the DPP kernel with its three equilibration vectors in global memory (three instances per CU) for
+ * batches beyond 512 instances without deferral, variant 5 otherwise; 8 = the four-wavefront planner kernels whatever the batch.  One
+ * arithmetic per (kind, N) by default: an instance's result does not depend on the batch it is solved in.
  * "defer_after" (iterations, 0 = off, default): STRAGGLER DEFERRAL for lpvmpc_solve_batch_dev.  One OSQP solve in a thousand
  * needs thousands of ADMM iterations where the typical one needs 50; a launch lasts as long as its slowest instance, so those
  * few hold the caller's stream for milliseconds.  With defer_after = K an instance that is still unsolved at a termination

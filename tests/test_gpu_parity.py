@@ -203,11 +203,13 @@ def test_four_wavefront_planner_kernels_are_bit_identical_to_the_two_wavefront_o
     that fills the chip unevenly (several residencies, stragglers to max_iter, polish) and a ragged one -- and straggler deferral
     (park / restore of the four-wavefront image, bounded passes) has to reproduce the plain call bit for bit."""
     from lpvmpc import workloads
-    for N, four_wave, two_wave, sizes in ((40, 0, 6, (1100, 37)), (30, 0, 4, (1300, 5))):
+    # (kernel_variant 8 = four wavefronts whatever the batch: the default takes them for launches that leave compute units free and
+    # the two-wavefront form for plain launches of 512 instances or more)
+    for N, four_wave, two_wave, sizes in ((40, 8, 6, (1100, 37)), (30, 8, 4, (1300, 5))):
         for B in sizes:
             w = workloads.planner_batch(B, N=N, seed=21 + B)
             outs = {}
-            for variant in (four_wave, two_wave):
+            for variant in (four_wave, two_wave, 0):
                 eng = workloads.make_solver(w)
                 eng.set_option("kernel_variant", variant)
                 o = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
@@ -215,6 +217,7 @@ def test_four_wavefront_planner_kernels_are_bit_identical_to_the_two_wavefront_o
                 eng.close()
             for k in ("status", "iters", "polish", "xPred", "uPred"):
                 assert np.array_equal(outs[four_wave][k], outs[two_wave][k], equal_nan=True), (N, B, k)
+                assert np.array_equal(outs[0][k], outs[two_wave][k], equal_nan=True), (N, B, k, "default")      # (whichever form the default took for this batch)
             # (residual norms are maxima: equal; the objective value is a sum over four wavefronts' partial sums instead of two)
             assert np.array_equal(outs[four_wave]["resid"][:, [0, 1, 3]], outs[two_wave]["resid"][:, [0, 1, 3]], equal_nan=True)
             assert np.allclose(outs[four_wave]["resid"][:, 2], outs[two_wave]["resid"][:, 2], rtol=1e-12, atol=1e-12, equal_nan=True)

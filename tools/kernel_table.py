@@ -31,13 +31,13 @@ SHIPS = [
     ("planner", 20, "0", (5, 20, 2, 1, 0, 0), "MFMA sweeps + factorisation, two wavefronts"),
     ("planner", 20, "tail", (5, 20, 8, 0, 0, 1), "whole-CU kernel (as the controller's)"),
     ("planner", 20, "3", (5, 20, 2, 0, 0, 0), "DPP sweeps, two wavefronts"),
-    ("planner", 30, "0", (5, 30, 4, 1, 0, 0), "MFMA sweeps, chains relayed over four wavefronts"),
+    ("planner", 30, "0 (B < 512, or deferral) / 8", (5, 30, 4, 1, 0, 0), "MFMA sweeps, chains relayed over four wavefronts"),
     ("planner", 30, "7 (B > 512, no deferral)", (5, 30, 2, 0, 1, 0), "DPP sweeps, equilibration vectors in global memory (three per CU)"),
     ("planner", 30, "5 / 7 / 3", (5, 30, 2, 0, 0, 0), "DPP sweeps, two wavefronts"),
-    ("planner", 30, "4", (5, 30, 2, 1, 0, 0), "MFMA sweeps, two wavefronts (diagnostic)"),
+    ("planner", 30, "0 (plain launch, B >= 512) / 4", (5, 30, 2, 1, 0, 0), "MFMA sweeps, two wavefronts (the same arithmetic as the four-wavefront form)"),
     ("planner", 30, "2", (5, 30, 1, 0, 0, 0), "one wavefront"),
-    ("planner", 40, "0", (5, 40, 4, 1, 0, 0), "MFMA sweeps, chains relayed over four wavefronts"),
-    ("planner", 40, "6", (5, 40, 2, 1, 0, 0), "MFMA sweeps, two wavefronts (round 3's default)"),
+    ("planner", 40, "0 / 8", (5, 40, 4, 1, 0, 0), "MFMA sweeps, chains relayed over four wavefronts"),
+    ("planner", 40, "6", (5, 40, 2, 1, 0, 0), "MFMA sweeps, two wavefronts (round 3's default; the same arithmetic as the four-wavefront form)"),
     ("planner", 40, "3", (5, 40, 2, 0, 0, 0), "DPP sweeps, two wavefronts"),
     ("planner", "other <= 52", "0 / 1", (5, 0, 1, 0, 0, 0), "run-time horizon, factor tiles in LDS"),
 ]
