@@ -2095,6 +2095,23 @@ struct Solver {
     __device__ __forceinline__ double objective(const double *xv) {
         P_mul(xv, VT);
         sync();
+        if constexpr (MF && NT >= 30) {
+            // The planner at N = 30 / 40 has a two- and a four-wavefront form of one arithmetic (launch_solve picks by batch size): the
+            // objective is the one sum whose association would depend on the number of wavefronts, so these kernels add the elements'
+            // terms in ONE order -- the terms go through AT (free here), wavefront 0 adds them lane by lane, then across the lanes.
+            for (int e = opaque(tid); e < NS * 8; e += kStride) AT[e] = xv[e] * (0.5 * VT[e] + Qv[e]);
+            sync();
+            if (wv == 0) {
+                double v = 0.0;
+                for (int e = opaque(lane); e < NS * 8; e += 64) v += AT[e];
+                v = wave_sum(v);
+                if (lane == 0) RED[0] = v;
+            }
+            sync();
+            const double v = RED[0] * cinv;
+            sync();
+            return v;
+        }
         double v = 0.0;
         for (int e = opaque(tid); e < NS * 8; e += kStride) v += xv[e] * (0.5 * VT[e] + Qv[e]);
         v = bsum<1>(v) * cinv;
