@@ -996,11 +996,10 @@ struct Solver {
                 const double gt = mm8r(rep_a(wtd), rep_b(cur.kot), 0.0);    // G' = W Ko'
                 const Rep2 Agt = rep_a(gt), Bgt = rep_b(gt);
                 const double sk = mm8r<true>(Agt, Bgt, cur.kd);             // S = Kd - G G'
-                const double ltn = mm8r<true>(Awd, Bgt, 0.0);               // -L' = -W' G'
-                const double ln = mm8r<true>(Agt, Bwd, 0.0);                // -L  = -G W
                 constexpr bool fa = odd, bb = (((P - (odd ? 1 : 0)) & 1) == 0) != kFlip;      // (operand forms: see the two-wavefront branch)
-                const double fc = fa ? ltn : qswap(ltn), fv = fa ? sinv : qswap(sinv);
-                const double bc = bb ? qswap(ln) : ln, ba = ab_entry(k, bb ? gB : gA);
+                const double fc = fa ? mm8r<true>(Awd, Bgt, 0.0) : mm8r<true>(Bwd, Agt, 0.0);      // -L' = -W' G'  (as it is / quads 1, 2 exchanged)
+                const double bc = bb ? mm8r<true>(Bgt, Awd, 0.0) : mm8r<true>(Agt, Bwd, 0.0);      // -L  = -G W    (exchanged / as it is)
+                const double fv = sinv, ba = ab_entry(k, bb ? gB : gA);                            // (S^-1 of the previous stage: formed in the form this step takes)
                 // (two levels of comparisons, each against a value the optimiser cannot trace: compared against ONE traceable index -- as a
                 // chain or as a switch -- the assignment becomes an indexed store and the tile arrays leave the registers for scratch memory)
                 {
@@ -1018,7 +1017,7 @@ struct Solver {
                 wd = chol_inverse_d(sk);
                 wtd = transpose_d(wd);
                 Awd = rep_a(wd); Bwd = rep_b(wd);
-                sinv = mm8r(Awd, Bwd, 0.0);                                 // S^-1 = W' W
+                sinv = odd ? mm8r(Bwd, Awd, 0.0) : mm8r(Awd, Bwd, 0.0);     // S^-1 = W' W, in the form the NEXT step takes (an even one: exchanged)
                 if constexpr (fetch) cur = nxt;
             };
             // steps PA .. PB, two per trip; the last one forms the inputs of step PB + 1 only with FETCH_LAST
@@ -1071,7 +1070,7 @@ struct Solver {
             if (wv == 3) { ltn = PUB[lane]; ln = PUB[64 + lane]; sm = PUB[128 + lane]; }
             if (inner) {    // link to the middle stage, the middle pivot (see the two-wavefront branch)
                 constexpr bool fa = (P & 1) != 0;
-                fC[P - 1 - kHO] = fa ? ltn : qswap(ltn); fV[P - 1 - kHO] = fa ? sinv : qswap(sinv);
+                fC[P - 1 - kHO] = fa ? ltn : qswap(ltn); fV[P - 1 - kHO] = sinv;      // (sinv: already in the form of step P, see step())
                 bC[P - 1 - kHO] = kFlip ? ln : qswap(ln); bA[P - 1 - kHO] = ab_entry(kMid, kFlip ? gA : gB);     // (step P - 1 is of type B, of type A with kFlip)
                 mS = kFlip ? qswap(sm) : sm;
             } else {        // wave 0's closing product [A|B]_0 x_0 (x_0 leaves the last backward step in layout B iff P is even); an outer
@@ -1118,14 +1117,16 @@ struct Solver {
                 const double gt = mm8r(rep_a(wtd), rep_b(cur.kot), 0.0);    // G' = W Ko'
                 const Rep2 Agt = rep_a(gt), Bgt = rep_b(gt);
                 const double sk = mm8r<true>(Agt, Bgt, cur.kd);             // S = Kd - G G'
-                const double ltn = mm8r<true>(Awd, Bgt, 0.0);               // -L' = -W' G'
-                const double ln = mm8r<true>(Agt, Bwd, 0.0);                // -L  = -G W
                 // forward step p consumes y_{p-1} (layout A for odd p): tiles -L_p and S_{p-1}^-1; backward step p - 1
                 // consumes x at chain position p (layout B when P - p is even): tiles -L_p' and [A|B] of stage k.
-                // A type A operand is the D form of the tile's transpose, a type B operand the same with quads 1, 2 swapped.
+                // A type A operand is the D form of the tile's transpose, a type B operand the same with quads 1, 2 exchanged -- and
+                // a product with its two off-diagonal 4x4 blocks exchanged is the same product with the replicas' roles exchanged (block
+                // b of the result then holds (I, J) = (b & 1, b >> 1): the A operand takes the B pattern of its matrix and vice versa),
+                // so a tile comes out of its MFMAs in the form its step takes: no quad swap (round 5; the same MFMAs, the same sums).
                 constexpr bool fa = odd, bb = (((P - (odd ? 1 : 0)) & 1) == 0) != kFlip;
-                const double fc = fa ? ltn : qswap(ltn), fv = fa ? sinv : qswap(sinv);
-                const double bc = bb ? qswap(ln) : ln, ba = ab_entry(k, bb ? gB : gA);
+                const double fc = fa ? mm8r<true>(Awd, Bgt, 0.0) : mm8r<true>(Bwd, Agt, 0.0);      // -L' = -W' G'  (as it is / exchanged)
+                const double bc = bb ? mm8r<true>(Bgt, Awd, 0.0) : mm8r<true>(Agt, Bwd, 0.0);      // -L  = -G W    (exchanged / as it is)
+                const double fv = sinv, ba = ab_entry(k, bb ? gB : gA);                            // (S^-1 of the previous stage: formed in the form this step takes)
 #pragma unroll
                 for (int pp = 0; pp < kMP; ++pp) if (pp == p - 1) { fC[pp] = fc; fV[pp] = fv; bC[pp] = bc; bA[pp] = ba; }
                 STAMP(5);
@@ -1136,7 +1137,7 @@ struct Solver {
                 wtd = transpose_d(wd);
                 STAMP(6);
                 Awd = rep_a(wd); Bwd = rep_b(wd);
-                sinv = mm8r(Awd, Bwd, 0.0);                                 // S^-1 = W' W
+                sinv = odd ? mm8r(Bwd, Awd, 0.0) : mm8r(Awd, Bwd, 0.0);     // S^-1 = W' W, in the form the NEXT step takes (an even one: exchanged)
                 STAMP(7);
                 cur = nxt;
             };
@@ -1169,7 +1170,7 @@ struct Solver {
             {   // link to the middle stage (forward step P, backward step P - 1: its operand x_m is in layout B), the middle
                 // pivot (type A) and wave 0's closing product [A|B]_0 x_0 (x_0 leaves the last backward step in layout B iff P is even)
                 constexpr bool fa = (P & 1) != 0, tb = ((P & 1) == 0) != kFlip;
-                fC[P - 1] = fa ? ltn : qswap(ltn); fV[P - 1] = fa ? sinv : qswap(sinv);
+                fC[P - 1] = fa ? ltn : qswap(ltn); fV[P - 1] = sinv;      // (sinv: already in the form of step P, see step())
                 bC[P - 1] = kFlip ? ln : qswap(ln); bA[P - 1] = ab_entry(kMid, kFlip ? gA : gB);     // (step P - 1 is of type B, of type A with kFlip)
                 mS = kFlip ? qswap(sm) : sm;
                 tT = ab_entry(0, tb ? gB : gA);
