@@ -171,3 +171,22 @@ def test_role_divergent_barrier_counts_are_checked(tmp_path):
         for kname, groups in ckr.role_barriers(f).items():
             for grp, counts in groups.items():
                 assert len(set(counts)) == 1 and counts[0] > 0, (kname, grp, counts)
+
+
+def test_hot_region_scan_follows_the_control_flow(tmp_path):
+    """tools/check_kernel_resources.py: the per-iteration code is what can EXECUTE between the HOT markers -- a block of the iteration
+    that the compiler laid out behind the loop (reached by a branch from inside the region) is counted and checked for scratch accesses,
+    a block of other code that merely sits between the markers in the text is not."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_kernel_resources as ckr
+    f = tmp_path / "k.s"
+    f.write_text("_Zk:\n\tv_mov_b32_e32 v1, v2\n\t; LPVMPC_HOT_BEGIN\n\tv_add_f64 v[2:3], v[2:3], v[4:5]\n\ts_cbranch_scc1 .LBB0_9\n"
+                 ".LBB0_2:\n\tv_mul_f64 v[2:3], v[2:3], v[4:5]\n\ts_branch .LBB0_3\n"
+                 ".LBB0_7:\n\tscratch_load_dwordx2 v[8:9], off, off\n\ts_endpgm\n"                 # other code, laid out in between: not reachable from the region
+                 ".LBB0_3:\n\t; LPVMPC_HOT_END\n\ts_endpgm\n"
+                 ".LBB0_9:\n\tscratch_store_dwordx2 off, v[2:3], off\n\ts_branch .LBB0_2\n"      # a block of the iteration behind the loop
+                 ".Lfunc_end0:\n")
+    h = ckr.hot_path(str(f))["_Zk"]
+    assert h == dict(instructions=6, scratch=1, scratch_stores=1, spill_lane_moves=0), h
+
