@@ -148,7 +148,7 @@ int lpvmpc_last_error_code(void);
  * "defer_tail" (0 | 1, default 1): the passes that run parked instances to completion (lpvmpc_join, the synchronous entry
  * points, "defer_budget" 0) use the whole-CU tail kernel where one exists for the handle (controller or planner, N = 20): a 512-thread
  * workgroup per instance that applies K^-1 as a dense matrix held in registers, runs two phases per ADMM iteration and evaluates the
- * termination checks beside the iterations (round 5: 1.0 us per iteration against 2.1 us for an instance that has the GPU to
+ * termination checks beside the iterations (round 5: 1.0 us per iteration against 1.9 us for an instance that has the GPU to
  * itself).  Handles with steering_delay > 0 keep the two-wavefront kernel for these passes.  Statuses, iteration counts and polish
  * flags have been OBSERVED equal to the other kernel's on every instance compared so far (196 608 over four tracks,
  * profiles/r05_tail_parity_sweep.txt; the seeds of tests/test_gpu_deferral.py are regression fixtures for this build) -- an
