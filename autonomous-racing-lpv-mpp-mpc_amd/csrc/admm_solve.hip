@@ -2869,7 +2869,17 @@ struct Solver {
     __device__ __forceinline__ int restore(const SolveArgs &a, int entry, int &iter, int &to_chk, int &to_adp) {
         const int n = (int)image_doubles(N);
         const double *src = a.pool_in + (size_t)entry * a.pool_stride;
-        for (int i = tid; i < n; i += kStride) tA[i] = src[i];
+        {   // the image, eight loads of a thread in flight at a time (the rolled loop waited for every one of its 40 global loads in turn)
+            int i = tid;
+            for (; i + 7 * kStride < n; i += 8 * kStride) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[i + u * kStride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tA[i + u * kStride] = v[u];
+            }
+            for (; i < n; i += kStride) tA[i] = src[i];
+        }
         // the MFMA sweeps read their zeros from SINK: an image parked by a kernel that uses the area otherwise (the DPP two-wavefront
         // factorisation hands a tile through it) must not bring its contents along -- lpvmpc_set_option joins parked work before a
         // kernel_variant change, this makes the kernel itself safe
@@ -2922,6 +2932,23 @@ struct Solver {
         sync();
         {
             const double *src = a.AB + (size_t)inst * N * NX * NB;
+            if constexpr (kFixN) {
+                // every load of the thread in flight at once (round 5: the rolled loop waited for each of its eight global loads in turn --
+                // 6 us of a 250 us solve)
+                constexpr int kTotal = NT * NX * NB, kTrips = (kTotal + kStride - 1) / kStride;
+                double v[kTrips];
+#pragma unroll
+                for (int i = 0; i < kTrips; ++i) { const int e = tid + i * kStride; v[i] = src[e < kTotal ? e : kTotal - 1]; }
+#pragma unroll
+                for (int i = 0; i < kTrips; ++i) {
+                    const int e = tid + i * kStride;
+                    if (e < kTotal) {
+                        const int k = e / (NX * NB), rem = e - k * (NX * NB), r = rem / NB, col = rem - r * NB;
+                        bad |= !__builtin_isfinite(v[i]);
+                        tA[k * kTS + r * 8 + col] = v[i];
+                    }
+                }
+            } else
             for (int e = tid; e < N * NX * NB; e += kStride) {
                 const int k = e / (NX * NB), rem = e - k * (NX * NB), r = rem / NB, col = rem - r * NB;
                 const double v = src[e];
@@ -2933,12 +2960,28 @@ struct Solver {
         const double uo0 = a.u_old ? a.u_old[(size_t)inst * uos + 0] : 0.0, uo1 = a.u_old ? a.u_old[(size_t)inst * uos + 1] : 0.0;
         const double mey = (!kCtrl && a.max_ey) ? a.max_ey[inst] : 0.0;
         bad |= !__builtin_isfinite(uo0) || !__builtin_isfinite(uo1) || !__builtin_isfinite(mey);
-        for (int e = opaque(tid); e < NS * 8; e += kStride) {
+        // (the reference velocities of this thread's elements, every round's load in flight before the first use)
+        constexpr int kVr = kFixN ? ((NT + 1) * 8 + kStride - 1) / kStride : 1;
+        double vref[kVr];
+        if constexpr (kCtrl && kFixN) {
+#pragma unroll
+            for (int i = 0; i < kVr; ++i) { const int k_ = (tid + i * kStride) >> 3; vref[i] = a.vel_ref[(size_t)inst * (N + 1) + (k_ < N ? k_ : N)]; }
+        }
+        int round_ = 0;
+        for (int e = opaque(tid); e < NS * 8; e += kStride, ++round_) {
             const int k = e >> 3, r = e & 7;
             // linear cost: controller q = -2 xtrack' M0 (CTRL:434-447); planner q = L_cf (PLAN:163)
             double q = 0.0;
             if (r < NX) {
-                if (kCtrl) q = -cfg.Q[0 * NX + r] * 2.0 * a.vel_ref[(size_t)inst * (N + 1) + k];
+                if (kCtrl) {
+                    double vr_;
+                    if constexpr (kFixN) {
+                        vr_ = vref[0];
+#pragma unroll
+                        for (int i = 1; i < kVr; ++i) if (round_ == i) vr_ = vref[i];
+                    } else vr_ = a.vel_ref[(size_t)inst * (N + 1) + k];
+                    q = -cfg.Q[0 * NX + r] * 2.0 * vr_;
+                }
                 else q = cfg.Lcf[r];
             } else if (r < NB && k == 0) q = -2.0 * (r == NX ? uo0 : uo1) * cfg.dR[r - NX];   // CTRL:462 / PLAN:167
             bad |= !__builtin_isfinite(q);
