@@ -393,8 +393,12 @@ static int is_primal_infeasible(work_t *w, double eps) {
         if (lhs < -eps * nd) {
             mat_tpose_vec(w->A, w->delta_y, w->Atdelta_y, 0, 0);
             if (w->s.scaling && !w->s.scaled_termination) for (int j = 0; j < w->n; j++) w->Atdelta_y[j] *= w->Dinv[j];
+            /* diagnostic (tests/diagnostics/certificate_margin.py; single-threaded callers only): the margins of the certificate */
+            if (getenv("OSQP_REF_TRACE")) fprintf(stderr, "osqp_ref primal certificate at iter %d: |dy| %.17g  u'dy+ + l'dy- %.17g (< %.17g)  |A'dy| %.17g (< %.17g: %d)\n",
+                                                  w->info.iter, nd, lhs, -eps * nd, norm_inf(w->Atdelta_y, w->n), eps * nd, norm_inf(w->Atdelta_y, w->n) < eps * nd);
             return norm_inf(w->Atdelta_y, w->n) < eps * nd;
         }
+        if (getenv("OSQP_REF_TRACE")) fprintf(stderr, "osqp_ref primal certificate at iter %d: |dy| %.17g  u'dy+ + l'dy- %.17g (not < %.17g)\n", w->info.iter, nd, lhs, -eps * nd);
     }
     return 0;
 }

@@ -1,8 +1,12 @@
 """Test infrastructure: the stated float tolerance of the QP stage (include/lpvmpc.h) as code.
 
-Against the CPU oracle on identical data, status and iteration count are EQUAL (the one documented exception: a run that ends at
-max_iter, where OSQP's "solved inaccurate" test -- 10 eps -- is decided by round-off: MAX_ITER_REACHED on one side,
-SOLVED_INACCURATE on the other, same iteration count) and the solution falls in one of three classes:
+Against the CPU oracle on identical data, status and iteration count are EQUAL, with two documented exceptions:
+  (1) a run that ends at max_iter, where OSQP's "solved inaccurate" test -- 10 eps -- is decided by round-off: MAX_ITER_REACHED on
+      one side, SOLVED_INACCURATE on the other, same iteration count (one instance of the 110 202 of the wide sweep: oval, sweep
+      seed 0, planner N = 20);
+  (2) class D below: a PRIMAL INFEASIBLE planner QP whose certificate fires one termination check (25 iterations) apart (one
+      instance of 110 202: Euge_Track, sweep seed 4, planner N = 40, #393 -- device 50, batch oracle 75).
+The solution falls in one of three classes:
 
   A  polished (status SOLVED, polish flag 1): both sit on the active-set optimum            -> |dx|, |du| <= 1e-6
   B  un-polished, converged (SOLVED without a successful polish, SOLVED_INACCURATE before the cap): the two implementations run
@@ -11,10 +15,20 @@ SOLVED_INACCURATE on the other, same iteration count) and the solution falls in 
      point is an UNCONVERGED ADMM iterate of an ill-conditioned planner QP (P has 31 near-zero eigenvalues; the
      forward-Euler model grows like 2^N); 4000 iterations amplify the round-off difference of the two implementations.  OSQP
      guarantees nothing for such a point and the reference uses it as it comes (CTRL:322-324, PLAN:214-216).  Held: same iteration
-     count (the cap), statuses within {MAX_ITER_REACHED, SOLVED_INACCURATE}, |du| <= 5e-2 (observed over 110 202 instances: 42 in
+     count (the cap), statuses within {MAX_ITER_REACHED, SOLVED_INACCURATE}, |du| <= 2e-2 (observed over 110 202 instances: 42 in
      this class, |du| <= 1.01e-2, 40 of them with the objective within 1e-3 and the primal residual inside the status's tolerance;
-     profiles/r05_parity_sweep.txt lists every one).
+     profiles/r06_parity_sweep.txt lists every one).  The class carries NO objective bound: two of the 42 (3110, sweep seed 1,
+     planner N = 20 / 30, #63) differ from the oracle's point by 1.8e-2 / 2.8e-4 in the objective.
 Every instance of the wide sweep (tests/diagnostics/seed_sweep.py) beyond 1e-6 is in class C.
+
+  D  no solution on either side (PRIMAL / DUAL INFEASIBLE, exact or inaccurate: NaN outputs, equal statuses): the iterates of an
+     infeasible QP diverge, K is as ill-conditioned as it gets (forward-Euler growth 1.7^40 at N = 40) and the certificate's third
+     test, |A' dy| < eps |dy|, is then decided by the round-off of the KKT solve -- THE ORACLE ITSELF stops one check apart under its
+     two elimination orders of the same KKT matrix (oracle/lpv_ref.c hands osqp_ref.c the stage-wise order, oracle/osqp_ref.py's
+     solve_qp the RCM order of the assembled matrices: 75 against 50 iterations on the named instance, |dy| 12 037 against 567 at the
+     check of iteration 25; tests/diagnostics/certificate_margin.py prints the margins).  Held: equal statuses, no solution on either
+     side, and the device's iteration count equals the oracle's under ONE of its two elimination orders.  The reference discards
+     such a result whatever its iteration count (feasible = 0: CTRL:320-324, PLAN:214-216).
 """
 import numpy as np
 
@@ -22,6 +36,22 @@ from oracle import lpv_ref as L
 
 P = dict(L.DEFAULT_PARAMS)
 SOLVED, SOLVED_INACC, MAX_ITER = 1, 2, -2
+NO_SOLUTION = (-3, 3, -4, 4)        # primal / dual infeasible, exact or inaccurate
+CLASS_C_DU = 2e-2                   # (round 6: 5e-2 -> 2e-2; observed <= 1.01e-2)
+
+
+def class_d(w, kind, j, out, ref):
+    """Class D: an infeasible QP whose certificate fires one check apart.  True iff statuses are equal, neither side returns a
+    solution and the device's iteration count is the oracle's under its OTHER elimination order (solve_qp: RCM) of the same data."""
+    from oracle import osqp_ref as O
+    st, sr = int(out["status"][j]), int(ref["status"][j])
+    if st != sr or st not in NO_SOLUTION:
+        return False
+    if np.isfinite(out["uPred"][j]).any() or np.isfinite(ref["uPred"][j]).any():
+        return False
+    qp = instance_qp(w, kind, j)
+    r = O.solve_qp(qp.P, qp.q, qp.A, qp.l, qp.u)
+    return r.info.status_val == st and int(r.info.iter) == int(out["iters"][j])
 
 
 def instance_qp(w, kind, j):
@@ -30,8 +60,7 @@ def instance_qp(w, kind, j):
     if kind == "controller":
         S, A, B = L.ctrl_lpv_prediction(p, w["dt"], N, w["track"], w["x0"][j], w["u_prev"][j], w["vel_ref"][j],
                                         None if w["curv_s"] is None else w["curv_s"][j], w["cf_new"], w["lap"])
-        x0 = w["x0"][j] if int(w["lap"]) == 0 else w["x0"][j]
-        return L.ctrl_build_qp(w["Q"], w["R"], w["dR"], N, A, B, x0, w["u_old"][j], w["vel_ref"][j], p["max_vel"])
+        return L.ctrl_build_qp(w["Q"], w["R"], w["dR"], N, A, B, w["x0"][j], w["u_old"][j], w["vel_ref"][j], p["max_vel"])
     S, A, B = L.plan_lpv_prediction(p, w["dt"], N, w["track"], w["x0"][j], w["curv_s"][j], w["u_prev"][j])
     mey = float(np.broadcast_to(w["max_ey"], (w["x0"].shape[0],))[j])
     return L.plan_build_qp(w["Q"], w["R"], w["dR"], w["L_cf"], N, A, B, w["x0"][j], w["u_old"][j], mey, p["max_vel"], p["min_vel"])
@@ -69,7 +98,7 @@ def outlier_report(w, kind, j, out, ref):
         why.append("status (only runs that end at the cap may differ beyond class B)")
     if not capped:
         why.append("iterations (not at the cap)")
-    if du > 5e-2:
+    if du > CLASS_C_DU:
         why.append("|du|")
     lim = tol if st == SOLVED else (10.0 * tol if st == SOLVED_INACC else float("inf"))      # (informative: a MAX_ITER point met no rule)
     return dict(status=st, status_ref=st_ref, polish=pol, iters=int(out["iters"][j]), iters_ref=int(ref["iters"][j]), du=du, obj_gap=gap,
@@ -79,13 +108,15 @@ def outlier_report(w, kind, j, out, ref):
 def check_batch(w, kind, out, ref, allow_status_flip_at_max_iter=True):
     """The whole rule set on a batch; returns counts per class and raises AssertionError on the first violation."""
     sane = (ref["status"] != -10) & ~(np.isnan(ref["uPred"]).any(axis=(1, 2)) & (ref["status"] == 1))
-    counts = dict(A=0, B=0, C=0, no_solution=0, flips=0)
+    counts = dict(A=0, B=0, C=0, D=0, no_solution=0, flips=0)
     for j in np.nonzero(sane)[0]:
         st, sr = int(out["status"][j]), int(ref["status"][j])
         if st != sr:
             assert allow_status_flip_at_max_iter and {st, sr} <= {SOLVED_INACC, MAX_ITER} and int(out["iters"][j]) == int(ref["iters"][j]), (int(j), st, sr)
             counts["flips"] += 1
-        assert int(out["iters"][j]) == int(ref["iters"][j]), (int(j), int(out["iters"][j]), int(ref["iters"][j]))
+        if int(out["iters"][j]) != int(ref["iters"][j]):
+            assert class_d(w, kind, int(j), out, ref), (int(j), st, sr, int(out["iters"][j]), int(ref["iters"][j]))
+            counts["D"] += 1
         fo, fr = np.isfinite(out["uPred"][j]).all(), np.isfinite(ref["uPred"][j]).all()
         assert fo == fr, (int(j), "finite", fo, fr)
         if not fo:

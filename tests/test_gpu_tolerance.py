@@ -20,7 +20,7 @@ def test_planner_on_the_other_tracks_against_oracle(shape, N):
     one of the three stated classes (polished 1e-6; un-polished 2e-4; beyond that an eps-iterate of an ill-conditioned planner QP,
     held to OSQP's own guarantee -- objective within 1e-3 of the oracle's point, primal residual within the status's tolerance)."""
     from lpvmpc import workloads
-    total = dict(A=0, B=0, C=0, no_solution=0, flips=0)
+    total = dict(A=0, B=0, C=0, D=0, no_solution=0, flips=0)
     for seed in (200, 201):
         w = workloads.planner_batch(256, N=N, seed=seed, shape=shape)
         eng = workloads.make_solver(w)
@@ -31,7 +31,28 @@ def test_planner_on_the_other_tracks_against_oracle(shape, N):
         for k in total:
             total[k] += c[k]
     assert total["A"] + total["B"] >= 0.9 * (total["A"] + total["B"] + total["C"]), total      # class C is the exception, not the rule
-    assert total["A"] > 0 and total["no_solution"] < 512, total
+    # (planner batches of this distribution: about a seventh primal infeasible -- slow starts, forward-Euler growth)
+    assert total["A"] > 0 and total["no_solution"] <= 0.3 * 512 and total["D"] <= 1, total
+
+
+def test_infeasibility_certificate_one_check_apart_is_the_only_iteration_difference():
+    """`Euge_Track, sweep seed 4 (workload seed 204), planner N = 40` of the wide sweep: the ONE instance of 110 202 whose iteration
+    count differs from the batch oracle's (#393: PRIMAL INFEASIBLE on both sides, NaN outputs; device 50 iterations, oracle 75).
+    Class D of tests/_tolerance.py: the oracle itself stops at 50 under its other elimination order of the same KKT matrix -- the
+    certificate's |A'dy| < eps |dy| test on a diverging iterate is decided by the round-off of the KKT solve.  Everything else
+    about the batch follows the stated classes; the reference discards such a tick either way (PLAN:214-216)."""
+    from lpvmpc import workloads
+    w = workloads.planner_batch(512, N=40, seed=204, shape="Euge_Track")
+    eng = workloads.make_solver(w)
+    out = eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
+    eng.close()
+    ref = O.plan_tick_batch(w, nthreads=16)
+    c = T.check_batch(w, "planner", out, ref)
+    sane = ref["status"] != -10
+    diff = np.nonzero((out["iters"] != ref["iters"]) & sane)[0]
+    assert c["D"] == len(diff) <= 1, (c, diff.tolist())
+    for j in diff:
+        assert int(out["status"][j]) == int(ref["status"][j]) == -3 and abs(int(out["iters"][j]) - int(ref["iters"][j])) == 25, (int(j), out["iters"][j], ref["iters"][j])
 
 
 def test_max_iter_status_decided_by_round_off_is_the_only_status_difference():
