@@ -69,7 +69,7 @@ EXPORTS = ("lpvmpc_version", "lpvmpc_default_config", "lpvmpc_create", "lpvmpc_d
            "lpvmpc_solve_batch", "lpvmpc_solve_batch_dev", "lpvmpc_last_kernel_ms", "lpvmpc_set_timing",
            "lpvmpc_kernel_time_stats", "lpvmpc_set_option",
            "lpvmpc_local_position_batch", "lpvmpc_global_position_batch", "lpvmpc_plant_step_batch",
-           "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read", "lpvmpc_cl_release", "lpvmpc_join", "lpvmpc_resume_time_stats",
+           "lpvmpc_cl_init", "lpvmpc_cl_tick", "lpvmpc_cl_read", "lpvmpc_cl_release", "lpvmpc_join", "lpvmpc_resume_time_stats", "lpvmpc_defer_stats",
            "lpvmpc_handoff_default_config", "lpvmpc_handoff_length", "lpvmpc_handoff_operators", "lpvmpc_handoff_setup",
            "lpvmpc_handoff_batch", "lpvmpc_cascade_init", "lpvmpc_cascade_tick", "lpvmpc_cascade_read", "lpvmpc_cascade_alive_ticks")
 
@@ -142,6 +142,11 @@ def load():
     lib.lpvmpc_cl_release.argtypes = [vp]
     lib.lpvmpc_join.argtypes = [vp, vp]
     lib.lpvmpc_resume_time_stats.argtypes = [vp, P(_d), P(_i)]
+    try:        # (tools/ab_equal.py / ab_lib.sh load older builds of the library through this module: round 5's has no such export)
+        lib.lpvmpc_defer_stats.argtypes = [vp, P(C.c_int64), P(C.c_int64)]
+        lib.lpvmpc_defer_stats.restype = C.c_int
+    except AttributeError:
+        pass
     lib.lpvmpc_handoff_default_config.argtypes = [P(HandoffConfig)]
     lib.lpvmpc_handoff_default_config.restype = None
     lib.lpvmpc_handoff_length.argtypes = [_i, _d, P(HandoffConfig)]

@@ -134,6 +134,13 @@ class BatchedSolver:
         outputs of the deferred calls are complete for work enqueued on ``stream`` afterwards."""
         self._chk(self._lib.lpvmpc_join(self._h, C.c_void_p(int(stream))))
 
+    def defer_stats(self):
+        """(parked, refused) of the straggler deferral since the handle's first deferred call (lpvmpc_defer_stats: waits for the
+        stream of the last deferred call)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.lpvmpc_defer_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def resume_time_stats(self):
         tot = C.c_double(0.0); n = C.c_int32(0)
         self._chk(self._lib.lpvmpc_resume_time_stats(self._h, C.byref(tot), C.byref(n)))

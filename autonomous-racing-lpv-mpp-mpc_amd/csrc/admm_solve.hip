@@ -395,6 +395,28 @@ struct Solver {
         return SumMax{s_, m_};
     }
 
+    // The planner at N = 30 / 40 has a two- and a four-wavefront form of ONE arithmetic (launch_solve picks by the shape of the launch,
+    // lpvmpc.h promises that every output word is the same either way).  A block-wide SUM associates by the number of wavefronts
+    // (rounds of kStride elements per thread, then wave sums, then the wavefronts' partial results), so in these kernels every sum
+    // whose value reaches a decision -- the cost normalisation of the equilibration, the two infeasibility certificates, the objective
+    // value -- is added up in one order: the elements' terms go through AT (free wherever such a sum is taken), wavefront 0 adds them
+    // lane by lane and then across the lanes (round 5: the objective; round 6: the other three).  Maxima are exact and stay as they are.
+    static constexpr bool kFixedSums = MF && NT >= 30;
+    // the caller has stored the terms to AT[0 .. 8 NS)
+    __device__ __forceinline__ double ordered_total() const {
+        sync();
+        if (wv == 0) {
+            double v = 0.0;
+            for (int e = opaque(lane); e < NS * 8; e += 64) v += AT[e];
+            v = wave_sum(v);
+            if (lane == 0) RED[0] = v;
+        }
+        sync();
+        const double v = RED[0];
+        sync();
+        return v;
+    }
+
     // ---- operators on the scaled problem ---------------------------------------------------------
     // After equilibration the products that every A / A' application needs are cached in the two unused
     // rows of each stage tile:  Eid[k][r] = Ed D (identity part of dynamics row r; 0 for padding) at
@@ -637,20 +659,24 @@ struct Solver {
             sync();
             // cost normalisation (with the new D)
             double psum = 0.0, qmax = 0.0;
-            if constexpr (kFuseS) if (fuse2_wave()) {
+            if constexpr (kFuseS) { if (fuse2_wave()) {
                 const int e0 = tid, e1 = tid + kStride;
                 const bool on1 = e1 < NS * 8;
                 const int e1c = on1 ? e1 : e0;
                 const CostIn q0 = cost_load(e0, Dn), q1 = cost_load(e1c, Dn);
                 const double p0 = cost_form(e0, q0), p1 = cost_form(e1c, q1);
                 pacc[0] = p0; pacc[1] = p1;
-                psum += p0 * c * q0.de;
+                const double m1 = fabs(c * q1.de * q1.qv);
+                if constexpr (kFixedSums) { AT[e0] = p0 * c * q0.de; AT[e1c] = p1 * c * q1.de; }      // (no second element: the first one's term once more)
+                else {
+                    psum += p0 * c * q0.de;
+                    const double ps1 = psum + p1 * c * q1.de;     // (the sum in the shape of the plain loop's: the same contraction)
+                    psum = on1 ? ps1 : psum;
+                }
                 qmax = fmax(qmax, fabs(c * q0.de * q0.qv));
-                const double ps1 = psum + p1 * c * q1.de, m1 = fabs(c * q1.de * q1.qv);     // (the sum in the shape of the plain loop's: the same contraction)
-                psum = on1 ? ps1 : psum;
                 qmax = fmax(qmax, on1 ? m1 : 0.0);
                 fused = true;
-            } else fused = false;
+            } else fused = false; }
             if (fused) { }
             else if constexpr (kReg) {
 #pragma unroll
@@ -658,7 +684,7 @@ struct Solver {
                     const int e = tid + r * kStride;
                     if (e < NS * 8) {
                         pacc[r] = P_row_d<true, true>(e >> 3, Dn, Dn);
-                        psum += pacc[r] * c * Dn[e];
+                        if constexpr (kFixedSums) AT[e] = pacc[r] * c * Dn[e]; else psum += pacc[r] * c * Dn[e];
                         qmax = fmax(qmax, fabs(c * Dn[e] * Qv[e]));
                     }
                 }
@@ -668,7 +694,9 @@ struct Solver {
                     qmax = fmax(qmax, fabs(c * Dn[e] * Qv[e]));
                 }
             }
-            const SumMax pq = bsum_bmax<0>(psum, qmax);
+            SumMax pq;
+            if constexpr (kFixedSums) { pq.s = ordered_total(); pq.m = bmax<0>(qmax); }     // (one summation order for the two forms of these kernels: see kFixedSums)
+            else pq = bsum_bmax<0>(psum, qmax);
             psum = pq.s / (double)ntrue;
             qmax = limit_scaling(pq.m);
             const double ct = limit_scaling(fmax(psum, qmax));
@@ -676,6 +704,115 @@ struct Solver {
         };
         const int n_it = cfg.scaling;
         int it = 0;
+        if constexpr (kFuseS) {
+            // Round 6: the passes behind the first keep what does not change between passes in REGISTERS -- the element's column of [A|B]_k,
+            // its row of [A|B]_{k-1}, q, the thread's row of the Hessian block (38 doubles for two elements) -- and the element's own
+            // scalings, which are the previous pass's results.  A pass then loads the neighbours' scalings only (24 instead of 47 values
+            // per element): the equilibration is bound by the LDS pipe at four instances per CU (all of them start with it at once).
+            // norm_form / cost_form and their operands are those of the fused form in pass(): every scaling is unchanged, bit for bit.
+            if (n_it >= 1) { pass(true, D, Ed, Eb, XT, ZTd, ZTb); it = 1; }
+            if (n_it >= 2) {
+                const bool two = fuse2_wave();
+                const int e0 = tid, e1 = tid + kStride;
+                const bool on1 = two && e1 < NS * 8;
+                const int e1c = on1 ? e1 : e0;
+                struct EC { double col[NX], row[NB], qv; };
+                auto consts = [&](int e) {
+                    EC c_;
+                    const int k = e >> 3, a = tj, kp = k > 0 ? k - 1 : 0;
+                    const double *col = tA + k * kTS + a, *row = tA + kp * kTS + a * 8;
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) c_.col[r] = col[r * 8];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) c_.row[b] = row[b];
+                    c_.qv = Qv[e];
+                    return c_;
+                };
+                const EC c0 = consts(e0), c1 = consts(e1c);
+                double prow[8];
+                {
+                    const double2 *pr = reinterpret_cast<const double2 *>(Pm + tj * 8);
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) { const double2 p = pr[h]; prow[2 * h] = p.x; prow[2 * h + 1] = p.y; }
+                }
+                // the thread's own scalings (the first pass left them in XT / ZTd / ZTb) and un-scaled Hessian column norms
+                double sd[2] = {XT[e0], XT[e1c]}, se[2] = {ZTd[e0], ZTd[e1c]}, sb[2] = {ZTb[e0], ZTb[e1c]};
+                if (!on1) pacc[1] = pacc[0];
+                auto nload = [&](int e, const EC &ec, int i, const double *Ds, const double *Es, const double *Bs) {
+                    NormIn q;
+                    const int k = e >> 3, kn = k < N ? k + 1 : N, kp = k > 0 ? k - 1 : 0;
+                    q.de = sd[i]; q.ede = se[i]; q.ebe = sb[i];
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) { q.col[r] = ec.col[r]; q.es[r] = Es[kn * 8 + r]; }
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) { q.row[b] = ec.row[b]; q.ds[b] = Ds[kp * 8 + b]; }
+                    q.b0 = Bs[k * 8 + r0]; q.b1 = Bs[k * 8 + r1]; q.b2 = Bs[k * 8 + r2]; q.dbv = Ds[k * 8 + bvar];
+                    return q;
+                };
+                auto cload = [&](int e, const EC &ec, int i, const double *Dn) {
+                    CostIn q;
+                    const int k = e >> 3;
+                    const double2 *dr = reinterpret_cast<const double2 *>(Dn + k * 8);
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) { const double2 d = dr[h]; q.pr[2 * h] = prow[2 * h]; q.pr[2 * h + 1] = prow[2 * h + 1]; q.dr[2 * h] = d.x; q.dr[2 * h + 1] = d.y; }
+                    const int en = (k + 1 < N) ? e + 8 : e, ep = (k >= 1) ? e - 8 : e;
+                    q.dnx = Dn[en]; q.dpv = Dn[ep]; q.de = sd[i]; q.qv = ec.qv;
+                    return q;
+                };
+                auto rpass = [&](const double *Ds, const double *Es, const double *Bs, double *Dn, double *En, double *Bn) {
+                    if (two) {
+                        const NormIn q0 = nload(e0, c0, 0, Ds, Es, Bs), q1 = nload(e1c, c1, 1, Ds, Es, Bs);
+                        const NormOut o0 = norm_form(e0, q0, pacc[0] * c * q0.de, r0, r1, r2), o1 = norm_form(e1c, q1, pacc[1] * c * q1.de, r0, r1, r2);
+                        Dn[e0] = o0.d; En[e0] = o0.e; Bn[e0] = o0.b;
+                        Dn[e1c] = o1.d; En[e1c] = o1.e; Bn[e1c] = o1.b;
+                        sd[0] = o0.d; se[0] = o0.e; sb[0] = o0.b; sd[1] = o1.d; se[1] = o1.e; sb[1] = o1.b;
+                    } else {
+                        const NormIn q0 = nload(e0, c0, 0, Ds, Es, Bs);
+                        const NormOut o0 = norm_form(e0, q0, pacc[0] * c * q0.de, r0, r1, r2);
+                        Dn[e0] = o0.d; En[e0] = o0.e; Bn[e0] = o0.b;
+                        sd[0] = o0.d; se[0] = o0.e; sb[0] = o0.b;
+                    }
+                    sync();
+                    double psum = 0.0, qmax = 0.0;
+                    if (two) {
+                        const CostIn q0 = cload(e0, c0, 0, Dn), q1 = cload(e1c, c1, 1, Dn);
+                        const double p0 = cost_form(e0, q0), p1 = cost_form(e1c, q1);
+                        pacc[0] = p0; pacc[1] = p1;
+                        const double m1 = fabs(c * q1.de * q1.qv);
+                        if constexpr (kFixedSums) { AT[e0] = p0 * c * q0.de; AT[e1c] = p1 * c * q1.de; }
+                        else {
+                            psum += p0 * c * q0.de;
+                            const double ps1 = psum + p1 * c * q1.de;
+                            psum = on1 ? ps1 : psum;
+                        }
+                        qmax = fmax(qmax, fabs(c * q0.de * q0.qv));
+                        qmax = fmax(qmax, on1 ? m1 : 0.0);
+                    } else {
+                        const CostIn q0 = cload(e0, c0, 0, Dn);
+                        const double p0 = cost_form(e0, q0);
+                        pacc[0] = p0;
+                        if constexpr (kFixedSums) AT[e0] = p0 * c * q0.de; else psum += p0 * c * q0.de;
+                        qmax = fmax(qmax, fabs(c * q0.de * q0.qv));
+                    }
+                    SumMax pq;
+                    if constexpr (kFixedSums) { pq.s = ordered_total(); pq.m = bmax<0>(qmax); }
+                    else pq = bsum_bmax<0>(psum, qmax);
+                    psum = pq.s / (double)ntrue;
+                    qmax = limit_scaling(pq.m);
+                    const double ct = limit_scaling(fmax(psum, qmax));
+                    c *= 1.0 / ct;
+                };
+                for (; it + 1 < n_it; it += 2) {
+                    rpass(XT, ZTd, ZTb, D, Ed, Eb);
+                    rpass(D, Ed, Eb, XT, ZTd, ZTb);
+                }
+                if (it < n_it) { rpass(XT, ZTd, ZTb, D, Ed, Eb); ++it; }
+            }
+            if (n_it & 1) {         // odd count: the result sits in the alternate arrays
+                for (int e = opaque(tid); e < NS * 8; e += kStride) { D[e] = XT[e]; Ed[e] = ZTd[e]; Eb[e] = ZTb[e]; }
+                sync();
+            }
+        } else {
         for (; it + 1 < n_it; it += 2) {
             pass(it == 0, D, Ed, Eb, XT, ZTd, ZTb);
             pass(false, XT, ZTd, ZTb, D, Ed, Eb);
@@ -684,6 +821,7 @@ struct Solver {
             pass(it == 0, D, Ed, Eb, XT, ZTd, ZTb);
             for (int e = opaque(tid); e < NS * 8; e += kStride) { D[e] = XT[e]; Ed[e] = ZTd[e]; Eb[e] = ZTb[e]; }
             sync();
+        }
         }
         cinv = 1.0 / c;
         if constexpr (kUniScalars) { c = unid(c); cinv = unid(cinv); }
@@ -2096,22 +2234,9 @@ struct Solver {
     __device__ __forceinline__ double objective(const double *xv) {
         P_mul(xv, VT);
         sync();
-        if constexpr (MF && NT >= 30) {
-            // The planner at N = 30 / 40 has a two- and a four-wavefront form of one arithmetic (launch_solve picks by batch size): the
-            // objective is the one sum whose association would depend on the number of wavefronts, so these kernels add the elements'
-            // terms in ONE order -- the terms go through AT (free here), wavefront 0 adds them lane by lane, then across the lanes.
+        if constexpr (kFixedSums) {     // (one summation order for the two forms of these kernels: see kFixedSums)
             for (int e = opaque(tid); e < NS * 8; e += kStride) AT[e] = xv[e] * (0.5 * VT[e] + Qv[e]);
-            sync();
-            if (wv == 0) {
-                double v = 0.0;
-                for (int e = opaque(lane); e < NS * 8; e += 64) v += AT[e];
-                v = wave_sum(v);
-                if (lane == 0) RED[0] = v;
-            }
-            sync();
-            const double v = RED[0] * cinv;
-            sync();
-            return v;
+            return ordered_total() * cinv;
         }
         double v = 0.0;
         for (int e = opaque(tid); e < NS * 8; e += kStride) v += xv[e] * (0.5 * VT[e] + Qv[e]);
@@ -2140,12 +2265,21 @@ struct Solver {
         bool res = false;
         if (nd > eps) {
             double lhs = 0.0;
+            if constexpr (kFixedSums) {         // (the element's term with explicit fused operations: the same bits in both forms of the kernel)
+                for (int e = opaque(tid); e < NS * 8; e += kStride) {
+                    const double b = dyn_bound(e), dyd = DYd[e], dyb = DYb[e];
+                    const double td = __builtin_fma(b, fmax(dyd, 0.0), b * fmin(dyd, 0.0)), tb = __builtin_fma(Hi[e], fmax(dyb, 0.0), Lo[e] * fmin(dyb, 0.0));
+                    AT[e] = td + tb;
+                }
+                lhs = ordered_total();
+            } else {
             for (int e = opaque(tid); e < NS * 8; e += kStride) {
                 const double b = dyn_bound(e), dyd = DYd[e], dyb = DYb[e];
                 lhs += b * fmax(dyd, 0.0) + b * fmin(dyd, 0.0);
                 lhs += Hi[e] * fmax(dyb, 0.0) + Lo[e] * fmin(dyb, 0.0);
             }
             lhs = bsum<1>(lhs);
+            }
             if (lhs < -eps * nd) {
                 At_mul(DYd, DYb, AT);
                 sync();
@@ -2160,8 +2294,13 @@ struct Solver {
     }
     __device__ __forceinline__ bool dual_infeasible(double eps) {
         double nd = 0.0, qdx = 0.0;
+        if constexpr (kFixedSums) {
+            for (int e = opaque(tid); e < NS * 8; e += kStride) { nd = fmax(nd, fabs(D[e] * DX[e])); AT[e] = Qv[e] * DX[e]; }
+            qdx = ordered_total(); nd = bmax<3>(nd);
+        } else {
         for (int e = opaque(tid); e < NS * 8; e += kStride) { nd = fmax(nd, fabs(D[e] * DX[e])); qdx += Qv[e] * DX[e]; }
         { const SumMax qn = bsum_bmax<3>(qdx, nd); qdx = qn.s; nd = qn.m; }
+        }
         bool res = false;
         if (nd > eps && qdx < -c * eps * nd) {
             P_mul(DX, VT);
@@ -2207,24 +2346,11 @@ struct Solver {
             // run (16-byte loads, half the LDS instructions of the broadcast reads at stride 8); the last slots spill a few words into AT,
             // which only the termination checks use
             for (int e = opaque(tid); e < NS * 8; e += kStride) VT[(e & 7) * kRhsPitch + (e >> 3)] = At_elem(e, ZTd, ZTb, lc) + (sigma * X[e] - Qv[e]);
-        } else if constexpr (kUniScalars && kMf && kTwo) {
+        } else if constexpr (kUniScalars && kMf && kTwo && !kRegState) {
             // (round 5: the rounds unrolled from the plain thread index, like update(): their LDS addresses are loop invariants the
-            // compiler may keep in registers now)
+            // compiler may keep in registers now.  The kernels with the element state in registers -- kRegState -- run this form once in
+            // 25 iterations: they take the rolled loop below, whose addresses are formed where they are used)
             constexpr int kRounds = ((NT + 1) * 8 + kStride - 1) / kStride;
-            if constexpr (kFuse2) {
-                // both rounds of a wavefront in one basic block (see update(); the pinned-steering row is a uniform branch inside At_elem)
-                if (!(kCtrl && delay > 0) && fuse2_wave()) {
-                    const int e0 = tid, e1 = tid + kStride;
-                    const bool on1 = e1 < NS * 8;
-                    const int e1c = on1 ? e1 : e0;
-                    const RhsIn a0 = rhs_load(e0, lc), a1 = rhs_load(e1c, lc);       // (all loads of both rounds first, in the source too)
-                    const double v0 = rhs_form(a0, sigma), v1 = rhs_form(a1, sigma);
-                    XT[e0] = v0;
-                    XT[e1c] = v1;               // (no second element: v1 == v0, stored again)
-                    if constexpr (SYNC) sync();
-                    return;
-                }
-            }
 #pragma unroll
             for (int r = 0; r < kRounds; ++r) {
                 const int e = tid + r * kStride;
@@ -2269,55 +2395,122 @@ struct Solver {
     __device__ __forceinline__ bool fuse2_wave() const { return __builtin_amdgcn_readfirstlane(kStride + 64 * wv) < NS * 8; }
     // right-hand side element: At_elem (without the pinned-steering row) + sigma x - q, loads and arithmetic apart
     struct RhsIn { double c_[NX], d_[NX], sb0, sb1, w0, w1, ei, wd, x, q; };
-    __device__ __forceinline__ RhsIn rhs_load(int e, const LaneC &lc) const {
+    // (the fused operations written out: what the compiler contracts `a b + c d` into depends on the code around it -- with implicit
+    // contraction the register form of the element phases differed from the LDS form in the last bits.  These are the operations of
+    // round 5's build, read off its assembly; the LDS forms -- At_elem, update()'s element() -- compile to the same ones: tools/ab_equal.py)
+    __device__ __forceinline__ double rhs_form(const RhsIn &r, double sigma) const {
+        double acc0 = __builtin_fma(r.c_[0], r.d_[0], r.c_[1] * r.d_[1]);
+        const double acc1 = __builtin_fma(r.c_[2], r.d_[2], r.c_[3] * r.d_[3]);
+#pragma unroll
+        for (int i = 4; i < NX; ++i) acc0 = __builtin_fma(r.c_[i], r.d_[i], acc0);
+        const double boxes = __builtin_fma(r.sb0, r.w0, r.sb1 * r.w1);
+        const double dyn = __builtin_fma(r.ei, r.wd, -(acc1 + acc0));
+        return (boxes + dyn) + __builtin_fma(sigma, r.x, -r.q);
+    }
+    // ---- element state in registers (round 6) ----------------------------------------------------------------------------------
+    // The two element phases of a plain ADMM iteration pass five vectors through LDS that nobody but the element's own thread touches
+    // between two termination checks: x, z and y of the element's dynamics row and box row (update() stores them, the next update()
+    // loads them; the right-hand side loads x and the thread's own rho z_d - y_d once more).  That is 12 of the 44 LDS accesses of an
+    // element and iteration, in a kernel whose LDS pipe is the busiest unit of the CU at four instances per CU (SQ_ACTIVE_INST_LDS:
+    // half of the launch; VALU issue 28 %, matrix cores 10 %: profiles/r05_pmc.json).  In the two-wavefront MFMA kernels with two
+    // element rounds (kFuse2) the thread keeps them in registers between the checks: the state is loaded behind a check (or the set-up),
+    // lives through the plain iterations -- the fused blocks below read and write it in place of their loads and stores; ZT* still go
+    // to LDS, the neighbours' right-hand sides gather them -- and is flushed in front of the next iteration that checks or adapts rho,
+    // which runs the LDS form of the phases as before (the checks, the re-factorisation, parking and the polish read the arrays).
+    // The operations and their order are those of el_form / rhs_form: every output word is unchanged (tools/ab_equal.py).
+    // Handles with steeringDelay > 0 (a third box row in the right-hand side: a uniform branch the fused block does not carry) stay on
+    // the LDS form.
+    static constexpr bool kRegState = kFuse2;
+    // (z_d is not part of it: the projection of a dynamics row is its bound, z_d == b after any update -- the first iteration of a launch
+    // runs the LDS form, so that this holds whenever the state is in registers: cold start z = 0, warm start z = A x)
+    struct ElState { double x, yd, zb, yb, wtd; };
+    ElState es_[kRegState ? 2 : 1];
+    __device__ __forceinline__ void state_load() {
+        const int e0 = tid, e1 = tid + kStride, e1c = e1 < NS * 8 ? e1 : e0;
+        es_[0] = ElState{X[e0], Yd[e0], Zb[e0], Yb[e0], ZTd[e0]};
+        if (fuse2_wave()) es_[1] = ElState{X[e1c], Yd[e1c], Zb[e1c], Yb[e1c], ZTd[e1c]};     // (no second element: a copy of the first one, kept equal by equal arithmetic)
+    }
+    __device__ __forceinline__ void state_flush() {
+        const int e0 = tid, e1 = tid + kStride, e1c = e1 < NS * 8 ? e1 : e0;
+        X[e0] = es_[0].x; Yd[e0] = es_[0].yd; Zb[e0] = es_[0].zb; Yb[e0] = es_[0].yb;         // (Zd holds b already)
+        if (fuse2_wave()) { X[e1c] = es_[1].x; Yd[e1c] = es_[1].yd; Zb[e1c] = es_[1].zb; Yb[e1c] = es_[1].yb; }
+    }
+    // right-hand side of the thread's elements from the state (rhs_load without the loads of X[e] and ZTd[e])
+    __device__ __forceinline__ RhsIn rhs_load_s(int e, const LaneC &lc, const ElState &st) const {
         RhsIn r;
         const int k = e >> 3, kn = k < N ? k + 1 : N;         // the stage-N tile is all zero
         const double *col = tA + k * kTS + tj, *sd = ZTd + kn * 8;
 #pragma unroll
         for (int i = 0; i < NX; ++i) { r.c_[i] = col[i * 8]; r.d_[i] = sd[i]; }
-        r.sb0 = Sb(k, lc.r0); r.sb1 = Sb(k, lc.r1); r.w0 = ZTb[k * 8 + lc.r0]; r.w1 = ZTb[k * 8 + lc.r1]; r.ei = Eid(k, tj); r.wd = ZTd[e];
-        r.x = X[e]; r.q = Qv[e];
+        r.sb0 = Sb(k, lc.r0); r.sb1 = Sb(k, lc.r1); r.w0 = ZTb[k * 8 + lc.r0]; r.w1 = ZTb[k * 8 + lc.r1]; r.ei = Eid(k, tj); r.wd = st.wtd;
+        r.x = st.x; r.q = Qv[e];
         return r;
     }
-    __device__ __forceinline__ double rhs_form(const RhsIn &r, double sigma) const {
-        double acc0 = r.c_[0] * r.d_[0] + r.c_[1] * r.d_[1], acc1 = r.c_[2] * r.d_[2] + r.c_[3] * r.d_[3];
-#pragma unroll
-        for (int i = 4; i < NX; ++i) acc0 += r.c_[i] * r.d_[i];
-        const double boxes = r.sb0 * r.w0 + r.sb1 * r.w1;
-        return (boxes + (r.ei * r.wd - (acc0 + acc1))) + (sigma * r.x - r.q);
+    __device__ __forceinline__ void rhs_s(double sigma) {
+        const LaneC lc = lane_consts();
+        const int e0 = tid;
+        if (fuse2_wave()) {
+            const int e1 = tid + kStride, e1c = e1 < NS * 8 ? e1 : e0;
+            const RhsIn a0 = rhs_load_s(e0, lc, es_[0]), a1 = rhs_load_s(e1c, lc, es_[1]);
+            const double v0 = rhs_form(a0, sigma), v1 = rhs_form(a1, sigma);
+            XT[e0] = v0;
+            XT[e1c] = v1;
+        } else {
+            const RhsIn a0 = rhs_load_s(e0, lc, es_[0]);
+            XT[e0] = rhs_form(a0, sigma);
+        }
     }
-    struct ElIn { double xt, xo, zd, yd, zb, yb, lo, hi, b, sb, xv, ei, dot; };
-    struct ElOut { double ynd, znd, wtd, ynb, znb, wtb, xn; };
-    // (the same loads, operations and operation order as update()'s element(); every load unconditional)
-    __device__ __forceinline__ ElIn el_load(int e, int bvar) const {
+    // update of the thread's elements on the state (el_load / el_form / el_store without the state's loads and stores)
+    struct ElInS { double xt, lo, hi, b, sb, xv, ei, dot; };
+    __device__ __forceinline__ ElInS el_load_s(int e, int bvar) const {
         const int k = e >> 3;
-        ElIn q;
-        q.xt = XT[e]; q.xo = X[e]; q.zd = Zd[e]; q.yd = Yd[e]; q.zb = Zb[e]; q.yb = Yb[e]; q.lo = Lo[e]; q.hi = Hi[e];
+        ElInS q;
+        q.xt = XT[e]; q.lo = Lo[e]; q.hi = Hi[e];
         q.b = dyn_bound(e); q.sb = Sb(k, tj); q.xv = XT[k * 8 + bvar]; q.ei = Eid(k, tj);
         const double d0 = AT[e], d1 = kRawV ? VT[e] : 0.0;
         const double dsum = kRawV ? d0 + d1 : d0;
         q.dot = k > 0 ? dsum : 0.0;
         return q;
     }
-    __device__ __forceinline__ ElOut el_form(const ElIn &q, double alpha, double oma, double rmask, double w, double winv) const {
-        ElOut o;
-        const double ztd = rmask * (q.ei * q.xt - q.dot);
-        const double zrd = alpha * ztd + oma * q.zd;
+    // returns rho z_b - y_b of the box row; the state is advanced in place
+    __device__ __forceinline__ double el_form_s(const ElInS &q, ElState &st, double alpha, double oma, double rmask, double w, double winv) const {
+        // (explicit fused operations: see rhs_form)
+        const double ztd = rmask * __builtin_fma(q.ei, q.xt, -q.dot);
+        const double zrd = __builtin_fma(oma, q.b, alpha * ztd);        // (z_d == b: see ElState)
         const double znd = q.b;
-        const double dyd = rho_eq * (zrd - znd), ynd = q.yd + dyd;
-        const double zrb = alpha * (q.sb * q.xv) + oma * q.zb;
-        const double znb = clipd(zrb + winv * q.yb, q.lo, q.hi);
-        const double dyb = w * (zrb - znb), ynb = q.yb + dyb;
-        o.xn = alpha * q.xt + oma * q.xo;
-        o.ynd = ynd; o.znd = znd; o.wtd = rho_eq * znd - ynd;
-        o.ynb = ynb; o.znb = znb; o.wtb = w * znb - ynb;
-        return o;
+        const double ynd = __builtin_fma(rho_eq, zrd - znd, st.yd);
+        const double zrb = __builtin_fma(oma, st.zb, alpha * (q.sb * q.xv));
+        const double znb = clipd(__builtin_fma(winv, st.yb, zrb), q.lo, q.hi);
+        const double ynb = __builtin_fma(w, zrb - znb, st.yb);
+        st.x = __builtin_fma(alpha, q.xt, oma * st.x);
+        st.yd = ynd; st.wtd = __builtin_fma(rho_eq, znd, -ynd);
+        st.yb = ynb; st.zb = znb;
+        return __builtin_fma(w, znb, -ynb);
     }
-    __device__ __forceinline__ void el_store(int e, const ElOut &o) {
-        Yd[e] = o.ynd; Zd[e] = o.znd; ZTd[e] = o.wtd;
-        Yb[e] = o.ynb; Zb[e] = o.znb; ZTb[e] = o.wtb;
-        X[e] = o.xn;
+    __device__ __forceinline__ void update_s(double alpha, double oma) {
+        const LaneC lc = lane_consts();
+        const int bvar = lc.bvar;
+        const double rmask = lc.rmask;
+        const int e0 = tid;
+        if (fuse2_wave()) {
+            const int e1 = tid + kStride, e1c = e1 < NS * 8 ? e1 : e0;
+            const ElInS a0 = el_load_s(e0, bvar), a1 = el_load_s(e1c, bvar);
+            const double wb0 = el_form_s(a0, es_[0], alpha, oma, rmask, wbx[0], wbxi[0]), wb1 = el_form_s(a1, es_[1], alpha, oma, rmask, wbx[1], wbxi[1]);
+            ZTd[e0] = es_[0].wtd; ZTb[e0] = wb0;
+            ZTd[e1c] = es_[1].wtd; ZTb[e1c] = wb1;
+            asm volatile("; LPVMPC_ROLE_BEGIN regstate_update");
+            sync();
+            asm volatile("; LPVMPC_ROLE_END regstate_update");
+        } else {
+            const ElInS a0 = el_load_s(e0, bvar);
+            const double wb0 = el_form_s(a0, es_[0], alpha, oma, rmask, wbx[0], wbxi[0]);
+            ZTd[e0] = es_[0].wtd; ZTb[e0] = wb0;
+            asm volatile("; LPVMPC_ROLE_BEGIN regstate_update");
+            sync();
+            asm volatile("; LPVMPC_ROLE_END regstate_update");
+        }
     }
+
     // z~ = A x~ fused with OSQP update_x / update_z / update_y; leaves rho z - y in ZT*.
     // All LDS reads of a round are issued before any of its writes.
     // (SET: four-wavefront kernel only -- 1 / 2 = that element set, no barrier; see iterate4)
@@ -2362,23 +2555,7 @@ struct Solver {
         } else if constexpr (kCacheW) {
             // (round 5: with the uniform scalars in SGPRs and the post-loop addresses laundered, the two-wavefront MFMA kernels have the
             // registers to let this loop's addresses be hoisted: -24 instructions per iteration in the headline kernel)
-            const int t0 = (kUniScalars && kMf && kTwo) ? tid : opaque(tid);
-            if constexpr (kFuse2) {
-                // A wavefront that owns elements in both rounds runs them as ONE basic block (plain iterations only: want_delta is a
-                // uniform branch inside element()): both rounds' loads, both rounds' arithmetic, then the stores -- one LDS round trip is
-                // exposed instead of two.  A lane without a second element repeats its first one (same values, stored twice).
-                if (!want_delta && fuse2_wave()) {
-                    const int e0 = t0, e1 = t0 + kStride;
-                    const bool on1 = e1 < NS * 8;
-                    const int e1c = on1 ? e1 : e0;
-                    const ElIn a0 = el_load(e0, bvar), a1 = el_load(e1c, bvar);
-                    const ElOut o0 = el_form(a0, alpha, oma, rmask, wbx[0], wbxi[0]), o1 = el_form(a1, alpha, oma, rmask, wbx[1], wbxi[1]);
-                    el_store(e0, o0);
-                    el_store(e1c, o1);          // (no second element: the first one's values once more -- no exec mask for the optimiser to sink the round into)
-                    sync();
-                    return;
-                }
-            }
+            const int t0 = (kUniScalars && kMf && kTwo && !kRegState) ? tid : opaque(tid);      // (kRegState: this form runs once in 25 iterations -- no hoisted addresses for it)
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
                 const int e = t0 + r * kStride;
@@ -2843,12 +3020,34 @@ struct Solver {
         const unsigned long long *pw = reinterpret_cast<const unsigned long long *>(a.pool_in + (size_t)entry * a.pool_stride + image_doubles(N) + 8);
         return Outs{(double *)uni(pw[0]), (double *)uni(pw[1]), (int32_t *)uni(pw[2]), (int32_t *)uni(pw[3]), (int32_t *)uni(pw[4]), (double *)uni(pw[5]), (double *)uni(pw[6])};
     }
+    // (admission of try_park below, one thread: the slot taken, or -1.  pool_count: [0] slots handed out, [1] readers of the resume pass,
+    // [2] requests of the young class, [3] requests of the middle class; plain atomic adds, no compare-and-swap loop -- the loop's
+    // registers cost the ADMM iteration 30 instructions through the allocator, these cost it 7)
+    __device__ __forceinline__ static int park_slot(const SolveArgs &a, int iter) {
+        const int K = a.resume ? 0 : a.defer_after, R = a.pool_cap >> 2;
+        const int cls = (K > 0 && iter < 2 * K) ? 2 : ((K > 0 && iter < 4 * K) ? 3 : 1);
+        const int lim = cls == 2 ? a.pool_cap - R : (cls == 3 ? (R >> 1) : 0x7fffffff);
+        const int q = atomicAdd(a.pool_count + cls, cls == 1 ? 0 : 1);
+        int s = -1;
+        if (q < lim) { s = atomicAdd(a.pool_count, 1); if (s >= a.pool_cap) s = -1; }
+        atomicAdd(a.defer_stats + (s >= 0 ? 0 : 1), 1ull);
+        return s;
+    }
+    // AGE-ORDERED ADMISSION (round 6).  A main launch parks into a pool of pool_cap entries that is emptied only by the resume pass
+    // behind it.  First come, first served let the many nearly-done instances of a small defer_after = K fill the pool at their first
+    // check beyond K, and the one 4000-iteration instance of the batch then stayed resident in the main launch for all of its
+    // iterations (defer_after 50: 0.99 M solves/s against 2.0 M at 75 / 100 / 125, profiles/r05_burst_sweep_driver.txt).  Now the
+    // instances are admitted by age class: the YOUNG ones (fewer than 2 K iterations) may take three quarters of the pool, the MIDDLE
+    // ones (2 K .. 4 K) an eighth of their own, and whoever is beyond 4 K takes any free entry -- at least the last eighth.  An instance
+    // that is refused goes on iterating and asks again at its next check, older by then: the long runners always find room, however
+    // many young ones wanted in.  Resume passes park into an empty pool of the size of the one they consume: nothing is refused there.
+    // lpvmpc_defer_stats reports the instances parked and the requests refused.
     __device__ __forceinline__ bool try_park(const SolveArgs &a, int entry, int inst, int iter, int to_chk, int to_adp) {
-        if (tid == 0) RED[79] = (double)atomicAdd(a.pool_count, 1);
+        if (tid == 0) RED[79] = (double)park_slot(a, iter);
         sync();
         const int slot = (int)RED[79];
         sync();
-        if (slot >= a.pool_cap) return false;                    // pool full: this instance simply goes on here
+        if (slot < 0) return false;                              // no room for this age class: the instance simply goes on here and asks again at its next check
         const int n = (int)image_doubles(N);
         double *dst = a.pool + (size_t)slot * a.pool_stride;
         for (int i = tid; i < n; i += kStride) dst[i] = tA[i];          // tA is the base of the LDS block
@@ -3037,7 +3236,8 @@ struct Solver {
         }
 
         // ---------- ADMM ----------
-        const double alpha = cfg.alpha, sigma = cfg.sigma;
+        double alpha = cfg.alpha, sigma = cfg.sigma, oma_u = 1.0 - cfg.alpha;
+        if constexpr (kRegState) { alpha = unid(alpha); sigma = unid(sigma); oma_u = unid(oma_u); }      // (uniform: scalar registers -- the element state takes the vector ones)
         int status = LPVMPC_UNSOLVED_, iter = 0, status_polish = 0;
         double pri_res = 0, dua_res = 0, obj = __builtin_nan("");
         Res R = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -3050,6 +3250,8 @@ struct Solver {
         const double rho_tol = cfg.rho_tol;
         int to_chk = resuming ? to_chk0 : chk_every, to_adp = resuming ? to_adp0 : adp_every;
         const int defer_after = a.defer_after > 0 ? (resuming ? iter0 - 1 + a.defer_after : a.defer_after) : 0;     // park at the first check at or beyond this iteration
+        bool es_live = false;                                     // (kRegState) the registers hold the element state, the arrays X, Z*, Y* are stale
+        const bool reg_state = kRegState && !(kCtrl && delay > 0);
         if constexpr (TAIL) {
             // ---- the tail kernel's loop: dense product, fused element phase; checks evaluated beside the iterations (see tail_fused).
             // The last wavefront runs the checker's side of the same loop (tail_loop<true>): the same scalar control flow on the same
@@ -3093,7 +3295,22 @@ struct Solver {
             if (LPVMPC_PHASE_ONLY == 3) update(alpha, checked);
 #else
             if constexpr (kFour) iterate4(sigma, alpha, checked);
-            else if constexpr (kMf) {
+            else if constexpr (kMf && kRegState) {
+                // a plain iteration keeps the element state in registers (see kRegState); one that checks or adapts rho runs the LDS form
+                const bool plain = reg_state && !(checked || adapt) && iter != iter0;
+                if (plain) {
+                    if (!es_live) { state_load(); es_live = true; }
+                    rhs_s(sigma);
+                } else {
+                    if (es_live) { state_flush(); es_live = false; }      // (the thread's own elements: what reads them next is this thread, or sits behind a barrier)
+                    build_rhs<false>(sigma);
+                }
+                const MfLane m = mf_lane();     // (in front of the barrier: the sweeps' lane constants form while the stores drain)
+                sync();
+                STAMP(0);
+                kkt_solve_mf(m);
+                if (plain) update_s(alpha, oma_u); else update(alpha, checked);
+            } else if constexpr (kMf) {
                 build_rhs<false>(sigma);
                 const MfLane m = mf_lane();     // (in front of the barrier: the sweeps' lane constants form while the stores drain)
                 sync();
@@ -3129,6 +3346,7 @@ struct Solver {
             }
         }
         STAMP5(4);
+        if constexpr (kRegState) { if (es_live) { state_flush(); sync(); } }      // (a loop that ends on a plain iteration: max_iter off the check grid)
         if constexpr (kUniScalars && !TAIL) launder_ids();      // (the post-loop code's addresses are formed behind the loop: see launder_ids)
         if (iter > max_iter) iter = max_iter;
         if (!checked) {
@@ -3368,7 +3586,7 @@ __global__ void __launch_bounds__(64 * NW, (min_waves_per_simd<NT, NW, GS>())) a
         if (threadIdx.x == 0) {
             n_parked = atomicAdd(a.pool_in_count, 0);
             __threadfence();
-            if (atomicAdd(a.pool_in_count + 1, 1) == (int)gridDim.x - 1) { a.pool_in_count[0] = 0; a.pool_in_count[1] = 0; }
+            if (atomicAdd(a.pool_in_count + 1, 1) == (int)gridDim.x - 1) { a.pool_in_count[0] = 0; a.pool_in_count[1] = 0; a.pool_in_count[2] = 0; a.pool_in_count[3] = 0; }
         }
         __syncthreads();
         const int n = n_parked;

@@ -79,7 +79,7 @@ static void free_defer(lpvmpc_handle *h) {
         if (h->dcount[i]) (void)hipFree(h->dcount[i]);
         h->dpool[i] = nullptr; h->dcount[i] = nullptr;
     }
-    h->defer_cur_cap = 0;
+    h->defer_cur_cap = 0;                   // (the counters of lpvmpc_defer_stats live as long as the handle: see ensure_defer / lpvmpc_destroy)
 }
 // an entry holds the LDS image of whichever kernel variant runs (the run-time-horizon kernel keeps its factor tiles in LDS:
 // the largest image) plus the loop scalars and output pointers
@@ -96,10 +96,11 @@ static int ensure_defer(lpvmpc_handle *h, int B, hipStream_t st) {
     free_defer(h);
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(h, hipMalloc((void **)&h->dpool[i], (size_t)cap * stride * 8));
-        HIP_TRY(h, hipMalloc((void **)&h->dcount[i], 8));
-        HIP_TRY(h, hipMemsetAsync(h->dcount[i], 0, 8, st));
+        HIP_TRY(h, hipMalloc((void **)&h->dcount[i], 16));
+        HIP_TRY(h, hipMemsetAsync(h->dcount[i], 0, 16, st));
     }
     if (!h->defer_event) HIP_TRY(h, hipEventCreateWithFlags(&h->defer_event, hipEventDisableTiming));
+    if (!h->dstats) { HIP_TRY(h, hipMalloc((void **)&h->dstats, 16)); HIP_TRY(h, hipMemsetAsync(h->dstats, 0, 16, st)); }
     h->defer_cur_cap = cap; h->defer_stride = stride; h->dcur = 0;
     return LPVMPC_OK;
 }
@@ -111,7 +112,7 @@ static int resume_pass(lpvmpc_handle *h, int budget, hipStream_t st) {
     a.B = h->defer_cur_cap; a.resume = 1; a.defer_after = budget; a.tail = h->defer_tail;
     a.pool_in = h->dpool[A]; a.pool_in_count = h->dcount[A];
     a.pool = h->dpool[Bp]; a.pool_count = h->dcount[Bp];
-    a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride; a.x0_stride = h->nx;
+    a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride; a.x0_stride = h->nx; a.defer_stats = h->dstats;
     const int slot = h->rv_count % kEventRing;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->rv0[slot], st));
     HIP_TRY(h, lpvmpc::launch_solve(h->dev, h->d_cfg, a, st, h->force_generic));
@@ -162,7 +163,7 @@ extern "C" lpvmpc_handle *lpvmpc_create(const lpvmpc_config *cfg) {
     h->cl_plant = h->cl_local = h->cl_cmd = nullptr; h->cl_local_next = nullptr; h->cl_next_valid = 0; h->cl_B = 0; h->cl_first_it = 1; h->cl_q9 = 1; h->cl_ticks = 0;
     h->d_Wop = h->d_FWop = nullptr; h->ho_M = 0; h->cascade = nullptr; h->cascade_owner = nullptr; h->cascade_prefetch = 1;
     h->defer_after = 0; h->defer_budget = 200; h->defer_cap = 0; h->defer_cur_cap = 0; h->defer_stride = 0; h->rv_count = 0;
-    h->dpool[0] = h->dpool[1] = nullptr; h->dcount[0] = h->dcount[1] = nullptr; h->dcur = 0; h->defer_stream = nullptr; h->defer_event = nullptr;
+    h->dpool[0] = h->dpool[1] = nullptr; h->dcount[0] = h->dcount[1] = nullptr; h->dstats = nullptr; h->dcur = 0; h->defer_stream = nullptr; h->defer_event = nullptr;
     h->defer_stream_set = false; h->defer_tail = 1; h->defer_skip_pass = false;
     h->h_pack_in = h->h_pack_out = h->d_pack_in = h->d_pack_out = nullptr;
     DevCfg &d = h->dev;
@@ -218,6 +219,7 @@ extern "C" void lpvmpc_destroy(lpvmpc_handle *h) {
     if (h->d_FWop) (void)hipFree(h->d_FWop);
     if (h->d_cfg) (void)hipFree(h->d_cfg);
     free_defer(h);
+    if (h->dstats) (void)hipFree(h->dstats);
     if (h->defer_event) (void)hipEventDestroy(h->defer_event);
     for (hipEvent_t e : h->rv0) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->rv1) (void)hipEventDestroy(e);
@@ -534,7 +536,7 @@ extern "C" int lpvmpc_solve_batch_dev(lpvmpc_handle *h, int32_t B, const double 
         }
         h->defer_stream = st; h->defer_stream_set = true;
         a.defer_after = h->defer_after; a.resume = 0; a.pool = h->dpool[h->dcur]; a.pool_count = h->dcount[h->dcur];
-        a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride;
+        a.pool_cap = h->defer_cur_cap; a.pool_stride = h->defer_stride; a.defer_stats = h->dstats;
         rc = lpvmpc_launch_solve_timed(h, a, st); if (rc) return rc;
         // the bounded pass behind the call -- unless the caller joins right away (budget -1, and the synchronous host-array entry
         // point): then the closing pass (the tail kernel) takes the parked instances straight from this launch
@@ -570,6 +572,21 @@ extern "C" int lpvmpc_resume_time_stats(lpvmpc_handle *h, double *total_ms, int3
         tot += ms;
     }
     *total_ms = tot; *count = n;
+    return LPVMPC_OK;
+}
+
+// instances parked / parking requests refused by the launches of this handle that have COMPLETED on the stream of its last deferred
+// call (waits for that stream); counted since the handle's first deferred call
+extern "C" int lpvmpc_defer_stats(lpvmpc_handle *h, int64_t *parked, int64_t *refused) {
+    if (!h) return LPVMPC_E_ARG;
+    unsigned long long v[2] = {0, 0};
+    if (h->dstats) {
+        HIP_TRY(h, hipSetDevice(h->cfg.device));
+        if (h->defer_stream_set) HIP_TRY(h, hipStreamSynchronize(h->defer_stream));
+        HIP_TRY(h, hipMemcpy(v, h->dstats, 16, hipMemcpyDeviceToHost));
+    }
+    if (parked) *parked = (int64_t)v[0];
+    if (refused) *refused = (int64_t)v[1];
     return LPVMPC_OK;
 }
 

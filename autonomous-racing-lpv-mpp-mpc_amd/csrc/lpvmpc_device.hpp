@@ -71,9 +71,11 @@ struct SolveArgs {
                             // iterations; 0: run to completion
     int resume;             // 1: continue the parked instances of pool_in (blockIdx.x = entry)
     double *pool;           // [pool_cap][pool_stride] entries written by this launch
-    int32_t *pool_count;    // entries requested so far in pool (may exceed pool_cap: the surplus instances were not parked)
+    int32_t *pool_count;    // [4]: slots requested so far in pool (may exceed pool_cap: the surplus instances were not parked), [1] see pool_in_count,
+                            // [2] / [3] requests of the young / middle age class (admission by age: Solver::park_slot)
+    unsigned long long *defer_stats;   // [2]: instances parked / parking attempts refused (pool share of the instance's age class full) by launches of this handle
     const double *pool_in;  // resume: entries to continue
-    int32_t *pool_in_count; // [2]: entries, and the number of resume workgroups that have read it (the last reader clears both:
+    int32_t *pool_in_count; // [4]: entries, the number of resume workgroups that have read it, the class counters (the last reader clears all:
                             // the pool is empty again when the pass ends, without a separate memset launch)
     int pool_cap, pool_stride;
     // planner N = 30, no deferral: the three equilibration vectors (D, E of the dynamics rows, E of the box rows) of instance i

@@ -59,6 +59,7 @@ struct lpvmpc_handle {
     int defer_cur_cap, defer_stride;
     double *dpool[2];
     int32_t *dcount[2];
+    unsigned long long *dstats;         // [2] device counters: instances parked / parking requests refused (lpvmpc_defer_stats)
     int dcur;
     hipStream_t defer_stream;           // stream of the last deferred call (lpvmpc_join orders against it); valid iff defer_stream_set
     bool defer_stream_set;              // (the null stream is a stream like any other: nullptr cannot mean "none yet")

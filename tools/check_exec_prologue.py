@@ -104,9 +104,14 @@ def scan(path, window=8, lookback=2000):
                     then_side = []
                     if else_open is not None:
                         j2 = i - 1
+                        # (round 6: the THEN side is the ONE basic block in front of the label -- the walk stops at the previous label or
+                        # branch.  A window of 2000 instructions made the exemption nearly unconditional in kernels that write almost
+                        # every register within it.)
                         while j2 >= 0 and len(then_side) < lookback and not re.match(r"^_Z\w+:", lines[j2]):
                             t2 = lines[j2].strip()
                             j2 -= 1
+                            if re.match(r"^\.LBB\d+_\d+:", t2) or re.match(r"s_(cbranch|branch|setpc|endpgm)", t2):
+                                break
                             if t2 and not t2.startswith((";", ".")):
                                 then_side.append(t2)
                     for idx, b in enumerate(body[:k]):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of the solve-kernel launches of the last K steps of a `rocprofv3 --kernel-trace --output-format csv` run of bench.py:
 tools/kernel_timeline.py <kernel_trace.csv> [K].  Classes: main (grid 1024 x 128), resume (pool-sized grid of the same kernel),
-tail (512-thread kernel over the pool), drain (ring_drain_kernel on the lane's tail stream)."""
+tail (512-thread kernel over the pool)."""
 import csv
 import sys
 
@@ -11,8 +11,6 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 
 def cls(r):
     n = r["Kernel_Name"]
-    if "ring_drain" in n:
-        return "drain"
     if "admm_solve" in n:
         g, w = int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"])
         if w == 512:
