@@ -201,7 +201,7 @@ struct Solver {
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
                 const int e = kFour ? (r == 0 ? elem_set1(tid) : elem_set2(tid))
-                                    : tid + r * kStride;
+                                    : (kChainOwn ? ca_elem(r) : tid + r * kStride);
                 double w = rho, wi = rinv;
                 if (e >= 0 && e < NS * 8) {
                     const double lo = Lo[e], hi = Hi[e];
@@ -211,7 +211,7 @@ struct Solver {
                 wbx[r] = w; wbxi[r] = wi;
             }
             // (kFuse2: a lane without an element in the second round repeats its first one there -- with the first one's weights)
-            if constexpr (MF && NW == 2 && kRnd == 2) { if (!(tid + kStride < NS * 8)) { wbx[1] = wbx[0]; wbxi[1] = wbxi[0]; } }
+            if constexpr (MF && NW == 2 && kRnd == 2) { if (kChainOwn ? ca_elem(1) < 0 : !(tid + kStride < NS * 8)) { wbx[1] = wbx[0]; wbxi[1] = wbxi[0]; } }
         }
     }
     int lpack;                // r0 | r1 << 4 | r2 << 8 | bvar << 12 | (tj < NX) << 16: one register for the whole solve, unpacked where used
@@ -1675,8 +1675,9 @@ struct Solver {
     __device__ __forceinline__ static double mf_close(double d) { return d + dpp_mov<TYPE_A ? 0x128 : 0x141>(d); }
     // (vq: the pivot products the backward sweep's first two steps take -- this wavefront's own stores, fetched here, in front of the
     // barrier between the sweeps, so that behind it only the other chain's contribution to the middle stage is one LDS round trip away)
-    template <bool BOT, bool STASHED>
-    __device__ __forceinline__ void mf_forward(const MfLane &m, double (&vq)[kVQ]) {
+    // CA: chain-aligned element ownership (see kChainOwn) -- the chain's contribution goes to the iteration's exchange buffer ex
+    template <bool BOT, bool STASHED, bool CA = false>
+    __device__ __forceinline__ void mf_forward(const MfLane &m, double (&vq)[kVQ], double *ex = nullptr) {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         // a type A step delivers layout B: right-hand side element eB in the blocks stB, results stored by the lanes c = 0 of them
@@ -1727,7 +1728,7 @@ struct Solver {
         // wait and the store were an LDS round trip before wave 0's first step
         double mid = 0.0;
         if (!STASHED && !BOT) mid = XT[kMid * 8 + (m.ln & 7)];
-        RED[32 + (BOT ? 8 : 0) + (la ? m.eB : m.eA)] = mf_close<la>(dl);      // (first: the other chain waits for it)
+        (CA ? ex + 40 : RED + 32)[(BOT ? 8 : 0) + (la ? m.eB : m.eA)] = mf_close<la>(dl);      // (first: the other chain waits for it)
         if constexpr (kRawV) vq[P - 1] = dv; else (la ? vsA : vsB)[stage(P - 1) * 8] = mf_close<la>(dv);
         if (!STASHED && !BOT) RED[48 + (m.ln & 7)] = mid;                      // (every lane stores a replica)
         wsync();
@@ -1738,8 +1739,8 @@ struct Solver {
             if (P >= 2) vq[(P - 2) % 3] = vlA[stage(P - 2) * 8];
         }
     }
-    template <bool BOT>
-    __device__ __forceinline__ void mf_backward(const MfLane &m, double (&vq)[kVQ]) {
+    template <bool BOT, bool CA = false>
+    __device__ __forceinline__ void mf_backward(const MfLane &m, double (&vq)[kVQ], const double *ex = nullptr) {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         // backward step p consumes x at chain position p + 1; x_m arrives in layout B, so step p is of type B iff P - 1 - p is even
@@ -1754,7 +1755,12 @@ struct Solver {
         // (pivot products are fetched two steps ahead; those of the first two steps came with vq)
         // middle stage, on both waves: x_m = S_m^-1 (b_m - L_t y_{m-1} - L_b y_{m+1}); type A step, x_m in layout B
         const int em = kFlip ? m.eB : m.eA;         // (kFlip: a type B step -- right-hand side in layout B, x_m in layout A)
-        const double ym = RED[48 + em] + (RED[32 + em] + RED[40 + em]);
+        double ym;
+        if constexpr (CA) {     // the middle stage's right-hand side from its parts (rhs_s): wavefront 0's, and wavefront 1's coupling sum
+            const double bx = ex[em], ei = ex[8 + em], wd = ex[16 + em], sq = ex[24 + em], acc = ex[32 + em];
+            const double ct = ex[40 + em], cb = ex[48 + em];
+            ym = rhs_finish(bx, ei, wd, acc, sq) + (ct + cb);
+        } else ym = RED[48 + em] + (RED[32 + em] + RED[40 + em]);
         double X = kFlip ? mf_close<false>(mfma4(mS, ym, 0.0)) : mf_close<true>(mfma4(mS, ym, 0.0));
         if constexpr (!BOT) XT[kMid * 8 + (kFlip ? m.eA : m.eB)] = X;
         double dal = 0.0;                                                   // dynamics-row product of the previous step, not yet closed
@@ -1790,6 +1796,12 @@ struct Solver {
         if (!BOT) {     // [A|B]_0 x_0 -> dynamics rows of stage 1; x_0 is in layout B iff P is even
             constexpr bool tb = ((P & 1) == 0) != kFlip;
             const double dt = mfma4(tT, X, 0.0);
+            if constexpr (CA) {         // (the address from an opaque lane index: one hoisted register less in a loop that has none to spare)
+                const int l_ = opaque(m.ln), r_ = l_ >> 4, b_ = (l_ >> 2) & 3;
+                const int el = tb ? 4 * (b_ >> 1) + r_ : 4 * (b_ & 1) + r_;
+                const bool st = tb ? (b_ & 1) == 0 : b_ < 2;
+                ((kRawV && !st) ? VT : AT)[8 + el] = kRawV ? dt : mf_close<!tb>(dt);
+            } else
             ((kRawV && !(tb ? m.stA : m.stB)) ? VT : AT)[8 + (tb ? m.eA : m.eB)] = kRawV ? dt : mf_close<!tb>(dt);
         }
     }
@@ -2039,6 +2051,18 @@ struct Solver {
         STAMP(1);
         if (wv == 0) mf_backward<false>(m, vq); else mf_backward<true>(m, vq);
         sync();
+        STAMP(2);
+    }
+    // the same under the chain-aligned ownership: the right-hand sides are this wavefront's own stores and so are the readers of its
+    // results -- ONE workgroup barrier, between the sweeps (see kChainOwn)
+    __device__ __forceinline__ void kkt_solve_ca(const MfLane &m, double *ex) {
+        double vq[kVQ];
+        wsync();
+        if (wv == 0) mf_forward<false, true, true>(m, vq, ex); else mf_forward<true, true, true>(m, vq, ex);
+        sync();
+        STAMP(1);
+        if (wv == 0) mf_backward<false, true>(m, vq, ex); else mf_backward<true, true>(m, vq, ex);
+        wsync();
         STAMP(2);
     }
     // STASHED: the caller has already copied the middle stage's right-hand side to RED[48..55]
@@ -2398,42 +2422,90 @@ struct Solver {
     // (the fused operations written out: what the compiler contracts `a b + c d` into depends on the code around it -- with implicit
     // contraction the register form of the element phases differed from the LDS form in the last bits.  These are the operations of
     // round 5's build, read off its assembly; the LDS forms -- At_elem, update()'s element() -- compile to the same ones: tools/ab_equal.py)
-    __device__ __forceinline__ double rhs_form(const RhsIn &r, double sigma) const {
+    // the coupling sum of an element: sum_r [A|B]_k[r][j] (rho z_d - y_d)_{k+1}[r]
+    __device__ __forceinline__ double rhs_acc(const RhsIn &r) const {
         double acc0 = __builtin_fma(r.c_[0], r.d_[0], r.c_[1] * r.d_[1]);
         const double acc1 = __builtin_fma(r.c_[2], r.d_[2], r.c_[3] * r.d_[3]);
 #pragma unroll
         for (int i = 4; i < NX; ++i) acc0 = __builtin_fma(r.c_[i], r.d_[i], acc0);
-        const double boxes = __builtin_fma(r.sb0, r.w0, r.sb1 * r.w1);
-        const double dyn = __builtin_fma(r.ei, r.wd, -(acc1 + acc0));
-        return (boxes + dyn) + __builtin_fma(sigma, r.x, -r.q);
+        return acc1 + acc0;
+    }
+    __device__ __forceinline__ static double rhs_boxes(const RhsIn &r) { return __builtin_fma(r.sb0, r.w0, r.sb1 * r.w1); }
+    __device__ __forceinline__ static double rhs_sxq(const RhsIn &r, double sigma) { return __builtin_fma(sigma, r.x, -r.q); }
+    // (boxes + (Eid w_d - acc)) + (sigma x - q)
+    __device__ __forceinline__ static double rhs_finish(double boxes, double ei, double wd, double acc, double sxq) {
+        return (boxes + __builtin_fma(ei, wd, -acc)) + sxq;
+    }
+    __device__ __forceinline__ double rhs_form(const RhsIn &r, double sigma) const {
+        return rhs_finish(rhs_boxes(r), r.ei, r.wd, rhs_acc(r), rhs_sxq(r, sigma));
     }
     // ---- element state in registers (round 6) ----------------------------------------------------------------------------------
-    // The two element phases of a plain ADMM iteration pass five vectors through LDS that nobody but the element's own thread touches
+    // The two element phases of an ADMM iteration pass five vectors through LDS that nobody but the element's own thread touches
     // between two termination checks: x, z and y of the element's dynamics row and box row (update() stores them, the next update()
-    // loads them; the right-hand side loads x and the thread's own rho z_d - y_d once more).  That is 12 of the 44 LDS accesses of an
-    // element and iteration, in a kernel whose LDS pipe is the busiest unit of the CU at four instances per CU (SQ_ACTIVE_INST_LDS:
-    // half of the launch; VALU issue 28 %, matrix cores 10 %: profiles/r05_pmc.json).  In the two-wavefront MFMA kernels with two
-    // element rounds (kFuse2) the thread keeps them in registers between the checks: the state is loaded behind a check (or the set-up),
-    // lives through the plain iterations -- the fused blocks below read and write it in place of their loads and stores; ZT* still go
-    // to LDS, the neighbours' right-hand sides gather them -- and is flushed in front of the next iteration that checks or adapts rho,
-    // which runs the LDS form of the phases as before (the checks, the re-factorisation, parking and the polish read the arrays).
-    // The operations and their order are those of el_form / rhs_form: every output word is unchanged (tools/ab_equal.py).
+    // loads them; the right-hand side loads x and the thread's own rho z_d - y_d once more) -- 12 of the 44 LDS accesses of an element
+    // and iteration.  In the two-wavefront MFMA kernels with two element rounds (kFuse2) the thread keeps them in registers for the
+    // whole ADMM loop: loaded once in front of it, read and written in place by the fused blocks below; ZT* still go to LDS every
+    // iteration (the neighbours' right-hand sides gather them), and an iteration that is followed by a termination check or a rho
+    // update also files the state and the deltas in the arrays, where the checks, the re-factorisation, parking and the polish read
+    // them (update_s, `want`).  The operations and their order are those of update()'s element() and of At_elem, written with explicit
+    // fused operations (rhs_form): every output word is unchanged (tools/ab_equal.py).
     // Handles with steeringDelay > 0 (a third box row in the right-hand side: a uniform branch the fused block does not carry) stay on
-    // the LDS form.
+    // the LDS form of the phases.
     static constexpr bool kRegState = kFuse2;
-    // (z_d is not part of it: the projection of a dynamics row is its bound, z_d == b after any update -- the first iteration of a launch
-    // runs the LDS form, so that this holds whenever the state is in registers: cold start z = 0, warm start z = A x)
+    // ---- chain-aligned element ownership (round 6; N = 20) ----------------------------------------------------------------------------
+    // With the state in registers the element phases touch, besides the thread's own slots, only (rho z - y) of the element's own stage
+    // and of the NEXT stage (right-hand side) and the sweep results of its own stage (update).  Let wavefront 0 own the elements of the
+    // stages its elimination chain works on -- 0 .. kMid, the middle stage included -- and wavefront 1 those of kMid + 1 .. N: then the
+    // right-hand sides a forward sweep fetches, the x~ and [A|B] x~ an update reads and the (rho z - y) a right-hand side gathers are ALL
+    // the wavefront's own stores, ordered by the LDS pipe itself (one wavefront's DS instructions execute in order), and three of the four
+    // workgroup barriers of an iteration go: only the one between the sweeps stays, where the chains exchange their contributions to
+    // the middle stage.  The one coupling across the cut -- the middle stage's right-hand side needs (rho z_d - y_d) of stage kMid + 1 --
+    // travels with that exchange: wavefront 1 forms the coupling sum (a pseudo-element on eight idle lanes of its second round),
+    // wavefront 0 files the other parts of that right-hand side, and both complete it behind the barrier (mf_backward), with the
+    // operations of rhs_finish: the same bits.  The exchange area is double-buffered by iteration parity (a wavefront may be a whole
+    // iteration ahead of the other's reads, never two) in DX, which plain iterations do not use; an iteration that files the deltas
+    // (update_s, want) takes a barrier first.  The second element round is short on both wavefronts (24 / 16 of 64 lanes): four
+    // wavefront-rounds instead of three -- instructions this latency-bound kernel has to spare.
+    static constexpr bool kChainOwn = kRegState && NT == 20 && !kFlip;
+    static constexpr int kOwn0 = (kMid + 1) * 8;                     // wavefront 0: elements [0, kOwn0), wavefront 1: the rest
+    static constexpr int kExSize = 56;                                // exchange buffer: boxes, Eid, w_d, sigma x - q, coupling sum (8 each), the two chains' contributions (16)
+    static_assert(!kChainOwn || (2 * kExSize <= (NT + 1) * 8 && kOwn0 - 64 <= 24 && (NT + 1) * 8 - kOwn0 - 64 <= 16 && kOwn0 - 64 > 16), "chain-aligned ownership: the second rounds / the pseudo-element's lanes do not fit");
+    __device__ __forceinline__ double *ex_buf(int par) const { return DX + kExSize * par; }
+    // element of round r of this thread under the chain-aligned ownership, or -1
+    __device__ __forceinline__ int ca_elem(int r) const {
+        const int i = opaque(lane) + 64 * r;        // (formed where it is used: hoisted out of the ADMM loop, the second round's indices and masks cost registers the loop does not have)
+        return wv == 0 ? (i < kOwn0 ? i : -1) : (i < (NT + 1) * 8 - kOwn0 ? kOwn0 + i : -1);
+    }
+    // the thread's elements in the fused element phases: e0, e1 (-1: none), e1c (a lane without a second element repeats its first one)
+    struct Own { int e0, e1, e1c; };
+    __device__ __forceinline__ Own own() const {
+        Own o;
+        if constexpr (kChainOwn) { o.e0 = ca_elem(0); o.e1 = ca_elem(1); }
+        else { o.e0 = tid; o.e1 = tid + kStride < NS * 8 ? tid + kStride : -1; }
+        o.e1c = o.e1 >= 0 ? o.e1 : o.e0;
+        return o;
+    }
+    __device__ __forceinline__ bool two_elems() const { if constexpr (kChainOwn) return true; else return fuse2_wave(); }
+    // (z_d is not part of it: the projection of a dynamics row is its bound, z_d == b after any update; the first iteration of a launch
+    // takes it from the array -- cold start z = 0, warm start z = A x)
     struct ElState { double x, yd, zb, yb, wtd; };
     ElState es_[kRegState ? 2 : 1];
     __device__ __forceinline__ void state_load() {
-        const int e0 = tid, e1 = tid + kStride, e1c = e1 < NS * 8 ? e1 : e0;
-        es_[0] = ElState{X[e0], Yd[e0], Zb[e0], Yb[e0], ZTd[e0]};
-        if (fuse2_wave()) es_[1] = ElState{X[e1c], Yd[e1c], Zb[e1c], Yb[e1c], ZTd[e1c]};     // (no second element: a copy of the first one, kept equal by equal arithmetic)
+        const Own o = own();
+        es_[0] = ElState{X[o.e0], Yd[o.e0], Zb[o.e0], Yb[o.e0], ZTd[o.e0]};
+        if (two_elems()) es_[1] = ElState{X[o.e1c], Yd[o.e1c], Zb[o.e1c], Yb[o.e1c], ZTd[o.e1c]};     // (no second element: a copy of the first one, kept equal by equal arithmetic)
     }
+    // rho z_d - y_d again from the array (behind recompute_w: the check block may have changed rho)
+    __device__ __forceinline__ void state_reload_w() {
+        const Own o = own();
+        es_[0].wtd = ZTd[o.e0];
+        if (two_elems()) es_[1].wtd = ZTd[o.e1c];
+    }
+    // the state to the arrays (a loop that ends on a plain iteration; z_d = b behind any update)
     __device__ __forceinline__ void state_flush() {
-        const int e0 = tid, e1 = tid + kStride, e1c = e1 < NS * 8 ? e1 : e0;
-        X[e0] = es_[0].x; Yd[e0] = es_[0].yd; Zb[e0] = es_[0].zb; Yb[e0] = es_[0].yb;         // (Zd holds b already)
-        if (fuse2_wave()) { X[e1c] = es_[1].x; Yd[e1c] = es_[1].yd; Zb[e1c] = es_[1].zb; Yb[e1c] = es_[1].yb; }
+        const Own o = own();
+        X[o.e0] = es_[0].x; Zd[o.e0] = dyn_bound(o.e0); Yd[o.e0] = es_[0].yd; Zb[o.e0] = es_[0].zb; Yb[o.e0] = es_[0].yb;
+        if (two_elems()) { X[o.e1c] = es_[1].x; Zd[o.e1c] = dyn_bound(o.e1c); Yd[o.e1c] = es_[1].yd; Zb[o.e1c] = es_[1].zb; Yb[o.e1c] = es_[1].yb; }
     }
     // right-hand side of the thread's elements from the state (rhs_load without the loads of X[e] and ZTd[e])
     __device__ __forceinline__ RhsIn rhs_load_s(int e, const LaneC &lc, const ElState &st) const {
@@ -2446,65 +2518,105 @@ struct Solver {
         r.x = st.x; r.q = Qv[e];
         return r;
     }
-    __device__ __forceinline__ void rhs_s(double sigma) {
+    // ex: the exchange buffer of this iteration (kChainOwn; see there)
+    __device__ __forceinline__ void rhs_s(double sigma, double *ex) {
         const LaneC lc = lane_consts();
-        const int e0 = tid;
-        if (fuse2_wave()) {
-            const int e1 = tid + kStride, e1c = e1 < NS * 8 ? e1 : e0;
-            const RhsIn a0 = rhs_load_s(e0, lc, es_[0]), a1 = rhs_load_s(e1c, lc, es_[1]);
-            const double v0 = rhs_form(a0, sigma), v1 = rhs_form(a1, sigma);
-            XT[e0] = v0;
-            XT[e1c] = v1;
+        const Own o = own();
+        if (two_elems()) {
+            if constexpr (kChainOwn) {
+                // second round: a real element files its right-hand side; wavefront 0's elements of the middle stage file the parts of
+                // theirs, wavefront 1's lanes 16 .. 23 form the middle stage's coupling sum (pseudo-element kMid * 8 + j)
+                const bool midel = o.e1 >= kMid * 8 && o.e1 < kOwn0;
+                const bool pseudo = wv == 1 && (lane >> 3) == 2;
+                const int j = lane & 7;
+                const int e1r = o.e1 >= 0 ? o.e1 : (pseudo ? kMid * 8 + j : o.e0);
+                const RhsIn a0 = rhs_load_s(o.e0, lc, es_[0]), a1 = rhs_load_s(e1r, lc, es_[1]);
+                const double v0 = rhs_form(a0, sigma);
+                const double acc1 = rhs_acc(a1), bx1 = rhs_boxes(a1), sq1 = rhs_sxq(a1, sigma);
+                const double v1 = rhs_finish(bx1, a1.ei, a1.wd, acc1, sq1);
+                XT[o.e0] = v0;
+                double *const dst = midel ? ex + j : (pseudo ? ex + 32 + j : XT + e1r);
+                *dst = midel ? bx1 : (pseudo ? acc1 : v1);
+                if (midel) { ex[8 + j] = a1.ei; ex[16 + j] = a1.wd; ex[24 + j] = sq1; }
+            } else {
+                const RhsIn a0 = rhs_load_s(o.e0, lc, es_[0]), a1 = rhs_load_s(o.e1c, lc, es_[1]);
+                const double v0 = rhs_form(a0, sigma), v1 = rhs_form(a1, sigma);
+                XT[o.e0] = v0;
+                XT[o.e1c] = v1;
+            }
         } else {
-            const RhsIn a0 = rhs_load_s(e0, lc, es_[0]);
-            XT[e0] = rhs_form(a0, sigma);
+            const RhsIn a0 = rhs_load_s(o.e0, lc, es_[0]);
+            XT[o.e0] = rhs_form(a0, sigma);
         }
     }
-    // update of the thread's elements on the state (el_load / el_form / el_store without the state's loads and stores)
-    struct ElInS { double xt, lo, hi, b, sb, xv, ei, dot; };
+    // update of the thread's elements on the state (update()'s element() without the state's loads and stores)
+    struct ElInS { double xt, zd, lo, hi, b, sb, xv, ei, dot; };
+    struct ElOutS { double wtb, znd, dyd, dyb, dx; };
     __device__ __forceinline__ ElInS el_load_s(int e, int bvar) const {
         const int k = e >> 3;
         ElInS q;
-        q.xt = XT[e]; q.lo = Lo[e]; q.hi = Hi[e];
+        q.xt = XT[e]; q.zd = Zd[e]; q.lo = Lo[e]; q.hi = Hi[e];
         q.b = dyn_bound(e); q.sb = Sb(k, tj); q.xv = XT[k * 8 + bvar]; q.ei = Eid(k, tj);
         const double d0 = AT[e], d1 = kRawV ? VT[e] : 0.0;
         const double dsum = kRawV ? d0 + d1 : d0;
         q.dot = k > 0 ? dsum : 0.0;
         return q;
     }
-    // returns rho z_b - y_b of the box row; the state is advanced in place
-    __device__ __forceinline__ double el_form_s(const ElInS &q, ElState &st, double alpha, double oma, double rmask, double w, double winv) const {
+    // the state is advanced in place; first: z_d of the dynamics row comes from the array (else it is the row's bound: see ElState)
+    __device__ __forceinline__ ElOutS el_form_s(const ElInS &q, ElState &st, bool first, double alpha, double oma, double rmask, double w, double winv) const {
         // (explicit fused operations: see rhs_form)
+        ElOutS o;
+        const double zd = first ? q.zd : q.b;
         const double ztd = rmask * __builtin_fma(q.ei, q.xt, -q.dot);
-        const double zrd = __builtin_fma(oma, q.b, alpha * ztd);        // (z_d == b: see ElState)
+        const double zrd = __builtin_fma(oma, zd, alpha * ztd);
         const double znd = q.b;
-        const double ynd = __builtin_fma(rho_eq, zrd - znd, st.yd);
+        const double dd = zrd - znd;
+        o.dyd = rho_eq * dd;
+        const double ynd = __builtin_fma(rho_eq, dd, st.yd);
         const double zrb = __builtin_fma(oma, st.zb, alpha * (q.sb * q.xv));
         const double znb = clipd(__builtin_fma(winv, st.yb, zrb), q.lo, q.hi);
-        const double ynb = __builtin_fma(w, zrb - znb, st.yb);
-        st.x = __builtin_fma(alpha, q.xt, oma * st.x);
+        const double db = zrb - znb;
+        o.dyb = w * db;
+        const double ynb = __builtin_fma(w, db, st.yb);
+        const double xn = __builtin_fma(alpha, q.xt, oma * st.x);
+        o.dx = xn - st.x;
+        st.x = xn;
         st.yd = ynd; st.wtd = __builtin_fma(rho_eq, znd, -ynd);
         st.yb = ynb; st.zb = znb;
-        return __builtin_fma(w, znb, -ynb);
+        o.znd = znd;
+        o.wtb = __builtin_fma(w, znb, -ynb);
+        return o;
     }
-    __device__ __forceinline__ void update_s(double alpha, double oma) {
+    // want: a termination check or a rho update follows -- the state and the deltas go to the arrays as well.  kChainOwn: no barrier
+    // behind a plain update (the next right-hand side gathers this wavefront's own stores); one in front of the filing, whose arrays
+    // hold the exchange area
+    __device__ __forceinline__ void update_s(double alpha, double oma, bool want, bool first) {
         const LaneC lc = lane_consts();
         const int bvar = lc.bvar;
         const double rmask = lc.rmask;
-        const int e0 = tid;
-        if (fuse2_wave()) {
-            const int e1 = tid + kStride, e1c = e1 < NS * 8 ? e1 : e0;
-            const ElInS a0 = el_load_s(e0, bvar), a1 = el_load_s(e1c, bvar);
-            const double wb0 = el_form_s(a0, es_[0], alpha, oma, rmask, wbx[0], wbxi[0]), wb1 = el_form_s(a1, es_[1], alpha, oma, rmask, wbx[1], wbxi[1]);
-            ZTd[e0] = es_[0].wtd; ZTb[e0] = wb0;
-            ZTd[e1c] = es_[1].wtd; ZTb[e1c] = wb1;
+        const Own o = own();
+        auto file = [&](int e, const ElState &st, const ElOutS &q) {
+            X[e] = st.x; Zd[e] = q.znd; Yd[e] = st.yd; Zb[e] = st.zb; Yb[e] = st.yb;
+            DYd[e] = q.dyd; DYb[e] = q.dyb; DX[e] = q.dx;
+        };
+        if (two_elems()) {
+            const ElInS a0 = el_load_s(o.e0, bvar), a1 = el_load_s(o.e1c, bvar);
+            const ElOutS o0 = el_form_s(a0, es_[0], first, alpha, oma, rmask, wbx[0], wbxi[0]), o1 = el_form_s(a1, es_[1], first, alpha, oma, rmask, wbx[1], wbxi[1]);
+            ZTd[o.e0] = es_[0].wtd; ZTb[o.e0] = o0.wtb;
+            ZTd[o.e1c] = es_[1].wtd; ZTb[o.e1c] = o1.wtb;
             asm volatile("; LPVMPC_ROLE_BEGIN regstate_update");
-            sync();
+            if constexpr (kChainOwn) {
+                if (want) { sync(); file(o.e0, es_[0], o0); file(o.e1c, es_[1], o1); sync(); }
+            } else {
+                if (want) { file(o.e0, es_[0], o0); file(o.e1c, es_[1], o1); }
+                sync();
+            }
             asm volatile("; LPVMPC_ROLE_END regstate_update");
         } else {
-            const ElInS a0 = el_load_s(e0, bvar);
-            const double wb0 = el_form_s(a0, es_[0], alpha, oma, rmask, wbx[0], wbxi[0]);
-            ZTd[e0] = es_[0].wtd; ZTb[e0] = wb0;
+            const ElInS a0 = el_load_s(o.e0, bvar);
+            const ElOutS o0 = el_form_s(a0, es_[0], first, alpha, oma, rmask, wbx[0], wbxi[0]);
+            ZTd[o.e0] = es_[0].wtd; ZTb[o.e0] = o0.wtb;
+            if (want) file(o.e0, es_[0], o0);
             asm volatile("; LPVMPC_ROLE_BEGIN regstate_update");
             sync();
             asm volatile("; LPVMPC_ROLE_END regstate_update");
@@ -2558,8 +2670,8 @@ struct Solver {
             const int t0 = (kUniScalars && kMf && kTwo && !kRegState) ? tid : opaque(tid);      // (kRegState: this form runs once in 25 iterations -- no hoisted addresses for it)
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
-                const int e = t0 + r * kStride;
-                if (e < NS * 8) element(e, true, wbx[r], wbxi[r]);
+                const int e = kChainOwn ? ca_elem(r) : t0 + r * kStride;      // (the cached weights follow the ownership)
+                if (e >= 0 && e < NS * 8) element(e, true, wbx[r], wbxi[r]);
             }
         } else {
             for (int e = opaque(tid); e < NS * 8; e += kStride) element(e, false, 0.0, 0.0);
@@ -3250,8 +3362,10 @@ struct Solver {
         const double rho_tol = cfg.rho_tol;
         int to_chk = resuming ? to_chk0 : chk_every, to_adp = resuming ? to_adp0 : adp_every;
         const int defer_after = a.defer_after > 0 ? (resuming ? iter0 - 1 + a.defer_after : a.defer_after) : 0;     // park at the first check at or beyond this iteration
-        bool es_live = false;                                     // (kRegState) the registers hold the element state, the arrays X, Z*, Y* are stale
-        const bool reg_state = kRegState && !(kCtrl && delay > 0);
+        constexpr bool reg_state = kRegState;
+        bool filed = true, ran = false;                           // (kRegState) the last iteration filed the state in the arrays; an iteration has run
+        int par = 0;                                              // (kChainOwn) parity of the exchange buffer
+        if constexpr (kRegState && !TAIL) { if (reg_state) state_load(); }
         if constexpr (TAIL) {
             // ---- the tail kernel's loop: dense product, fused element phase; checks evaluated beside the iterations (see tail_fused).
             // The last wavefront runs the checker's side of the same loop (tail_loop<true>): the same scalar control flow on the same
@@ -3296,20 +3410,24 @@ struct Solver {
 #else
             if constexpr (kFour) iterate4(sigma, alpha, checked);
             else if constexpr (kMf && kRegState) {
-                // a plain iteration keeps the element state in registers (see kRegState); one that checks or adapts rho runs the LDS form
-                const bool plain = reg_state && !(checked || adapt) && iter != iter0;
-                if (plain) {
-                    if (!es_live) { state_load(); es_live = true; }
-                    rhs_s(sigma);
+                // the element state lives in registers (see kRegState); handles with steeringDelay > 0 run the LDS form
+                // (launch_solve sends controller handles with steeringDelay > 0 -- a third box row in the right-hand side, which the fused
+                // blocks do not carry -- to the DPP kernel: these kernels have no LDS form of the element phases)
+                if constexpr (kChainOwn) {      // one barrier per iteration (see kChainOwn)
+                    double *const ex = ex_buf(par);
+                    par ^= 1;
+                    rhs_s(sigma, ex);
+                    const MfLane m = mf_lane();
+                    STAMP(0);
+                    kkt_solve_ca(m, ex);
                 } else {
-                    if (es_live) { state_flush(); es_live = false; }      // (the thread's own elements: what reads them next is this thread, or sits behind a barrier)
-                    build_rhs<false>(sigma);
+                    rhs_s(sigma, nullptr);
+                    const MfLane m = mf_lane();     // (in front of the barrier: the sweeps' lane constants form while the stores drain)
+                    sync();
+                    STAMP(0);
+                    kkt_solve_mf(m);
                 }
-                const MfLane m = mf_lane();     // (in front of the barrier: the sweeps' lane constants form while the stores drain)
-                sync();
-                STAMP(0);
-                kkt_solve_mf(m);
-                if (plain) update_s(alpha, oma_u); else update(alpha, checked);
+                update_s(alpha, oma_u, checked || adapt, iter == iter0); filed = checked || adapt; ran = true;
             } else if constexpr (kMf) {
                 build_rhs<false>(sigma);
                 const MfLane m = mf_lane();     // (in front of the barrier: the sweeps' lane constants form while the stores drain)
@@ -3339,6 +3457,7 @@ struct Solver {
                     if (rn > rho * rho_tol || rn < rho / rho_tol) { set_rho(rn); cache_box_weights(); factor(sigma); }
                 }
                 recompute_w();              // the residual evaluation used ZT* as scratch (and rho may have changed)
+                if constexpr (kRegState) { if (reg_state) state_reload_w(); }
                 // straggler deferral: unsolved at this check and past the budget -> park and end the workgroup (block-uniform)
                 if (checked && defer_after > 0 && iter >= defer_after && iter < max_iter && try_park(a, entry, inst, iter, to_chk, to_adp)) return;
                 if constexpr (kUniScalars) ids_restore(loop_ids);
@@ -3346,7 +3465,7 @@ struct Solver {
             }
         }
         STAMP5(4);
-        if constexpr (kRegState) { if (es_live) { state_flush(); sync(); } }      // (a loop that ends on a plain iteration: max_iter off the check grid)
+        if constexpr (kRegState) { if (reg_state && ran && !filed) { state_flush(); sync(); } }      // (a loop that ends on a plain iteration: max_iter off the check grid)
         if constexpr (kUniScalars && !TAIL) launder_ids();      // (the post-loop code's addresses are formed behind the loop: see launder_ids)
         if (iter > max_iter) iter = max_iter;
         if (!checked) {
@@ -3641,13 +3760,15 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
 #if defined(LPVMPC_DEV_TAIL_ONLY)
     return hipErrorInvalidValue;       // development builds (seconds instead of minutes): the tail kernels only, for looking at their assembly
 #elif defined(LPVMPC_DEV_MAIN_ONLY)
-    return launch_one<6, 20, 2, true>(cfg, dcfg, a, stream);      // ... or the headline kernel only
+    return launch_one<6, 20, 2, true>(cfg, dcfg, a, stream);      // ... or the headline kernel only (no steeringDelay > 0 in this build)
 #elif defined(LPVMPC_DEV_P30_ONLY)
     return cfg.N == 30 ? launch_one<5, 30, 4, true>(cfg, dcfg, a, stream) : launch_one<5, 40, 4, true>(cfg, dcfg, a, stream);      // ... or the four-wavefront planner kernels
 #else
     if (cfg.kind == 0) {
+        // (steeringDelay > 0, CTRL:518-527: a third box row on delta in the first stages.  The MFMA kernel's element phases keep their state
+        // in registers and carry two box rows per variable: such handles take the DPP kernel -- the reference runs delay 0, CMAIN:49)
         if (!generic && cfg.N == 20) return one_wave ? launch_one<6, 20, 1>(cfg, dcfg, a, stream)
-                                          : (dpp ? launch_one<6, 20, 2>(cfg, dcfg, a, stream) : launch_one<6, 20, 2, true>(cfg, dcfg, a, stream));
+                                          : ((dpp || cfg.steering_delay > 0) ? launch_one<6, 20, 2>(cfg, dcfg, a, stream) : launch_one<6, 20, 2, true>(cfg, dcfg, a, stream));
         if (!generic && cfg.N == 10) return launch_one<6, 10, 1>(cfg, dcfg, a, stream);
         if (!generic && cfg.N == 8) return launch_one<6, 8, 1>(cfg, dcfg, a, stream);      // the launch file's controller horizon (MAIN_LAUNCH.launch:117)
         return launch_one<6, 0, 1>(cfg, dcfg, a, stream);
