@@ -185,6 +185,8 @@ struct Solver {
     static constexpr bool kCacheW = kReg && !GS && (MF || (NW == 2 && NT > 20));   // (the N <= 20 DPP / one-wave instantiations have no registers to spare; the tail kernel keeps its own copies: tail_begin)
     static constexpr int kRnd = kCacheW ? (kFour ? 2 : ((NT + 1) * 8 + kStride - 1) / kStride) : 1;
     double wbx[kRnd], wbxi[kRnd];
+    int wcls;       // (kRegState kernels: the rows' classes instead -- 2 bits per round: 0 inequality, 1 equality, 2 loose; the weights are the uniform rho, rho_eq, rho_min and
+                    // their reciprocals, selected where used: seven registers less in a loop that keeps the element state)
     // NW == 4: element of set 1 / set 2 (see kS2n) that thread t owns in the right-hand side and update phases (>= 8 NS: none)
     __device__ __forceinline__ static int elem_set1(int t) {
         int e = t;
@@ -201,7 +203,7 @@ struct Solver {
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
                 const int e = kFour ? (r == 0 ? elem_set1(tid) : elem_set2(tid))
-                                    : (kChainOwn ? ca_elem(r) : tid + r * kStride);
+                                    : tid + r * kStride;
                 double w = rho, wi = rinv;
                 if (e >= 0 && e < NS * 8) {
                     const double lo = Lo[e], hi = Hi[e];
@@ -210,8 +212,22 @@ struct Solver {
                 }
                 wbx[r] = w; wbxi[r] = wi;
             }
+            if constexpr (kRegState) {
+                wcls = 0;
+#pragma unroll
+                for (int r = 0; r < kRnd; ++r) {
+                    const int e = tid + r * kStride;
+                    int c_ = 0;
+                    if (e >= 0 && e < NS * 8) {
+                        const double lo = Lo[e], hi = Hi[e];
+                        const bool loose = lo < -kInfty * kMinScaling && hi > kInfty * kMinScaling, eq = hi - lo < kRhoTol;
+                        c_ = loose ? 2 : (eq ? 1 : 0);
+                    } else c_ = wcls & 3;       // (no second element: the first one's class)
+                    wcls |= c_ << (2 * r);
+                }
+            }
             // (kFuse2: a lane without an element in the second round repeats its first one there -- with the first one's weights)
-            if constexpr (MF && NW == 2 && kRnd == 2) { if (kChainOwn ? ca_elem(1) < 0 : !(tid + kStride < NS * 8)) { wbx[1] = wbx[0]; wbxi[1] = wbxi[0]; } }
+            if constexpr (MF && NW == 2 && kRnd == 2) { if (!(tid + kStride < NS * 8)) { wbx[1] = wbx[0]; wbxi[1] = wbxi[0]; } }
         }
     }
     int lpack;                // r0 | r1 << 4 | r2 << 8 | bvar << 12 | (tj < NX) << 16: one register for the whole solve, unpacked where used
@@ -255,14 +271,8 @@ struct Solver {
             lpack = r0 | (r1 << 4) | (r2 << 8) | (box_var(tj) << 12) | ((tj < NX ? 1 : 0) << 16);
         }
         c = 1.0; cinv = 1.0; pol = false; rho = rho_eq = rinv = rinv_eq = 0.0; rSm = rLt = rLb = 0.0;
-        {   // lane (r, b = 2I + J, c) of an A operand: type A step T[4J + c][4I + r], type B step T[4I + c][4J + r]
-            const int r_ = lane >> 4, I_ = (lane >> 3) & 1, J_ = (lane >> 2) & 1, c_ = lane & 3;
-            gA = (4 * J_ + c_) * 8 + 4 * I_ + r_;
-            gB = (4 * I_ + c_) * 8 + 4 * J_ + r_;
-        }
         mS = tT = 0.0;
-        li = 4 * ((lane >> 3) & 1) + (lane >> 4); lj = lane & 7;
-        tlane = 8 * dgroup(lj) + li;
+        set_fac_ids(lane);
     }
     // the part of the LDS block that a pool entry carries (try_park / restore): everything up to and including SINK
     static constexpr __host__ __device__ size_t image_doubles(int N) {
@@ -308,7 +318,17 @@ struct Solver {
     __device__ __forceinline__ void launder_ids() {
         tid = opaque(tid); wv = tid >> 6; lane = tid & 63; ti = lane >> 3; tj = tid & 7;
         lpack = opaque(lpack);
-        gA = opaque(gA); gB = opaque(gB); li = opaque(li); lj = opaque(lj); tlane = opaque(tlane);
+        set_fac_ids(lane);
+    }
+    // the lane indices of the factorisation (MFMA operand gathers, D form), from the lane number.  Formed again wherever code behind the
+    // ADMM loop's entry needs them (the check block, the code behind the loop) instead of living in five registers through every
+    // iteration: the loop keeps the element state there (kRegState)
+    __device__ __forceinline__ void set_fac_ids(int l) {
+        const int r_ = l >> 4, I_ = (l >> 3) & 1, J_ = (l >> 2) & 1, c_ = l & 3;
+        gA = (4 * J_ + c_) * 8 + 4 * I_ + r_;       // lane (r, b = 2I + J, c) of an A operand: type A step T[4J + c][4I + r], type B step T[4I + c][4J + r]
+        gB = (4 * I_ + c_) * 8 + 4 * J_ + r_;
+        li = 4 * I_ + r_; lj = l & 7;
+        tlane = 8 * dgroup(lj) + li;
     }
     // The termination checks, the rho update and the re-factorisation sit INSIDE the iteration loop and run once in 25 iterations or
     // less; what they compute from the lane indices (addresses, lane masks -- the factorisation's above all) is loop invariant, so the
@@ -1675,9 +1695,8 @@ struct Solver {
     __device__ __forceinline__ static double mf_close(double d) { return d + dpp_mov<TYPE_A ? 0x128 : 0x141>(d); }
     // (vq: the pivot products the backward sweep's first two steps take -- this wavefront's own stores, fetched here, in front of the
     // barrier between the sweeps, so that behind it only the other chain's contribution to the middle stage is one LDS round trip away)
-    // CA: chain-aligned element ownership (see kChainOwn) -- the chain's contribution goes to the iteration's exchange buffer ex
-    template <bool BOT, bool STASHED, bool CA = false>
-    __device__ __forceinline__ void mf_forward(const MfLane &m, double (&vq)[kVQ], double *ex = nullptr) {
+    template <bool BOT, bool STASHED>
+    __device__ __forceinline__ void mf_forward(const MfLane &m, double (&vq)[kVQ]) {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         // a type A step delivers layout B: right-hand side element eB in the blocks stB, results stored by the lanes c = 0 of them
@@ -1728,7 +1747,7 @@ struct Solver {
         // wait and the store were an LDS round trip before wave 0's first step
         double mid = 0.0;
         if (!STASHED && !BOT) mid = XT[kMid * 8 + (m.ln & 7)];
-        (CA ? ex + 40 : RED + 32)[(BOT ? 8 : 0) + (la ? m.eB : m.eA)] = mf_close<la>(dl);      // (first: the other chain waits for it)
+        RED[32 + (BOT ? 8 : 0) + (la ? m.eB : m.eA)] = mf_close<la>(dl);      // (first: the other chain waits for it)
         if constexpr (kRawV) vq[P - 1] = dv; else (la ? vsA : vsB)[stage(P - 1) * 8] = mf_close<la>(dv);
         if (!STASHED && !BOT) RED[48 + (m.ln & 7)] = mid;                      // (every lane stores a replica)
         wsync();
@@ -1739,8 +1758,8 @@ struct Solver {
             if (P >= 2) vq[(P - 2) % 3] = vlA[stage(P - 2) * 8];
         }
     }
-    template <bool BOT, bool CA = false>
-    __device__ __forceinline__ void mf_backward(const MfLane &m, double (&vq)[kVQ], const double *ex = nullptr) {
+    template <bool BOT>
+    __device__ __forceinline__ void mf_backward(const MfLane &m, double (&vq)[kVQ]) {
         constexpr int P = kMid;
         auto stage = [](int p) constexpr { return BOT ? NT - p : p; };
         // backward step p consumes x at chain position p + 1; x_m arrives in layout B, so step p is of type B iff P - 1 - p is even
@@ -1755,12 +1774,7 @@ struct Solver {
         // (pivot products are fetched two steps ahead; those of the first two steps came with vq)
         // middle stage, on both waves: x_m = S_m^-1 (b_m - L_t y_{m-1} - L_b y_{m+1}); type A step, x_m in layout B
         const int em = kFlip ? m.eB : m.eA;         // (kFlip: a type B step -- right-hand side in layout B, x_m in layout A)
-        double ym;
-        if constexpr (CA) {     // the middle stage's right-hand side from its parts (rhs_s): wavefront 0's, and wavefront 1's coupling sum
-            const double bx = ex[em], ei = ex[8 + em], wd = ex[16 + em], sq = ex[24 + em], acc = ex[32 + em];
-            const double ct = ex[40 + em], cb = ex[48 + em];
-            ym = rhs_finish(bx, ei, wd, acc, sq) + (ct + cb);
-        } else ym = RED[48 + em] + (RED[32 + em] + RED[40 + em]);
+        const double ym = RED[48 + em] + (RED[32 + em] + RED[40 + em]);
         double X = kFlip ? mf_close<false>(mfma4(mS, ym, 0.0)) : mf_close<true>(mfma4(mS, ym, 0.0));
         if constexpr (!BOT) XT[kMid * 8 + (kFlip ? m.eA : m.eB)] = X;
         double dal = 0.0;                                                   // dynamics-row product of the previous step, not yet closed
@@ -1796,12 +1810,6 @@ struct Solver {
         if (!BOT) {     // [A|B]_0 x_0 -> dynamics rows of stage 1; x_0 is in layout B iff P is even
             constexpr bool tb = ((P & 1) == 0) != kFlip;
             const double dt = mfma4(tT, X, 0.0);
-            if constexpr (CA) {         // (the address from an opaque lane index: one hoisted register less in a loop that has none to spare)
-                const int l_ = opaque(m.ln), r_ = l_ >> 4, b_ = (l_ >> 2) & 3;
-                const int el = tb ? 4 * (b_ >> 1) + r_ : 4 * (b_ & 1) + r_;
-                const bool st = tb ? (b_ & 1) == 0 : b_ < 2;
-                ((kRawV && !st) ? VT : AT)[8 + el] = kRawV ? dt : mf_close<!tb>(dt);
-            } else
             ((kRawV && !(tb ? m.stA : m.stB)) ? VT : AT)[8 + (tb ? m.eA : m.eB)] = kRawV ? dt : mf_close<!tb>(dt);
         }
     }
@@ -2051,18 +2059,6 @@ struct Solver {
         STAMP(1);
         if (wv == 0) mf_backward<false>(m, vq); else mf_backward<true>(m, vq);
         sync();
-        STAMP(2);
-    }
-    // the same under the chain-aligned ownership: the right-hand sides are this wavefront's own stores and so are the readers of its
-    // results -- ONE workgroup barrier, between the sweeps (see kChainOwn)
-    __device__ __forceinline__ void kkt_solve_ca(const MfLane &m, double *ex) {
-        double vq[kVQ];
-        wsync();
-        if (wv == 0) mf_forward<false, true, true>(m, vq, ex); else mf_forward<true, true, true>(m, vq, ex);
-        sync();
-        STAMP(1);
-        if (wv == 0) mf_backward<false, true>(m, vq, ex); else mf_backward<true, true>(m, vq, ex);
-        wsync();
         STAMP(2);
     }
     // STASHED: the caller has already copied the middle stage's right-hand side to RED[48..55]
@@ -2452,40 +2448,16 @@ struct Solver {
     // Handles with steeringDelay > 0 (a third box row in the right-hand side: a uniform branch the fused block does not carry) stay on
     // the LDS form of the phases.
     static constexpr bool kRegState = kFuse2;
-    // ---- chain-aligned element ownership (round 6; N = 20) ----------------------------------------------------------------------------
-    // With the state in registers the element phases touch, besides the thread's own slots, only (rho z - y) of the element's own stage
-    // and of the NEXT stage (right-hand side) and the sweep results of its own stage (update).  Let wavefront 0 own the elements of the
-    // stages its elimination chain works on -- 0 .. kMid, the middle stage included -- and wavefront 1 those of kMid + 1 .. N: then the
-    // right-hand sides a forward sweep fetches, the x~ and [A|B] x~ an update reads and the (rho z - y) a right-hand side gathers are ALL
-    // the wavefront's own stores, ordered by the LDS pipe itself (one wavefront's DS instructions execute in order), and three of the four
-    // workgroup barriers of an iteration go: only the one between the sweeps stays, where the chains exchange their contributions to
-    // the middle stage.  The one coupling across the cut -- the middle stage's right-hand side needs (rho z_d - y_d) of stage kMid + 1 --
-    // travels with that exchange: wavefront 1 forms the coupling sum (a pseudo-element on eight idle lanes of its second round),
-    // wavefront 0 files the other parts of that right-hand side, and both complete it behind the barrier (mf_backward), with the
-    // operations of rhs_finish: the same bits.  The exchange area is double-buffered by iteration parity (a wavefront may be a whole
-    // iteration ahead of the other's reads, never two) in DX, which plain iterations do not use; an iteration that files the deltas
-    // (update_s, want) takes a barrier first.  The second element round is short on both wavefronts (24 / 16 of 64 lanes): four
-    // wavefront-rounds instead of three -- instructions this latency-bound kernel has to spare.
-    static constexpr bool kChainOwn = kRegState && NT == 20 && !kFlip;
-    static constexpr int kOwn0 = (kMid + 1) * 8;                     // wavefront 0: elements [0, kOwn0), wavefront 1: the rest
-    static constexpr int kExSize = 56;                                // exchange buffer: boxes, Eid, w_d, sigma x - q, coupling sum (8 each), the two chains' contributions (16)
-    static_assert(!kChainOwn || (2 * kExSize <= (NT + 1) * 8 && kOwn0 - 64 <= 24 && (NT + 1) * 8 - kOwn0 - 64 <= 16 && kOwn0 - 64 > 16), "chain-aligned ownership: the second rounds / the pseudo-element's lanes do not fit");
-    __device__ __forceinline__ double *ex_buf(int par) const { return DX + kExSize * par; }
-    // element of round r of this thread under the chain-aligned ownership, or -1
-    __device__ __forceinline__ int ca_elem(int r) const {
-        const int i = opaque(lane) + 64 * r;        // (formed where it is used: hoisted out of the ADMM loop, the second round's indices and masks cost registers the loop does not have)
-        return wv == 0 ? (i < kOwn0 ? i : -1) : (i < (NT + 1) * 8 - kOwn0 ? kOwn0 + i : -1);
-    }
+    static_assert(!kFuse2 || kStride == 128, "element state in registers: the second round / second wavefront own elements 64 and up (el_load_s, BZ)");
     // the thread's elements in the fused element phases: e0, e1 (-1: none), e1c (a lane without a second element repeats its first one)
     struct Own { int e0, e1, e1c; };
     __device__ __forceinline__ Own own() const {
         Own o;
-        if constexpr (kChainOwn) { o.e0 = ca_elem(0); o.e1 = ca_elem(1); }
-        else { o.e0 = tid; o.e1 = tid + kStride < NS * 8 ? tid + kStride : -1; }
+        o.e0 = tid; o.e1 = tid + kStride < NS * 8 ? tid + kStride : -1;
         o.e1c = o.e1 >= 0 ? o.e1 : o.e0;
         return o;
     }
-    __device__ __forceinline__ bool two_elems() const { if constexpr (kChainOwn) return true; else return fuse2_wave(); }
+    __device__ __forceinline__ bool two_elems() const { return fuse2_wave(); }
     // (z_d is not part of it: the projection of a dynamics row is its bound, z_d == b after any update; the first iteration of a launch
     // takes it from the array -- cold start z = 0, warm start z = A x)
     struct ElState { double x, yd, zb, yb, wtd; };
@@ -2518,32 +2490,14 @@ struct Solver {
         r.x = st.x; r.q = Qv[e];
         return r;
     }
-    // ex: the exchange buffer of this iteration (kChainOwn; see there)
-    __device__ __forceinline__ void rhs_s(double sigma, double *ex) {
+    __device__ __forceinline__ void rhs_s(double sigma) {
         const LaneC lc = lane_consts();
         const Own o = own();
         if (two_elems()) {
-            if constexpr (kChainOwn) {
-                // second round: a real element files its right-hand side; wavefront 0's elements of the middle stage file the parts of
-                // theirs, wavefront 1's lanes 16 .. 23 form the middle stage's coupling sum (pseudo-element kMid * 8 + j)
-                const bool midel = o.e1 >= kMid * 8 && o.e1 < kOwn0;
-                const bool pseudo = wv == 1 && (lane >> 3) == 2;
-                const int j = lane & 7;
-                const int e1r = o.e1 >= 0 ? o.e1 : (pseudo ? kMid * 8 + j : o.e0);
-                const RhsIn a0 = rhs_load_s(o.e0, lc, es_[0]), a1 = rhs_load_s(e1r, lc, es_[1]);
-                const double v0 = rhs_form(a0, sigma);
-                const double acc1 = rhs_acc(a1), bx1 = rhs_boxes(a1), sq1 = rhs_sxq(a1, sigma);
-                const double v1 = rhs_finish(bx1, a1.ei, a1.wd, acc1, sq1);
-                XT[o.e0] = v0;
-                double *const dst = midel ? ex + j : (pseudo ? ex + 32 + j : XT + e1r);
-                *dst = midel ? bx1 : (pseudo ? acc1 : v1);
-                if (midel) { ex[8 + j] = a1.ei; ex[16 + j] = a1.wd; ex[24 + j] = sq1; }
-            } else {
-                const RhsIn a0 = rhs_load_s(o.e0, lc, es_[0]), a1 = rhs_load_s(o.e1c, lc, es_[1]);
-                const double v0 = rhs_form(a0, sigma), v1 = rhs_form(a1, sigma);
-                XT[o.e0] = v0;
-                XT[o.e1c] = v1;
-            }
+            const RhsIn a0 = rhs_load_s(o.e0, lc, es_[0]), a1 = rhs_load_s(o.e1c, lc, es_[1]);
+            const double v0 = rhs_form(a0, sigma), v1 = rhs_form(a1, sigma);
+            XT[o.e0] = v0;
+            XT[o.e1c] = v1;
         } else {
             const RhsIn a0 = rhs_load_s(o.e0, lc, es_[0]);
             XT[o.e0] = rhs_form(a0, sigma);
@@ -2552,11 +2506,14 @@ struct Solver {
     // update of the thread's elements on the state (update()'s element() without the state's loads and stores)
     struct ElInS { double xt, zd, lo, hi, b, sb, xv, ei, dot; };
     struct ElOutS { double wtb, znd, dyd, dyb, dx; };
+    // FIRST: the first iteration of a launch -- z_d of the dynamics row comes from the array (see ElState).  BZ: the element's stage is
+    // known to be >= 1, whose dynamics rows have the bound 0 (beq[8], an exact +0: only stage 0 carries x0) -- no load
+    template <bool FIRST, bool BZ>
     __device__ __forceinline__ ElInS el_load_s(int e, int bvar) const {
         const int k = e >> 3;
         ElInS q;
-        q.xt = XT[e]; q.zd = Zd[e]; q.lo = Lo[e]; q.hi = Hi[e];
-        q.b = dyn_bound(e); q.sb = Sb(k, tj); q.xv = XT[k * 8 + bvar]; q.ei = Eid(k, tj);
+        q.xt = XT[e]; q.zd = FIRST ? Zd[e] : 0.0; q.lo = Lo[e]; q.hi = Hi[e];
+        q.b = BZ ? 0.0 : dyn_bound(e); q.sb = Sb(k, tj); q.xv = XT[k * 8 + bvar]; q.ei = Eid(k, tj);
         const double d0 = AT[e], d1 = kRawV ? VT[e] : 0.0;
         const double dsum = kRawV ? d0 + d1 : d0;
         q.dot = k > 0 ? dsum : 0.0;
@@ -2587,10 +2544,17 @@ struct Solver {
         o.wtb = __builtin_fma(w, znb, -ynb);
         return o;
     }
-    // want: a termination check or a rho update follows -- the state and the deltas go to the arrays as well.  kChainOwn: no barrier
-    // behind a plain update (the next right-hand side gathers this wavefront's own stores); one in front of the filing, whose arrays
-    // hold the exchange area
-    __device__ __forceinline__ void update_s(double alpha, double oma, bool want, bool first) {
+    struct WW { double w, wi; };
+    __device__ __forceinline__ WW weights_of(int r) const {
+        const int c_ = (opaque(wcls) >> (2 * r)) & 3;
+        WW q;
+        q.w = c_ == 0 ? rho : (c_ == 1 ? rho_eq : kRhoMin);
+        q.wi = c_ == 0 ? rinv : (c_ == 1 ? rinv_eq : 1.0 / kRhoMin);
+        return q;
+    }
+    // want: a termination check or a rho update follows -- the state and the deltas go to the arrays as well
+    template <bool FIRST>
+    __device__ __forceinline__ void update_s(double alpha, double oma, bool want) {
         const LaneC lc = lane_consts();
         const int bvar = lc.bvar;
         const double rmask = lc.rmask;
@@ -2600,21 +2564,21 @@ struct Solver {
             DYd[e] = q.dyd; DYb[e] = q.dyb; DX[e] = q.dx;
         };
         if (two_elems()) {
-            const ElInS a0 = el_load_s(o.e0, bvar), a1 = el_load_s(o.e1c, bvar);
-            const ElOutS o0 = el_form_s(a0, es_[0], first, alpha, oma, rmask, wbx[0], wbxi[0]), o1 = el_form_s(a1, es_[1], first, alpha, oma, rmask, wbx[1], wbxi[1]);
+            // (the second element sits in a stage >= 16: bound 0 -- a lane without one repeats its first element, bound included)
+            ElInS a0 = el_load_s<FIRST, false>(o.e0, bvar), a1 = el_load_s<FIRST, true>(o.e1c, bvar);
+            a1.b = o.e1 >= 0 ? 0.0 : a0.b;
+            const WW w0 = weights_of(0), w1 = weights_of(1);
+            const ElOutS o0 = el_form_s(a0, es_[0], FIRST, alpha, oma, rmask, w0.w, w0.wi), o1 = el_form_s(a1, es_[1], FIRST, alpha, oma, rmask, w1.w, w1.wi);
             ZTd[o.e0] = es_[0].wtd; ZTb[o.e0] = o0.wtb;
             ZTd[o.e1c] = es_[1].wtd; ZTb[o.e1c] = o1.wtb;
+            if (want) { file(o.e0, es_[0], o0); file(o.e1c, es_[1], o1); }
             asm volatile("; LPVMPC_ROLE_BEGIN regstate_update");
-            if constexpr (kChainOwn) {
-                if (want) { sync(); file(o.e0, es_[0], o0); file(o.e1c, es_[1], o1); sync(); }
-            } else {
-                if (want) { file(o.e0, es_[0], o0); file(o.e1c, es_[1], o1); }
-                sync();
-            }
+            sync();
             asm volatile("; LPVMPC_ROLE_END regstate_update");
         } else {
-            const ElInS a0 = el_load_s(o.e0, bvar);
-            const ElOutS o0 = el_form_s(a0, es_[0], first, alpha, oma, rmask, wbx[0], wbxi[0]);
+            const ElInS a0 = el_load_s<FIRST, true>(o.e0, bvar);        // (a wavefront without a second round owns elements 64 and up: stages >= 8)
+            const WW w0 = weights_of(0);
+            const ElOutS o0 = el_form_s(a0, es_[0], FIRST, alpha, oma, rmask, w0.w, w0.wi);
             ZTd[o.e0] = es_[0].wtd; ZTb[o.e0] = o0.wtb;
             if (want) file(o.e0, es_[0], o0);
             asm volatile("; LPVMPC_ROLE_BEGIN regstate_update");
@@ -2670,8 +2634,8 @@ struct Solver {
             const int t0 = (kUniScalars && kMf && kTwo && !kRegState) ? tid : opaque(tid);      // (kRegState: this form runs once in 25 iterations -- no hoisted addresses for it)
 #pragma unroll
             for (int r = 0; r < kRnd; ++r) {
-                const int e = kChainOwn ? ca_elem(r) : t0 + r * kStride;      // (the cached weights follow the ownership)
-                if (e >= 0 && e < NS * 8) element(e, true, wbx[r], wbxi[r]);
+                const int e = t0 + r * kStride;
+                if (e < NS * 8) element(e, true, wbx[r], wbxi[r]);
             }
         } else {
             for (int e = opaque(tid); e < NS * 8; e += kStride) element(e, false, 0.0, 0.0);
@@ -3364,7 +3328,6 @@ struct Solver {
         const int defer_after = a.defer_after > 0 ? (resuming ? iter0 - 1 + a.defer_after : a.defer_after) : 0;     // park at the first check at or beyond this iteration
         constexpr bool reg_state = kRegState;
         bool filed = true, ran = false;                           // (kRegState) the last iteration filed the state in the arrays; an iteration has run
-        int par = 0;                                              // (kChainOwn) parity of the exchange buffer
         if constexpr (kRegState && !TAIL) { if (reg_state) state_load(); }
         if constexpr (TAIL) {
             // ---- the tail kernel's loop: dense product, fused element phase; checks evaluated beside the iterations (see tail_fused).
@@ -3413,21 +3376,13 @@ struct Solver {
                 // the element state lives in registers (see kRegState); handles with steeringDelay > 0 run the LDS form
                 // (launch_solve sends controller handles with steeringDelay > 0 -- a third box row in the right-hand side, which the fused
                 // blocks do not carry -- to the DPP kernel: these kernels have no LDS form of the element phases)
-                if constexpr (kChainOwn) {      // one barrier per iteration (see kChainOwn)
-                    double *const ex = ex_buf(par);
-                    par ^= 1;
-                    rhs_s(sigma, ex);
-                    const MfLane m = mf_lane();
-                    STAMP(0);
-                    kkt_solve_ca(m, ex);
-                } else {
-                    rhs_s(sigma, nullptr);
-                    const MfLane m = mf_lane();     // (in front of the barrier: the sweeps' lane constants form while the stores drain)
-                    sync();
-                    STAMP(0);
-                    kkt_solve_mf(m);
-                }
-                update_s(alpha, oma_u, checked || adapt, iter == iter0); filed = checked || adapt; ran = true;
+                rhs_s(sigma);
+                const MfLane m = mf_lane();     // (in front of the barrier: the sweeps' lane constants form while the stores drain)
+                sync();
+                STAMP(0);
+                kkt_solve_mf(m);
+                if (iter == iter0) update_s<true>(alpha, oma_u, checked || adapt); else update_s<false>(alpha, oma_u, checked || adapt);
+                filed = checked || adapt; ran = true;
             } else if constexpr (kMf) {
                 build_rhs<false>(sigma);
                 const MfLane m = mf_lane();     // (in front of the barrier: the sweeps' lane constants form while the stores drain)
@@ -3448,7 +3403,7 @@ struct Solver {
             if (checked || adapt) {
                 const Ids loop_ids = ids_save();
                 if constexpr (kUniScalars && LPVMPC_BLOCK_LAUNDER == 1) launder_ids();       // (see ids_save)
-                if constexpr (kUniScalars && LPVMPC_BLOCK_LAUNDER == 2) { gA = opaque(gA); gB = opaque(gB); li = opaque(li); lj = opaque(lj); tlane = opaque(tlane); }
+                if constexpr (kUniScalars && LPVMPC_BLOCK_LAUNDER == 2) set_fac_ids(opaque(lane));
                 R = residuals(X, Zd, Zb, Yd, Yb);
                 pri_res = R.pri; dua_res = R.dua;
                 if (checked) { status = check_termination(R, false); if (status != LPVMPC_UNSOLVED_) break; }
@@ -3761,6 +3716,8 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
     return hipErrorInvalidValue;       // development builds (seconds instead of minutes): the tail kernels only, for looking at their assembly
 #elif defined(LPVMPC_DEV_MAIN_ONLY)
     return launch_one<6, 20, 2, true>(cfg, dcfg, a, stream);      // ... or the headline kernel only (no steeringDelay > 0 in this build)
+#elif defined(LPVMPC_DEV_P30_2W)
+    return launch_one<5, 30, 2, true>(cfg, dcfg, a, stream);      // ... or the two-wavefront MFMA planner kernel at N = 30
 #elif defined(LPVMPC_DEV_P30_ONLY)
     return cfg.N == 30 ? launch_one<5, 30, 4, true>(cfg, dcfg, a, stream) : launch_one<5, 40, 4, true>(cfg, dcfg, a, stream);      // ... or the four-wavefront planner kernels
 #else
