@@ -681,7 +681,7 @@ def load_pmc(B, planner):
     the output next to the numbers."""
     if planner or B != BATCH:
         return {}
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
