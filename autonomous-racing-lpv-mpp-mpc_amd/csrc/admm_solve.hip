@@ -3646,7 +3646,7 @@ template <int NT, int NW, bool GS>
 #ifdef LPVMPC_FORCE_TWO_WAVES_PER_SIMD
 constexpr int min_waves_per_simd() { return NW >= 8 ? NW / 4 : NW; }      // diagnostic: provoke register spilling in the big-N kernels
 #else
-constexpr int min_waves_per_simd() { return ((NW == 2 && NT <= 20) || (NW == 1 && NT > 0 && NT <= 8) || GS || NW == 8 || NW == 4) ? 2 : 1; }     // N = 8 (one wavefront): 256 registers without a spill -> eight instances per CU; NW = 8: the tail kernel, one workgroup per CU
+constexpr int min_waves_per_simd() { return ((NW == 2 && NT <= 20) || (NW == 1 && NT > 0 && NT <= 10) || GS || NW == 8 || NW == 4) ? 2 : 1; }     // N = 8 / 10 (one wavefront): 256 registers -> eight / seven instances per CU (N = 10 sat at 256 without the bound in round 5 and at 257 -- four per CU -- in round 6: the bound holds it); NW = 8: the tail kernel, one workgroup per CU
 #endif
 
 template <int NX, int NT, int NW, bool MF = false, bool GS = false, bool TAIL = false>
@@ -3716,6 +3716,8 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
     return hipErrorInvalidValue;       // development builds (seconds instead of minutes): the tail kernels only, for looking at their assembly
 #elif defined(LPVMPC_DEV_MAIN_ONLY)
     return launch_one<6, 20, 2, true>(cfg, dcfg, a, stream);      // ... or the headline kernel only (no steeringDelay > 0 in this build)
+#elif defined(LPVMPC_DEV_C10)
+    return launch_one<6, 10, 1>(cfg, dcfg, a, stream);      // ... or the one-wavefront controller kernel at N = 10
 #elif defined(LPVMPC_DEV_P30_2W)
     return launch_one<5, 30, 2, true>(cfg, dcfg, a, stream);      // ... or the two-wavefront MFMA planner kernel at N = 30
 #elif defined(LPVMPC_DEV_P30_ONLY)
