@@ -437,6 +437,9 @@ class PathFollowingLPV_MPC(_DropInBase):
         self.verbose_status = True
         self._eng = BatchedSolver("controller", N, dt, self.Q, self.R, self.dR, track=map.PointAndTangent,
                                   params=p, device=device, steering_delay=int(steeringDelay), **settings)
+        # one vehicle per handle: the latency form of the N = 20 kernel (four wavefronts per instance; lpvmpc.h, kernel_variant 9 --
+        # other horizons and steeringDelay > 0 take their default kernels under it)
+        self._eng.set_option("kernel_variant", 9)
 
     # CTRL:108-110 leaves G, E, L, Eu, M, q on the object; F, b exist from the constructor on (CTRL:79)
     G = property(lambda self: self._qp()["G"])

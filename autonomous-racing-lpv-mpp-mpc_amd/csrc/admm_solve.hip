@@ -76,7 +76,7 @@ struct Solver {
     // that sweep by the two wavefronts that wait for the relay (iterate4).  Same arithmetic, step for step, as the two-wavefront kernel.
     static constexpr bool kFour = (NW == 4) && !TAIL;
     static_assert(!MF || ((NW == 2 || NW == 4) && NT > 0), "the MFMA sweeps are written for the two- / four-wavefront compile-time-horizon kernels");
-    static_assert(NW != 4 || TAIL || (MF && !GS && NT >= 24 && NT % 2 == 0), "four wavefronts: MFMA sweeps, even compile-time horizon >= 24");
+    static_assert(NW != 4 || TAIL || (MF && !GS && NT >= 20 && NT % 2 == 0), "four wavefronts: MFMA sweeps, even compile-time horizon >= 20");
     static_assert(TAIL || NW == 1 || NW == 4 || (NW == 2 && NT >= 16 && NT % 2 == 0), "two wavefronts need an even compile-time horizon >= 16");
     static_assert(!TAIL || (NT > 0 && NW == 8 && !MF && !GS), "the tail kernel: compile-time horizon, eight wavefronts, no MFMA sweeps");
     static constexpr bool kLastOdd = ((NT / 2 - 1) & 1) != 0;   // parity of the last chain position (both chains have NT/2 stages)
@@ -104,6 +104,7 @@ struct Solver {
     // RED (doubles): [0, 80) as in the two-wavefront kernels; NW == 4 adds [80, 112) residual maxima of four wavefronts, [112, 144) four
     // reduction slots {sum x 4, max x 4}, [144, 160) the relay of the forward sweeps (y at chain position kHO, top / bottom)
     static constexpr int kRedSize = kFour ? 160 : 80;
+    static constexpr bool kFourSmall = kFour && 2 * (NT + 1) * 8 < 448;     // N = 20 on four wavefronts
     static constexpr int kStride = 64 * NW;
 
     const DevCfg &cfg;
@@ -127,6 +128,7 @@ struct Solver {
     double *Zd, *Yd, *Ed, *ZTd, *DYd;
     double *Zb, *Yb, *Eb, *ZTb, *DYb, *Lo, *Hi;
     double *beq;   // [8] scaled x0 (bounds of the stage-0 dynamics rows)
+    double *FX;    // [448] kFourSmall only
     double *SINK;  // [64 + 8 NS] all zero in the MFMA kernels (their sweeps load the C operand of non-owner blocks from it); the DPP two-wavefront
                    // factorisation hands a tile from wave 0 to wave 1 through it; part of the parked image
     double *Pm;    // [64] unscaled stage Hessian block 2*[Q 0; 0 R + 2 diag(dR)] (LDS copy of the weights)
@@ -259,6 +261,8 @@ struct Solver {
         }
         Lo = p; p += V; Hi = p; p += V;
         beq = p; p += 16; Pm = p; p += 64; dRl = p; p += 8; RED = p; p += kRedSize; SINK = p; p += 64 + 8 * NS;
+        FX = nullptr;
+        if constexpr (kFourSmall) { FX = p; p += 448; }     // (behind the image: the factorisation's hand-over area where VT + AT are too short for it)
         RT = WS = STG = TT = CK = nullptr;
         cs = cr = ckn = ckk = 0; ckc = cka = false; ck_alpha = ck_eps_abs = ck_eps_rel = ck_eps_p = ck_eps_d = ck_rho_tol = 0.0;
         if constexpr (TAIL) {   // behind the image: factor tiles, reduction slots, sweep scratch, staging
@@ -279,7 +283,7 @@ struct Solver {
         return (size_t)(N + 1) * ((kFixN ? 1 : 3) * kTS + (GS ? 16 : 19) * 8 + 8) + 16 + 64 + 8 + kRedSize + 64;
     }
     static constexpr __host__ __device__ size_t lds_doubles(int N) {
-        return image_doubles(N) + (TAIL ? (size_t)(N + 1) * (2 * kTS + kDenseRound * 64) + 96 + NW * 128 : 0);
+        return image_doubles(N) + (TAIL ? (size_t)(N + 1) * (2 * kTS + kDenseRound * 64) + 96 + NW * 128 : 0) + (kFourSmall ? 448 : 0);
     }
 
     // ---- problem structure ---------------------------------------------------------------------
@@ -1124,8 +1128,7 @@ struct Solver {
             // positions 0 .. kHO and keeps the operand tiles 0 .. kHO-1 that these steps leave, hands W and S^-1 of position kHO to the
             // inner one (wv >= 2) through LDS, which goes on to position kMid-1 (operand tiles kHO .. kMid-2) and takes the link tile
             // kMid-1 from the middle stage (wavefront 2).  Every value is the one the two-wavefront kernel computes.
-            double *const WDv = XT, *const WBv = DX, *const PUB = VT;       // free vectors: row weights, hand-over area (VT + AT)
-            static_assert(2 * (NT + 1) * 8 >= 448, "four wavefronts: the hand-over area of the factorisation does not fit VT + AT");
+            double *const WDv = XT, *const WBv = DX, *const PUB = kFourSmall ? FX : VT;       // free vectors: row weights, hand-over area (VT + AT; N = 20: its own 448 words)
             for (int e = opaque(tid); e < NS * 8; e += kStride) { WDv[e] = w_dyn(e); WBv[e] = w_box(e); }
             sync();
             constexpr int P = kMid;
@@ -3718,6 +3721,8 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
     return launch_one<6, 20, 2, true>(cfg, dcfg, a, stream);      // ... or the headline kernel only (no steeringDelay > 0 in this build)
 #elif defined(LPVMPC_DEV_C10)
     return launch_one<6, 10, 1>(cfg, dcfg, a, stream);      // ... or the one-wavefront controller kernel at N = 10
+#elif defined(LPVMPC_DEV_C20_4W)
+    return launch_one<6, 20, 4, true>(cfg, dcfg, a, stream);      // ... or a four-wavefront controller kernel (experiment)
 #elif defined(LPVMPC_DEV_P30_2W)
     return launch_one<5, 30, 2, true>(cfg, dcfg, a, stream);      // ... or the two-wavefront MFMA planner kernel at N = 30
 #elif defined(LPVMPC_DEV_P30_ONLY)
@@ -3726,6 +3731,15 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
     if (cfg.kind == 0) {
         // (steeringDelay > 0, CTRL:518-527: a third box row on delta in the first stages.  The MFMA kernel's element phases keep their state
         // in registers and carry two box rows per variable: such handles take the DPP kernel -- the reference runs delay 0, CMAIN:49)
+        // kernel_variant 9: the LATENCY form of the headline kernel -- its two chains relayed over four wavefronts (Solver::kFour, the planner
+        // kernels' relay at kMid = 10; the factorisation's hand-over area is its own 448 words, kFourSmall).  The arithmetic of the
+        // two-wavefront kernel step for step; an instance alone on its CU finishes 6 % sooner (B <= 256), a full chip gains nothing
+        // (two instances per CU instead of four).  Opt-in, not chosen by launch shape as the planner's forms are: the block sums of this
+        // kernel family at N = 20 (the cost normalisation's mean, the certificates' sums, the objective) associate by the number of
+        // wavefronts, so where such a sum decides a word may differ in its last bits between the forms.  Launches of a handle with
+        // straggler deferral keep the two-wavefront form (the parked image and the tail kernel are that form's).
+        if (!generic && cfg.N == 20 && kernel_variant == 9 && cfg.steering_delay == 0 && a.defer_after == 0 && !a.resume)
+            return launch_one<6, 20, 4, true>(cfg, dcfg, a, stream);
         if (!generic && cfg.N == 20) return one_wave ? launch_one<6, 20, 1>(cfg, dcfg, a, stream)
                                           : ((dpp || cfg.steering_delay > 0) ? launch_one<6, 20, 2>(cfg, dcfg, a, stream) : launch_one<6, 20, 2, true>(cfg, dcfg, a, stream));
         if (!generic && cfg.N == 10) return launch_one<6, 10, 1>(cfg, dcfg, a, stream);

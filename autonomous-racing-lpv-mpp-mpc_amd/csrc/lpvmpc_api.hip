@@ -243,7 +243,7 @@ extern "C" int lpvmpc_set_option(lpvmpc_handle *h, const char *name, int32_t val
         if (value < 0 || value > 2) return fail(h, LPVMPC_E_ARG, "warm_start must be 0 (off), 1 (previous solution) or 2 (shifted by one stage)");
         h->warm_mode = value; h->state_valid_B = 0; return LPVMPC_OK;
     }
-    if (std::strcmp(name, "kernel_variant") == 0) { if (value < 0 || value > 8) return fail(h, LPVMPC_E_ARG, "kernel_variant must be 0 .. 8"); h->force_generic = value; return LPVMPC_OK; }
+    if (std::strcmp(name, "kernel_variant") == 0) { if (value < 0 || value > 9) return fail(h, LPVMPC_E_ARG, "kernel_variant must be 0 .. 9"); h->force_generic = value; return LPVMPC_OK; }
     if (std::strcmp(name, "defer_after") == 0) {
         if (value < 0) return fail(h, LPVMPC_E_ARG, "defer_after must be >= 0 (iterations; 0 = off)");
         if (value == 0 && h->defer_after > 0 && h->dpool[0]) { int rc = lpvmpc_join(h, (void *)h->defer_stream); if (rc) return rc; }   // nothing stays parked

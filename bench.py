@@ -76,7 +76,7 @@ def main():
                     help="skip the legs outside the timed region (serial steps, batch latencies, one launch of all distinct "
                          "instances, single-solve latency): what the profiling passes use")
     ap.add_argument("--kernel-variant", type=int, default=0,
-                    help="diagnostic: lpvmpc_set_option(kernel_variant) on every engine (0 = default; 3 = the DPP two-wavefront kernel)")
+                    help="diagnostic: lpvmpc_set_option(kernel_variant) on every engine (0 = default; 3 = the DPP two-wavefront kernel; 9 = the four-wavefront latency form of the controller kernel)")
     ap.add_argument("--dump-results", default="",
                     help="rank 0 writes the gathered (u0, status, iters) of the closing all-gather to this .npz (tests compare them with "
                          "single-GPU solves of the same instances)")
@@ -420,7 +420,7 @@ def main():
                          # lives in LDS and registers, the counter traffic is a hundredth of the algorithmic bytes
                          "limiter": "valu_issue", "limiter_frac": (pmc.get("valu_timed") or {}).get("frac"),
                          "pmc_build": pmc.get("build"), "pmc_matches_build": pmc_matches_build(pmc),
-                         "kernel": ("admm_solve_kernel<%d, %d, 4, MFMA sweeps, chains relayed over four wavefronts>" % (nx, N) if planner and ((N == 40 and args.kernel_variant in (0, 8)) or (N == 30 and (args.kernel_variant == 8 or (args.kernel_variant == 0 and (B < 512 or args.defer > 0)))))
+                         "kernel": ("admm_solve_kernel<%d, %d, 4, MFMA sweeps, chains relayed over four wavefronts>" % (nx, N) if (not planner and N == 20 and args.kernel_variant == 9 and args.defer == 0) or planner and ((N == 40 and args.kernel_variant in (0, 8)) or (N == 30 and (args.kernel_variant == 8 or (args.kernel_variant == 0 and (B < 512 or args.defer > 0)))))
                                     else "admm_solve_kernel<%d, %d, 2%s>" % (nx, N, (", equilibration vectors in global memory (3 instances per CU)" if args.kernel_variant == 7 and args.defer == 0
                                                                                      else (", MFMA sweeps" if args.kernel_variant in (0, 4, 6) else ""))
                                                                             if planner else ("" if args.kernel_variant == 3 else ", MFMA sweeps"))),

@@ -175,6 +175,46 @@ def test_kernel_variants_agree(lpvmpc):
                 assert np.max(np.abs(a["uPred"][pol] - b["uPred"][pol])) < 1e-8
 
 
+def test_four_wavefront_controller_kernel_matches_the_default(lpvmpc):
+    """kernel_variant 9 (the latency form of the controller kernel at N = 20: the two chains relayed over four wavefronts) runs the
+    arithmetic of the default kernel step for step; only the block-wide sums associate differently (lpvmpc.h).  Statuses, polish
+    flags and iteration counts have to be equal, solutions to 5e-6 -- and on batches whose cost normalisation is decided by the
+    linear term's maximum (these) every word is equal, which is asserted for the iterates' outputs.  Handles with straggler
+    deferral, steeringDelay > 0 and the other horizons fall back to their default kernels under the option."""
+    from lpvmpc import workloads
+    for B, seed in ((1, 21), (7, 22), (200, 23), (600, 24)):
+        w = workloads.controller_batch(B, N=20, seed=seed)
+        outs = []
+        for variant in (0, 9):
+            eng = workloads.make_solver(w)
+            eng.set_option("kernel_variant", variant)
+            outs.append(eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"]))
+            eng.close()
+        a, b = outs
+        assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["polish"], b["polish"])
+        ok = np.isin(a["status"], (1, 2, -2))
+        assert np.max(np.abs(a["xPred"][ok] - b["xPred"][ok])) < 5e-6 and np.max(np.abs(a["uPred"][ok] - b["uPred"][ok])) < 5e-6
+        assert np.array_equal(a["xPred"], b["xPred"], equal_nan=True) and np.array_equal(a["uPred"], b["uPred"], equal_nan=True)
+    # the fall-backs: a deferring handle, a delayed-steering handle and another horizon give their default kernels' words
+    w = workloads.controller_batch(300, N=20, seed=25)
+    outs = []
+    for variant in (0, 9):
+        eng = workloads.make_solver(w); eng.set_option("kernel_variant", variant); eng.reserve(300)
+        eng.set_option("defer_pool", 600); eng.set_option("defer_after", 100)
+        outs.append(eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"]))
+        eng.close()
+    for k in ("xPred", "uPred", "status", "iters", "polish"):
+        assert np.array(outs[0][k]).tobytes() == np.array(outs[1][k]).tobytes(), k
+    w = workloads.controller_batch(64, N=10, seed=26)
+    outs = []
+    for variant in (0, 9):
+        eng = workloads.make_solver(w); eng.set_option("kernel_variant", variant)
+        outs.append(eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"]))
+        eng.close()
+    for k in ("xPred", "uPred", "status", "iters", "polish"):
+        assert np.array(outs[0][k]).tobytes() == np.array(outs[1][k]).tobytes(), k
+
+
 def test_planner_n30_global_scalings_kernel_is_bit_identical(lpvmpc):
     """The planner N = 30 kernel of kernel_variant 7 (round 3's default) keeps its three equilibration vectors in global memory (three instances per CU);
     kernel_variant 5 is the same code with them in LDS (two per CU).  Same arithmetic: every output word has to be equal, for a
