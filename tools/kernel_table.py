@@ -14,6 +14,8 @@ kTS = 72
 def lds_bytes(N, fixn, gs, tail, nw):
     red = 160 if (nw == 4 and not tail) else 80
     img = (N + 1) * ((1 if fixn else 3) * kTS + (16 if gs else 19) * 8 + 8) + 16 + 64 + 8 + red + 64
+    if nw == 4 and not tail and 2 * (N + 1) * 8 < 448:
+        img += 448        # kFourSmall: the factorisation's hand-over area
     if tail:
         img += (N + 1) * (2 * kTS + 7 * 64) + 96 + nw * 128
     return img * 8
@@ -22,6 +24,7 @@ def lds_bytes(N, fixn, gs, tail, nw):
 # (kind, N, kernel_variant, note) -> template arguments <NX, NT, NW, MF, GS, TAIL>
 SHIPS = [
     ("controller", 20, "0 (default)", (6, 20, 2, 1, 0, 0), "MFMA sweeps + factorisation, two wavefronts (twisted elimination)"),
+    ("controller", 20, "9 (latency form: one vehicle per handle, the drop-in class)", (6, 20, 4, 1, 0, 0), "the default's arithmetic, chains relayed over four wavefronts"),
     ("controller", 20, "tail (closing passes of the deferral, `defer_tail` 1)", (6, 20, 8, 0, 0, 1), "whole-CU kernel: dense K^-1 in registers, two-phase iteration, checks off the chain"),
     ("controller", 20, "3", (6, 20, 2, 0, 0, 0), "DPP sweeps, two wavefronts (round 1)"),
     ("controller", 20, "2", (6, 20, 1, 0, 0, 0), "one wavefront, factor in registers"),
