@@ -18,13 +18,18 @@ cls = {}
 worst = 0.0
 SHAPES = tuple(sys.argv[1].split(",")) if len(sys.argv) > 1 else ("oval", "L_shape", "3110", "Euge_Track")
 SEEDS = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else tuple(range(6))
+# LPVMPC_SWEEP_VARIANT=9: the controller N = 20 batches only, on the four-wavefront latency form of the kernel (lpvmpc.h, kernel_variant)
+VARIANT = int(os.environ.get("LPVMPC_SWEEP_VARIANT", "0"))
+CASES = (("controller", 20, 1), ("controller", 20, 0), ("controller", 8, 1), ("planner", 20, 1), ("planner", 30, 1), ("planner", 40, 1))
+if VARIANT == 9: CASES = CASES[:2]
 for shape in SHAPES:
     for seed in SEEDS:
-        for kind, N, lap in (("controller", 20, 1), ("controller", 20, 0), ("controller", 8, 1), ("planner", 20, 1), ("planner", 30, 1), ("planner", 40, 1)):
+        for kind, N, lap in CASES:
             B = 1024 if kind == "controller" else 512
             w = workloads.controller_batch(B, N=N, seed=100 + seed, shape=shape) if kind == "controller" else workloads.planner_batch(B, N=N, seed=200 + seed, shape=shape)
             w["lap"] = lap
             eng = workloads.make_solver(w)
+            if VARIANT: eng.set_option("kernel_variant", VARIANT)
             if kind == "controller":
                 a = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], lap)
                 ref = O.ctrl_tick_batch(w, nthreads=16)
