@@ -346,6 +346,17 @@ def main():
             engines[0].solve(one["x0"], one["u_prev"], one["vel_ref"], one["curv_s"], one["u_old"], one["max_ey"], one["cf_new"], one["lap"])
             lat1.append((time.perf_counter() - t1) * 1e3)
         extras["p50_single_solve_latency_ms"] = float(np.median(lat1[5:]))
+        # ... and on a handle of its own set to the latency form of the kernel (kernel_variant 9: four wavefronts per instance, what the
+        # drop-in controller class selects; the engines above are the throughput configuration: deferral, two wavefronts)
+        if not planner and N == 20:
+            lat_eng = workloads.make_solver(w, device=local_rank); lat_eng.set_option("kernel_variant", 9); lat_eng.reserve(1)
+            lat9 = []
+            for _ in range(30):
+                t1 = time.perf_counter()
+                lat_eng.solve(one["x0"], one["u_prev"], one["vel_ref"], one["curv_s"], one["u_old"], one["max_ey"], one["cf_new"], one["lap"])
+                lat9.append((time.perf_counter() - t1) * 1e3)
+            lat_eng.close()
+            extras["p50_single_solve_latency_ms_latency_form"] = float(np.median(lat9[5:]))
         # ... and of the drop-in classes the ROS nodes call, one vehicle at 30 / 20 Hz (CMAIN:361-363: LPVPrediction + solve per tick;
         # PMAIN: the planner at the launch file's N = 40): host arrays in, attributes out, nothing else on the GPU
         if not planner:
