@@ -213,6 +213,20 @@ def test_four_wavefront_controller_kernel_matches_the_default(lpvmpc):
         eng.close()
     for k in ("xPred", "uPred", "status", "iters", "polish"):
         assert np.array(outs[0][k]).tobytes() == np.array(outs[1][k]).tobytes(), k
+    # the opt-in warm start (row f3) on the latency form: second tick from the first one's shifted (x, y), as the default form takes it
+    w = workloads.controller_batch(96, N=20, seed=27)
+    outs = []
+    for variant in (0, 9):
+        eng = workloads.make_solver(w); eng.set_option("kernel_variant", variant); eng.set_option("warm_start", 2)
+        o0 = eng.solve(w["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"])
+        w2 = dict(w)
+        w2["x0"] = np.nan_to_num(np.array(o0["xPred"])[:, 1, :]).copy(); w2["u_old"] = np.nan_to_num(np.array(o0["uPred"])[:, 0, :]).copy()
+        outs.append(eng.solve(w2["x0"], w["u_prev"], w["vel_ref"], w["curv_s"], w2["u_old"], None, w["cf_new"], w["lap"]))
+        eng.close()
+    a, b = outs
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["polish"], b["polish"])
+    ok = np.isin(a["status"], (1, 2, -2))
+    assert np.max(np.abs(a["uPred"][ok] - b["uPred"][ok])) < 5e-6
 
 
 def test_planner_n30_global_scalings_kernel_is_bit_identical(lpvmpc):
