@@ -536,6 +536,9 @@ class LPV_MPC_Planner(_DropInBase):
         self.verbose_status = False                                       # PLAN:212-213: status print commented out
         self._eng = BatchedSolver("planner", N, dt, self.Q, self.R, self.dR, L_cf=self.L_cf,
                                   track=map.PointAndTangent, params=p, device=device, **settings)
+        # one vehicle per handle: the latency form where a horizon has one of its own (N = 20; N = 30 / 40 take four wavefronts for a
+        # lone instance by default) -- lpvmpc.h, kernel_variant 9
+        self._eng.set_option("kernel_variant", 9)
 
     Aeq = property(lambda self: self._qp()["Aeq"])                      # PLAN:108
 

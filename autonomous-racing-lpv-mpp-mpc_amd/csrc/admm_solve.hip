@@ -3773,6 +3773,8 @@ hipError_t launch_solve(const DevCfg &cfg, const DevCfg *dcfg, const SolveArgs &
         // of it iterates 5 % faster the cascade of configs[4] -- a thinning fleet, controller launches in between -- loses 7 % with it)
         return kernel_variant == 6 ? launch_one<5, 40, 2, true>(cfg, dcfg, a, stream) : launch_one<5, 40, 4, true>(cfg, dcfg, a, stream);
     }
+    // (kernel_variant 9 at N = 20: the latency form, as the controller's -- see there)
+    if (!generic && cfg.N == 20 && kernel_variant == 9 && a.defer_after == 0 && !a.resume) return launch_one<5, 20, 4, true>(cfg, dcfg, a, stream);
     if (!generic && cfg.N == 20) return dpp ? launch_one<5, 20, 2>(cfg, dcfg, a, stream) : launch_one<5, 20, 2, true>(cfg, dcfg, a, stream);     // the planner half of configs[3]
     return launch_one<5, 0, 1>(cfg, dcfg, a, stream);
 #endif

@@ -134,13 +134,15 @@ int lpvmpc_last_error_code(void);
  * 7 = round 3's default at N = 30: the DPP kernel with its three equilibration vectors in global memory (three instances per CU) for
  * batches beyond 512 instances without deferral, variant 5 otherwise; 8 = the four-wavefront planner kernels whatever the batch.  One
  * arithmetic per (kind, N) by default: an instance's result does not depend on the batch it is solved in.
- * 9 = the LATENCY form of the controller kernel at N = 20 (steeringDelay 0, no straggler deferral; every other handle and shape: as 0):
+ * 9 = the LATENCY form of the N = 20 kernels, controller (steeringDelay 0) and planner, on handles without straggler deferral (every
+ * other handle and shape: as 0):
  * the two elimination chains relayed over FOUR wavefronts, the arithmetic of the default kernel step for step.  An instance that has its
  * compute unit to itself (batches up to 256) finishes 6 % sooner, a full chip gains nothing.  Opt-in: the block-wide sums of the N = 20
  * kernels (the cost normalisation's mean, the infeasibility certificates' sums, the objective) associate by the number of wavefronts,
  * so between variants 0 and 9 a word may differ in its last bits where such a sum decides (statuses and iteration counts are equal,
  * solutions to 5e-6: tests/test_gpu_parity.py; every word equal on the batches tried, where the cost normalisation is decided by the
- * linear term's maximum).  The drop-in PathFollowingLPV_MPC (one vehicle per handle) selects it.
+ * linear term's maximum; planner N = 20: -7 % for a lone instance, -8 % at 64 ... 256).  The drop-in classes (one vehicle per handle)
+ * select it.
  * "defer_after" (iterations, 0 = off, default): STRAGGLER DEFERRAL for lpvmpc_solve_batch_dev.  One OSQP solve in a thousand
  * needs thousands of ADMM iterations where the typical one needs 50; a launch lasts as long as its slowest instance, so those
  * few hold the caller's stream for milliseconds.  With defer_after = K an instance that is still unsolved at a termination

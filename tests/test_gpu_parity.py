@@ -213,6 +213,18 @@ def test_four_wavefront_controller_kernel_matches_the_default(lpvmpc):
         eng.close()
     for k in ("xPred", "uPred", "status", "iters", "polish"):
         assert np.array(outs[0][k]).tobytes() == np.array(outs[1][k]).tobytes(), k
+    # the planner's N = 20 kernel has the same latency form (its cost normalisation follows the SUM for this tuning, so the block sums'
+    # association shows: decisions equal, solutions to round-off)
+    w = workloads.planner_batch(160, N=20, seed=28)
+    outs = []
+    for variant in (0, 9):
+        eng = workloads.make_solver(w); eng.set_option("kernel_variant", variant)
+        outs.append(eng.solve(w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"]))
+        eng.close()
+    a, b = outs
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["polish"], b["polish"])
+    ok = np.isin(a["status"], (1, 2, -2))
+    assert np.max(np.abs(a["xPred"][ok] - b["xPred"][ok])) < 5e-6 and np.max(np.abs(a["uPred"][ok] - b["uPred"][ok])) < 5e-6
     # the opt-in warm start (row f3) on the latency form: second tick from the first one's shifted (x, y), as the default form takes it
     w = workloads.controller_batch(96, N=20, seed=27)
     outs = []

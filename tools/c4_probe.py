@@ -12,7 +12,8 @@ from lpvmpc import workloads
 def run(w, variant, reps):
     eng = workloads.make_solver(w)
     eng.set_option("kernel_variant", variant)
-    args = (w["x0"], w["u_prev"], w.get("vel_ref"), w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"])
+    args = (w["x0"], w["u_prev"], w.get("vel_ref"), w["curv_s"], w["u_old"], None, w["cf_new"], w["lap"]) if w.get("max_ey") is None else \
+           (w["x0"], w["u_prev"], None, w["curv_s"], w["u_old"], w["max_ey"])
     o = eng.solve(*args)
     ts = []
     for _ in range(reps):
@@ -27,4 +28,14 @@ for B in (1, 16, 64, 256, 1024, 4096):
     same = all(np.array(o2[k]).tobytes() == np.array(o4[k]).tobytes() for k in ("xPred", "uPred", "status", "iters", "polish"))
     dx = float(np.nanmax(np.abs(np.array(o2["xPred"]) - np.array(o4["xPred"]))))
     print("B=%-5d two wavefronts %.3f ms | four %.3f ms | %s (status equal %s, iterations equal %s, max |dx| %.2e; mean iterations %.1f)"
+          % (B, t2, t4, "every word equal" if same else "DIFFERENT", np.array_equal(o2["status"], o4["status"]), np.array_equal(o2["iters"], o4["iters"]), dx, float(np.mean(o2["iters"]))))
+
+for B in (1, 64, 256, 1024):
+    w = workloads.planner_batch(B, N=20, seed=12)
+    o2, t2 = run(w, 0, 10)
+    o4, t4 = run(w, 9, 10)
+    same = all(np.array(o2[k]).tobytes() == np.array(o4[k]).tobytes() for k in ("xPred", "uPred", "status", "iters", "polish"))
+    fin = np.isfinite(np.array(o2["xPred"])).all(axis=(1, 2)) & np.isfinite(np.array(o4["xPred"])).all(axis=(1, 2))
+    dx = float(np.max(np.abs(np.array(o2["xPred"])[fin] - np.array(o4["xPred"])[fin]))) if fin.any() else 0.0
+    print("planner N=20 B=%-5d two wavefronts %.3f ms | four %.3f ms | %s (status equal %s, iterations equal %s, max |dx| %.2e; mean iterations %.1f)"
           % (B, t2, t4, "every word equal" if same else "DIFFERENT", np.array_equal(o2["status"], o4["status"]), np.array_equal(o2["iters"], o4["iters"]), dx, float(np.mean(o2["iters"]))))

@@ -32,6 +32,7 @@ SHIPS = [
     ("controller", 8, "0", (6, 8, 1, 0, 0, 0), "one wavefront, factor in registers (the launch file's horizon)"),
     ("controller", "other <= 52", "0 / 1", (6, 0, 1, 0, 0, 0), "run-time horizon, factor tiles in LDS"),
     ("planner", 20, "0", (5, 20, 2, 1, 0, 0), "MFMA sweeps + factorisation, two wavefronts"),
+    ("planner", 20, "9 (latency form)", (5, 20, 4, 1, 0, 0), "the default's arithmetic, chains relayed over four wavefronts"),
     ("planner", 20, "tail", (5, 20, 8, 0, 0, 1), "whole-CU kernel (as the controller's)"),
     ("planner", 20, "3", (5, 20, 2, 0, 0, 0), "DPP sweeps, two wavefronts"),
     ("planner", 30, "0 (B < 512, or deferral) / 8", (5, 30, 4, 1, 0, 0), "MFMA sweeps, chains relayed over four wavefronts"),
