@@ -18,10 +18,10 @@ cls = {}
 worst = 0.0
 SHAPES = tuple(sys.argv[1].split(",")) if len(sys.argv) > 1 else ("oval", "L_shape", "3110", "Euge_Track")
 SEEDS = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else tuple(range(6))
-# LPVMPC_SWEEP_VARIANT=9: the controller N = 20 batches only, on the four-wavefront latency form of the kernel (lpvmpc.h, kernel_variant)
+# LPVMPC_SWEEP_VARIANT=9: the N = 20 batches only, on the four-wavefront latency form of their kernels (lpvmpc.h, kernel_variant)
 VARIANT = int(os.environ.get("LPVMPC_SWEEP_VARIANT", "0"))
 CASES = (("controller", 20, 1), ("controller", 20, 0), ("controller", 8, 1), ("planner", 20, 1), ("planner", 30, 1), ("planner", 40, 1))
-if VARIANT == 9: CASES = CASES[:2]
+if VARIANT == 9: CASES = (CASES[0], CASES[1], CASES[3])        # (the N = 20 kernels have the form: controller, both laps, and planner)
 for shape in SHAPES:
     for seed in SEEDS:
         for kind, N, lap in CASES:
