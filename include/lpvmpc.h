@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LPVMPC_VERSION 200            /* 0.2.0: round 5 removed the lpvmpc_lane_* exports (an ABI break), round 6 adds lpvmpc_defer_stats */
+#define LPVMPC_VERSION 200            /* 0.2.0: round 5 removed the lpvmpc_lane_* exports (an ABI break), round 6 adds lpvmpc_defer_stats and kernel_variant 9 */
 
 #define LPVMPC_KIND_CONTROLLER 0      /* PathFollowingLPV_MPC  (CTRL:30-258) */
 #define LPVMPC_KIND_PLANNER    1      /* LPV_MPC_Planner       (PLAN:29-320) */
